@@ -1,0 +1,259 @@
+/*
+ * obhip.h -- C ABI of the MI355X-native outerbase hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one piece of
+ * the reference's Rcpp-module surface (RCPP_MODULE(obmod),
+ * src/interfaceR.cpp:661-793 of MattPlumlee/outerbase) or of the C++ objects
+ * behind it.  The reference interface each function replaces is cited as
+ * file:line relative to the reference checkout.  INTEGRATION.md shows the
+ * Rcpp glue a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C, opaque handles, caller owns every host buffer, the library
+ *     owns every device buffer behind a handle;
+ *   - every function returns 0 on success, non-zero on failure; the message
+ *     is in obhip_last_error() (thread-local).  Nothing throws across the ABI;
+ *   - matrices that cross the ABI on the HOST side are column-major FP64,
+ *     `terms` are column-major p x d unsigned 64-bit 0-based levels, exactly
+ *     like the Armadillo mat / umat the reference marshals
+ *     (SURVEY.md section 8b "Data marshalling");
+ *   - functions with the suffix _dev take DEVICE pointers (HBM resident
+ *     inputs/outputs) and enqueue on the stream set by obhip_set_stream();
+ *     they do not synchronise.  Functions without the suffix take host
+ *     pointers and return after the result is in the host buffer;
+ *   - there is NO CPU fallback: without a visible gfx950 device every
+ *     device-touching call fails with OBHIP_ERR_NO_DEVICE.
+ */
+#ifndef OBHIP_H
+#define OBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OBHIP_OK 0
+#define OBHIP_ERR_INVALID 1     /* bad argument (std::range_error / Armadillo
+                                   size error in the reference) */
+#define OBHIP_ERR_NO_DEVICE 2   /* no HIP device / kernels unavailable */
+#define OBHIP_ERR_HIP 3         /* a HIP runtime call failed */
+#define OBHIP_ERR_STATE 4       /* object not ready (e.g. knots not set) */
+#define OBHIP_ERR_NUMERIC 5     /* non-finite / not positive definite */
+
+/* covariance kinds: listcov() R/fitting.R:6-8, setcovfs
+ * src/interfaceR.cpp:53-73 */
+#define OBHIP_COV_MAT25 0
+#define OBHIP_COV_MAT25POW 1
+#define OBHIP_COV_MAT25ANG 2
+
+typedef struct obhip_model obhip_model; /* class outermod, modandbase.h:9-54 */
+typedef struct obhip_basis obhip_basis; /* class outerbase, modandbase.h:57-125 */
+typedef struct obhip_terms obhip_terms; /* a umat `terms` resident on device */
+
+/* ---- library ----------------------------------------------------------- */
+int obhip_abi_version(void);
+const char *obhip_last_error(void);
+int obhip_device_count(int *count);
+int obhip_set_device(int device);
+/* hipStream_t to launch on (NULL = default stream). */
+int obhip_set_stream(void *hip_stream);
+int obhip_synchronize(void);
+/* Per-kernel hipEvent timing (used by bench.py for the roofline line). */
+int obhip_profile_enable(int on);
+int obhip_profile_reset(void);
+int obhip_profile_get(const char *kernel, uint64_t *launches, double *total_ms);
+
+/* ---- covariance functions (classes covf_mat25 / covf_mat25pow /
+ * covf_mat25ang, src/covfuncs.h:34-67; module rows interfaceR.cpp:764-791) */
+int obhip_cov_numhyp(int kind, int *numhyp);
+/* hyp0, hyplb, hypub, hypvar (numhyp each), lowbnd, uppbnd
+ * (covfuncs.cpp:87-111,166-195,254-283) */
+int obhip_cov_info(int kind, double *hyp0, double *hyplb, double *hypub,
+                   double *hypvar, double *lowbnd, double *uppbnd);
+/* covf::cov (covfuncs.cpp:113-126,197-212,285-310): out is n1 x n2
+ * column-major.  Host arithmetic (knot-sized problems). */
+int obhip_cov(int kind, const double *hyp, const double *x1, uint64_t n1,
+              const double *x2, uint64_t n2, double *out);
+/* covf::lpdf (covfuncs.cpp:35-50) */
+int obhip_cov_hyplpdf(int kind, const double *hyp, double *out);
+
+/* ---- outermod ---------------------------------------------------------- */
+/* new(outermod) + setcovfs(om, covnames): interfaceR.cpp:53-73,
+ * outermod::hyp_init modandbase.cpp:128-153 */
+int obhip_model_create(obhip_model **out, uint64_t d, const int *kinds);
+int obhip_model_destroy(obhip_model *m);
+/* setknot(om, knotlist): interfaceR.cpp:94-149.  knotptst has d+1 entries
+ * (modandbase.h:18), knotpt has knotptst[d]. Triggers outermod::build. */
+int obhip_model_set_knots(obhip_model *m, const uint64_t *knotptst,
+                          const double *knotpt);
+/* om$updatehyp(hyp): outermod::hyp_set modandbase.cpp:161-202 */
+int obhip_model_set_hyp(obhip_model *m, const double *hyp, uint64_t nhyp);
+/* gethyp(om): interfaceR.cpp:167-180 */
+int obhip_model_get_hyp(const obhip_model *m, double *hyp);
+/* d, M = total knots, mmax = max knots per dim, nhyp */
+int obhip_model_dims(const obhip_model *m, uint64_t *d, uint64_t *M,
+                     uint64_t *mmax, uint64_t *nhyp);
+/* results of outermod::build (modandbase.cpp:210-276): rotmat is
+ * mmax x M column-major (modandbase.h:44), basisvar M (:12), maxlevel d
+ * (:29). */
+int obhip_model_get_rotation(const obhip_model *m, double *rotmat,
+                             double *basisvar, int64_t *maxlevel);
+/* Replace the eigen-decomposition results with caller-supplied ones (the
+ * reference takes them from LAPACK via arma::eig_sym, modandbase.cpp:236;
+ * parity tests inject the oracle's so that both sides share one rotation). */
+int obhip_model_set_rotation(obhip_model *m, const double *rotmat,
+                             const double *basisvar, const int64_t *maxlevel);
+/* om$selectterms(numele): modandbase.cpp:387-440.  seed==0: the reference's
+ * RNG shuffle (modandbase.cpp:408) is replaced by the identity permutation;
+ * seed!=0: SplitMix64-driven pick among the near-best candidates.
+ * terms_out: p x d column-major. */
+int obhip_model_select_terms(const obhip_model *m, uint64_t p, uint64_t seed,
+                             uint64_t *terms_out);
+/* om$getvar(terms): modandbase.cpp:350-356 */
+int obhip_model_term_var(const obhip_model *m, const uint64_t *terms,
+                         uint64_t p, double *out);
+/* om$hyplpdf(hyp): modandbase.cpp:89-99 */
+int obhip_model_hyplpdf(const obhip_model *m, const double *hyp, uint64_t nhyp,
+                        double *out);
+
+/* ---- terms ------------------------------------------------------------- */
+/* Upload a umat `terms` (p x d, column-major, 0-based levels) once; the
+ * reference passes it by value on every call (modandbase.cpp:649,677,700). */
+int obhip_terms_create(obhip_terms **out, const obhip_model *m,
+                       const uint64_t *terms, uint64_t p);
+int obhip_terms_destroy(obhip_terms *t);
+int obhip_terms_info(const obhip_terms *t, uint64_t *p, uint64_t *d,
+                     uint64_t *nnz_total, uint64_t *max_nnz);
+/* highest level used per dimension (d entries) */
+int obhip_terms_maxlevels(const obhip_terms *t, int64_t *levels);
+
+/* ---- outerbase --------------------------------------------------------- */
+/* new(outerbase, om, x): modandbase.cpp:459-480 + build :547-626.
+ * x is n x d column-major with leading dimension ldx (host).  levelcap
+ * (d entries, or NULL) bounds the levels evaluated per dimension; NULL = all
+ * knots-1 levels as the reference does.  The basis is built on the current
+ * device. */
+int obhip_basis_create(obhip_basis **out, const obhip_model *m, const double *x,
+                       uint64_t n, uint64_t ldx, const int64_t *levelcap);
+/* same with x already in HBM (column-major, ld = n) */
+int obhip_basis_create_dev(obhip_basis **out, const obhip_model *m,
+                           const double *d_x, uint64_t n,
+                           const int64_t *levelcap);
+/* ob$build(): rebuild after the model's hyp/knots changed
+ * (modandbase.cpp:547; vignettes/learning.Rmd:48-54) */
+int obhip_basis_rebuild(obhip_basis *b);
+int obhip_basis_destroy(obhip_basis *b);
+int obhip_basis_dims(const obhip_basis *b, uint64_t *n, uint64_t *d,
+                     uint64_t *ncols_stored);
+/* ob$getbase(k), k 1-based: modandbase.cpp:634-639; out n x m_k col-major */
+int obhip_basis_getbase(const obhip_basis *b, uint64_t k, double *out);
+/* ob$getmat(terms): getm_ linalg.cpp:647-715; out n x p col-major */
+int obhip_basis_getmat(const obhip_basis *b, const obhip_terms *t, double *out);
+/* ob$matmul(terms, a) / outerbase::mm: prodmm_ linalg.cpp:57-131 (vector)
+ * and :481-557 (matrix, ncol > 1; a is p x ncol, out n x ncol) */
+int obhip_basis_mm(const obhip_basis *b, const obhip_terms *t, const double *a,
+                   uint64_t ncol, double *out);
+/* ob$tmatmul(terms, a) / outerbase::tmm: tprodmm_ linalg.cpp:286-355 and
+ * :567-637 (a is n x ncol, out p x ncol) */
+int obhip_basis_tmm(const obhip_basis *b, const obhip_terms *t, const double *a,
+                    uint64_t ncol, double *out);
+/* outerbase::sqmm modandbase.cpp:784-790, sqtmm/sqtmmm :816-837,
+ * sqcolsums :863-867, residvar :889-895 */
+int obhip_basis_sqmm(const obhip_basis *b, const obhip_terms *t,
+                     const double *a, uint64_t ncol, double *out);
+int obhip_basis_sqtmm(const obhip_basis *b, const obhip_terms *t,
+                      const double *a, uint64_t ncol, double *out);
+int obhip_basis_sqcolsums(const obhip_basis *b, const obhip_terms *t,
+                          double *out);
+int obhip_basis_residvar(const obhip_basis *b, const obhip_terms *t,
+                         const obhip_model *m, double *out);
+
+/* device-pointer forms (single vector) used by the fit drivers, the
+ * benchmark and the multi-GPU path */
+int obhip_basis_mm_dev(const obhip_basis *b, const obhip_terms *t,
+                       const double *d_a, double *d_out, int squared);
+int obhip_basis_tmm_dev(const obhip_basis *b, const obhip_terms *t,
+                        const double *d_a, double *d_out, int squared);
+
+/* ---- Gram / Newton ("back end A") -------------------------------------- */
+/* G = B^T B (loglik_std::hess without its e^{-2 sigma}, loglik_std.cpp:
+ * 170-173) and g = B^T y (loglik_std::update at coeff = 0, :100-120).
+ * d_G: p x p (symmetric, full storage), d_g: p, both DEVICE buffers owned by
+ * the caller so that a multi-GPU caller can all-reduce them.  d_y may be
+ * NULL (then d_g is untouched). */
+int obhip_gram_dev(const obhip_basis *b, const obhip_terms *t,
+                   const double *d_y, double *d_G, double *d_g);
+/* bytes of device workspace obhip_newton_solve_dev needs for p terms */
+int obhip_newton_workspace_bytes(uint64_t p, uint64_t *bytes);
+/* One Newton step from coeff = 0 of lpdfvec(loglik_std, logpr_gauss)
+ * (lpdf::optnewton fit.cpp:98-131): H = e^{-2 sigma} G + diag(1/(sd e^rho)^2)
+ * (loglik_std.cpp:170-173, logpr_gauss.cpp:153-158, fit.cpp:503-512),
+ * theta = solve(H, e^{-2 sigma} g) by Cholesky + two triangular solves.
+ * d_G is overwritten by the Cholesky factor (lower triangle, row-major).
+ * d_theta: p (device).  d_diagH (p, may be NULL) receives diag(H)
+ * (lpdfvec::diaghess_, fit.cpp:557-566). */
+int obhip_newton_solve_dev(const obhip_model *m, const obhip_terms *t,
+                           double *d_G, const double *d_g, double sigma,
+                           double rho, double *d_theta, double *d_diagH,
+                           void *d_workspace, uint64_t workspace_bytes);
+/* host-buffer convenience: the whole back end A on one device.
+ * theta (p), diagH (p, may be NULL), H_out (p x p col-major, may be NULL). */
+int obhip_fit_newton(const obhip_basis *b, const obhip_terms *t,
+                     const obhip_model *m, const double *y, double sigma,
+                     double rho, double *theta, double *diagH, double *H_out);
+
+/* ---- matrix-free PCG ("back end B", what obfit runs) -------------------- */
+/* lpdf::optcg (fit.cpp:37-96) on lpdfvec(logpr_gauss, loglik_gauss)
+ * (loglik_gauss.cpp:110-157), domargadj = false.  theta is in/out (host, p);
+ * iters_out receives the iteration count; diagH (p, may be NULL) the
+ * preconditioner (lpdfvec::diaghess_). */
+int obhip_fit_cg(const obhip_basis *b, const obhip_terms *t,
+                 const obhip_model *m, const double *y, double sigma,
+                 double rho, double tol, uint64_t maxit, double *theta,
+                 uint64_t *iters_out, double *diagH, double *val_out);
+/* same with y / theta / diagH in HBM; all_reduce (may be NULL) is called on
+ * (device pointer, count) whenever a p-vector or a scalar block must be
+ * summed over ranks (multi-GPU row sharding). */
+typedef int (*obhip_allreduce_fn)(void *user, double *d_buf, uint64_t count);
+int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *t,
+                     const obhip_model *m, const double *d_y, double sigma,
+                     double rho, double tol, uint64_t maxit, double *d_theta,
+                     uint64_t *iters_out, double *d_diagH, double *val_out,
+                     obhip_allreduce_fn all_reduce, void *user);
+
+/* ---- predictor ---------------------------------------------------------- */
+/* predictor$update(x) + $mean() (+ $var() of pred_gauss):
+ * loglik_gauss.cpp:214-227, loglik_std.cpp:239-248.  The basis at xnew is
+ * evaluated and contracted with theta in one fused kernel; it is never
+ * written to HBM.  d_coeffvar (p) may be NULL; then d_var is untouched;
+ * otherwise var = B^2 coeffvar + e^{2 sigma}. */
+int obhip_predict_dev(const obhip_model *m, const obhip_terms *t,
+                      const double *d_theta, const double *d_x, uint64_t n,
+                      double *d_mean, const double *d_coeffvar, double sigma,
+                      double *d_var);
+int obhip_predict(const obhip_model *m, const obhip_terms *t,
+                  const double *theta, const double *x, uint64_t n,
+                  uint64_t ldx, double *mean, const double *coeffvar,
+                  double sigma, double *var);
+/* ---- synthetic workload of BASELINE.md section 3 (benchmark input) ------ */
+/* rows [row0, row0+n) of the counter-based SplitMix64 stream; d_x is n x d
+ * column-major, d_y n (raw, not standardised).  kinds: d entries. */
+int obhip_synth_xy_dev(uint64_t seed, uint64_t row0, uint64_t n, uint64_t d,
+                       const int *kinds, double *d_x, double *d_y);
+/* sum and sum of squares of a device vector (for standardising y) */
+int obhip_sum_sumsq_dev(const double *d_v, uint64_t n, double *d_out2);
+/* v = (v - cent) / sca in place */
+int obhip_affine_dev(double *d_v, uint64_t n, double cent, double sca);
+
+/* ---- device memory helpers for non-torch callers (Rcpp glue) ------------ */
+int obhip_malloc(void **d_ptr, uint64_t bytes);
+int obhip_free(void *d_ptr);
+int obhip_memcpy_h2d(void *d_dst, const void *src, uint64_t bytes);
+int obhip_memcpy_d2h(void *dst, const void *d_src, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBHIP_H */

@@ -1,0 +1,506 @@
+// C ABI of libobhip: outerbase objects, the Gram/Newton and PCG fit drivers and
+// the predictor.  Host logic only; every arithmetic pass over n rows is one of
+// the HIP kernels in kernels_*.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "obhip_internal.h"
+
+using namespace obhip;
+
+namespace {
+
+// om.getvar(terms) (modandbase.cpp:350-356) from the cached levels
+std::vector<double> term_var(const obhip_model &m, const obhip_terms &t) {
+  std::vector<double> v(t.p);
+  for (uint64_t k = 0; k < t.p; ++k) {
+    double s = 0;
+    for (uint64_t l = 0; l < t.d; ++l) s += m.basisvar[m.knotptst[l] + t.lev[k * t.d + l]];
+    v[k] = std::exp(s);
+  }
+  return v;
+}
+
+// logpr_gauss::diaghess (logpr_gauss.cpp:122-124)
+std::vector<double> prior_prec(const obhip_model &m, const obhip_terms &t, double rho) {
+  std::vector<double> v = term_var(m, t);
+  const double sca = std::exp(rho);
+  for (double &x : v) {
+    const double sd = std::sqrt(x) * sca;
+    x = 1.0 / (sd * sd);
+  }
+  return v;
+}
+
+int check_compat(const obhip_model *m, const obhip_terms *t) {
+  if (!m || !t) return fail(OBHIP_ERR_INVALID, "null model/terms");
+  if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  if (t->d != m->d) return fail(OBHIP_ERR_INVALID, "terms and model dimensions differ");
+  for (uint64_t l = 0; l < m->d; ++l)
+    if (t->maxlev[l] >= (int64_t)m->m_of(l))
+      return fail(OBHIP_ERR_INVALID, "terms use a level beyond the model's knots");
+  return 0;
+}
+
+int basis_setup(obhip_basis *b, const obhip_model *m, const int64_t *levelcap) {
+  std::vector<int64_t> cap;
+  if (levelcap) cap.assign(levelcap, levelcap + m->d);
+  OB_TRY(b->md.build(*m, cap));
+  const uint64_t tiles = b->n_pad / kTileRows;
+  OB_TRY(b->bm.alloc(tiles * b->md.Mc * kTileRows));
+  OB_TRY(b->scale.alloc(b->n_pad));
+  return launch_build_basis(*b);
+}
+
+double *g_scratch = nullptr;  // 2048 doubles for two-stage reductions (never freed)
+int scratch(double **p) {
+  if (!g_scratch) OB_HIP(hipMalloc((void **)&g_scratch, 2048 * sizeof(double)));
+  *p = g_scratch;
+  return 0;
+}
+
+int d2h(void *dst, const void *src, size_t bytes) {
+  OB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cur_stream()));
+  OB_HIP(hipStreamSynchronize(cur_stream()));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- outerbase ------------------------------------------------------------------
+int obhip_basis_create(obhip_basis **out, const obhip_model *m, const double *x, uint64_t n,
+                       uint64_t ldx, const int64_t *levelcap) {
+  if (!out || !m || !x || n == 0 || ldx < n) return fail(OBHIP_ERR_INVALID, "basis_create: bad argument");
+  if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  OB_TRY(require_device());
+  obhip_basis *b = new obhip_basis();
+  b->model = m;
+  b->n = n;
+  b->n_pad = (n + kTileRows - 1) / kTileRows * kTileRows;
+  b->d = m->d;
+  int rc = 0;
+  if (ldx == n) {
+    rc = b->x.upload(x, n * m->d);
+  } else {
+    std::vector<double> xc(n * m->d);
+    for (uint64_t l = 0; l < m->d; ++l) std::memcpy(&xc[l * n], x + l * ldx, n * sizeof(double));
+    rc = b->x.upload(xc.data(), xc.size());
+  }
+  if (!rc) rc = basis_setup(b, m, levelcap);
+  if (rc) {
+    delete b;
+    return rc;
+  }
+  *out = b;
+  return 0;
+}
+
+int obhip_basis_create_dev(obhip_basis **out, const obhip_model *m, const double *d_x, uint64_t n,
+                           const int64_t *levelcap) {
+  if (!out || !m || !d_x || n == 0) return fail(OBHIP_ERR_INVALID, "basis_create_dev: bad argument");
+  if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  OB_TRY(require_device());
+  obhip_basis *b = new obhip_basis();
+  b->model = m;
+  b->n = n;
+  b->n_pad = (n + kTileRows - 1) / kTileRows * kTileRows;
+  b->d = m->d;
+  int rc = b->x.alloc(n * m->d);
+  if (!rc && hipMemcpyAsync(b->x.p, d_x, n * m->d * sizeof(double), hipMemcpyDeviceToDevice,
+                            cur_stream()) != hipSuccess)
+    rc = fail(OBHIP_ERR_HIP, "copy of x failed");
+  if (!rc) rc = basis_setup(b, m, levelcap);
+  if (rc) {
+    delete b;
+    return rc;
+  }
+  *out = b;
+  return 0;
+}
+
+int obhip_basis_rebuild(obhip_basis *b) {
+  if (!b) return fail(OBHIP_ERR_INVALID, "null basis");
+  std::vector<int64_t> cap = b->md.cap;
+  if (b->model->d != b->d) return fail(OBHIP_ERR_INVALID, "model dimension changed");
+  return basis_setup(b, b->model, cap.data());
+}
+
+int obhip_basis_destroy(obhip_basis *b) {
+  if (b) (void)hipStreamSynchronize(cur_stream());
+  delete b;
+  return 0;
+}
+
+int obhip_basis_dims(const obhip_basis *b, uint64_t *n, uint64_t *d, uint64_t *ncols_stored) {
+  if (!b) return fail(OBHIP_ERR_INVALID, "null basis");
+  if (n) *n = b->n;
+  if (d) *d = b->d;
+  if (ncols_stored) *ncols_stored = b->md.Mc;
+  return 0;
+}
+
+int obhip_basis_getbase(const obhip_basis *b, uint64_t k, double *out) {
+  if (!b || !out) return fail(OBHIP_ERR_INVALID, "getbase: null argument");
+  if (k < 1 || k > b->d) return fail(OBHIP_ERR_INVALID, "getbase: dimension out of range (1-based)");
+  const uint64_t m = b->model->m_of(k - 1);
+  DevBuf<double> tmp;
+  OB_TRY(tmp.alloc(b->n * m));
+  OB_TRY(launch_getbase(*b, k - 1, tmp.p));
+  return d2h(out, tmp.p, b->n * m * sizeof(double));
+}
+
+int obhip_basis_getmat(const obhip_basis *b, const obhip_terms *t, double *out) {
+  if (!b || !t || !out) return fail(OBHIP_ERR_INVALID, "getmat: null argument");
+  OB_TRY(check_compat(b->model, t));
+  DevBuf<double> tmp;
+  OB_TRY(tmp.alloc(b->n * t->p));
+  OB_TRY(launch_getmat(*b, *const_cast<obhip_terms *>(t), tmp.p));
+  return d2h(out, tmp.p, b->n * t->p * sizeof(double));
+}
+
+static int mm_host(const obhip_basis *b, const obhip_terms *t, const double *a, uint64_t ncol,
+                   double *out, bool transposed, bool squared) {
+  if (!b || !t || !a || !out || ncol == 0) return fail(OBHIP_ERR_INVALID, "matmul: bad argument");
+  OB_TRY(check_compat(b->model, t));
+  const uint64_t nin = transposed ? b->n : t->p, nout = transposed ? t->p : b->n;
+  DevBuf<double> din, dout;
+  OB_TRY(dout.alloc(nout));
+  for (uint64_t c = 0; c < ncol; ++c) {
+    OB_TRY(din.upload(a + c * nin, nin));
+    if (transposed)
+      OB_TRY(launch_tmm(*b, *const_cast<obhip_terms *>(t), din.p, dout.p, squared));
+    else
+      OB_TRY(launch_mm(*b, *const_cast<obhip_terms *>(t), din.p, dout.p, squared));
+    OB_TRY(d2h(out + c * nout, dout.p, nout * sizeof(double)));
+  }
+  return 0;
+}
+
+int obhip_basis_mm(const obhip_basis *b, const obhip_terms *t, const double *a, uint64_t ncol,
+                   double *out) {
+  return mm_host(b, t, a, ncol, out, false, false);
+}
+int obhip_basis_tmm(const obhip_basis *b, const obhip_terms *t, const double *a, uint64_t ncol,
+                    double *out) {
+  return mm_host(b, t, a, ncol, out, true, false);
+}
+int obhip_basis_sqmm(const obhip_basis *b, const obhip_terms *t, const double *a, uint64_t ncol,
+                     double *out) {
+  return mm_host(b, t, a, ncol, out, false, true);
+}
+int obhip_basis_sqtmm(const obhip_basis *b, const obhip_terms *t, const double *a, uint64_t ncol,
+                      double *out) {
+  return mm_host(b, t, a, ncol, out, true, true);
+}
+
+int obhip_basis_sqcolsums(const obhip_basis *b, const obhip_terms *t, double *out) {
+  if (!b || !t || !out) return fail(OBHIP_ERR_INVALID, "sqcolsums: null argument");
+  std::vector<double> ones(b->n, 1.0);  // modandbase.cpp:864-866
+  return mm_host(b, t, ones.data(), 1, out, true, true);
+}
+
+int obhip_basis_residvar(const obhip_basis *b, const obhip_terms *t, const obhip_model *m,
+                         double *out) {
+  if (!b || !t || !m || !out) return fail(OBHIP_ERR_INVALID, "residvar: null argument");
+  OB_TRY(check_compat(m, t));
+  const std::vector<double> v = term_var(*m, *t);
+  OB_TRY(mm_host(b, t, v.data(), 1, out, false, true));
+  for (uint64_t i = 0; i < b->n; ++i) out[i] = 1.0 - out[i];  // modandbase.cpp:891
+  return 0;
+}
+
+int obhip_basis_mm_dev(const obhip_basis *b, const obhip_terms *t, const double *d_a, double *d_out,
+                       int squared) {
+  if (!b || !t || !d_a || !d_out) return fail(OBHIP_ERR_INVALID, "mm_dev: null argument");
+  OB_TRY(check_compat(b->model, t));
+  return launch_mm(*b, *const_cast<obhip_terms *>(t), d_a, d_out, squared != 0);
+}
+
+int obhip_basis_tmm_dev(const obhip_basis *b, const obhip_terms *t, const double *d_a, double *d_out,
+                        int squared) {
+  if (!b || !t || !d_a || !d_out) return fail(OBHIP_ERR_INVALID, "tmm_dev: null argument");
+  OB_TRY(check_compat(b->model, t));
+  return launch_tmm(*b, *const_cast<obhip_terms *>(t), d_a, d_out, squared != 0);
+}
+
+// ---- Gram / Newton ----------------------------------------------------------------
+int obhip_gram_dev(const obhip_basis *b, const obhip_terms *t, const double *d_y, double *d_G,
+                   double *d_g) {
+  if (!b || !t || !d_G) return fail(OBHIP_ERR_INVALID, "gram_dev: null argument");
+  if (d_y && !d_g) return fail(OBHIP_ERR_INVALID, "gram_dev: d_g is null");
+  OB_TRY(check_compat(b->model, t));
+  OB_TRY(launch_gram(*b, *const_cast<obhip_terms *>(t), d_G));
+  if (d_y) OB_TRY(launch_tmm(*b, *const_cast<obhip_terms *>(t), d_y, d_g, false));
+  return 0;
+}
+
+int obhip_newton_workspace_bytes(uint64_t p, uint64_t *bytes) {
+  if (!bytes) return fail(OBHIP_ERR_INVALID, "null argument");
+  // z + info (Cholesky) + prior precision + scaled right-hand side
+  *bytes = newton_workspace_bytes(p) + 2 * p * sizeof(double);
+  return 0;
+}
+
+int obhip_newton_solve_dev(const obhip_model *m, const obhip_terms *t, double *d_G, const double *d_g,
+                           double sigma, double rho, double *d_theta, double *d_diagH,
+                           void *d_workspace, uint64_t workspace_bytes) {
+  if (!m || !t || !d_G || !d_g || !d_theta || !d_workspace)
+    return fail(OBHIP_ERR_INVALID, "newton_solve_dev: null argument");
+  OB_TRY(check_compat(m, t));
+  const uint64_t p = t->p;
+  uint64_t need = 0;
+  obhip_newton_workspace_bytes(p, &need);
+  if (workspace_bytes < need) return fail(OBHIP_ERR_INVALID, "newton_solve_dev: workspace too small");
+  double *d_prec = (double *)d_workspace;
+  double *d_rhs = d_prec + p;
+  void *d_cholws = d_rhs + p;
+  const std::vector<double> prec = prior_prec(*m, *t, rho);
+  const double e2 = std::exp(-2.0 * sigma);
+  hipStream_t st = cur_stream();
+  OB_HIP(hipMemcpyAsync(d_prec, prec.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
+  OB_HIP(hipStreamSynchronize(st));  // prec is a local
+  // H = e^{-2 sigma} G + diag(prec)   (loglik_std.cpp:170-173 + logpr_gauss.cpp:153-158)
+  OB_TRY(launch_form_hessian(p, d_G, d_prec, e2, d_diagH));
+  // grad at coeff = 0: e^{-2 sigma} B^T y   (loglik_std.cpp:113-116)
+  OB_HIP(hipMemcpyAsync(d_rhs, d_g, p * sizeof(double), hipMemcpyDeviceToDevice, st));
+  OB_TRY(launch_scale(d_rhs, p, e2));
+  return launch_newton_solve(p, d_G, d_rhs, d_theta, d_cholws, newton_workspace_bytes(p));
+}
+
+int obhip_fit_newton(const obhip_basis *b, const obhip_terms *t, const obhip_model *m,
+                     const double *y, double sigma, double rho, double *theta, double *diagH,
+                     double *H_out) {
+  if (!b || !t || !m || !y || !theta) return fail(OBHIP_ERR_INVALID, "fit_newton: null argument");
+  OB_TRY(check_compat(m, t));
+  const uint64_t p = t->p;
+  DevBuf<double> dy, dG, dg, dth, ddiag;
+  DevBuf<char> ws;
+  uint64_t wsb = 0;
+  obhip_newton_workspace_bytes(p, &wsb);
+  OB_TRY(dy.upload(y, b->n));
+  OB_TRY(dG.alloc(p * p));
+  OB_TRY(dg.alloc(p));
+  OB_TRY(dth.alloc(p));
+  OB_TRY(ddiag.alloc(p));
+  OB_TRY(ws.alloc(wsb));
+  OB_TRY(obhip_gram_dev(b, t, dy.p, dG.p, dg.p));
+  if (H_out) {
+    // the caller wants H itself (lpdfvec::hess_, fit.cpp:503-512): form it on a copy
+    DevBuf<double> dH, dprec;
+    OB_TRY(dH.alloc(p * p));
+    OB_HIP(hipMemcpyAsync(dH.p, dG.p, p * p * sizeof(double), hipMemcpyDeviceToDevice, cur_stream()));
+    const std::vector<double> prec = prior_prec(*m, *t, rho);
+    OB_TRY(dprec.upload(prec.data(), p));
+    OB_TRY(launch_form_hessian(p, dH.p, dprec.p, std::exp(-2.0 * sigma), nullptr));
+    OB_TRY(d2h(H_out, dH.p, p * p * sizeof(double)));
+  }
+  OB_TRY(obhip_newton_solve_dev(m, t, dG.p, dg.p, sigma, rho, dth.p, ddiag.p, ws.p, wsb));
+  OB_TRY(d2h(theta, dth.p, p * sizeof(double)));
+  if (diagH) OB_TRY(d2h(diagH, ddiag.p, p * sizeof(double)));
+  return 0;
+}
+
+// ---- PCG ----------------------------------------------------------------------------
+int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_model *m,
+                     const double *d_y, double sigma, double rho, double tol, uint64_t maxit,
+                     double *d_theta, uint64_t *iters_out, double *d_diagH, double *val_out,
+                     obhip_allreduce_fn all_reduce, void *user) {
+  if (!b || !tc || !m || !d_y || !d_theta) return fail(OBHIP_ERR_INVALID, "fit_cg_dev: null argument");
+  OB_TRY(check_compat(m, tc));
+  obhip_terms &t = *const_cast<obhip_terms *>(tc);
+  const uint64_t n = b->n, p = t.p;
+  const double e2 = std::exp(-2.0 * sigma);
+  const std::vector<double> tv = term_var(*m, t);
+  const std::vector<double> prec = prior_prec(*m, t, rho);
+  double logsd = 0;  // sum(log(coeffsd * sca)), logpr_gauss.cpp:101
+  for (uint64_t k = 0; k < p; ++k) logsd += std::log(std::sqrt(tv[k]) * std::exp(rho));
+
+  DevBuf<double> yhat, r, tmp, din, dpv;
+  OB_TRY(yhat.alloc(n));
+  OB_TRY(r.alloc(n));
+  OB_TRY(tmp.alloc(n));
+  OB_TRY(din.alloc(p));
+  OB_TRY(dpv.alloc(p + 2));
+  double *red = nullptr;
+  OB_TRY(scratch(&red));
+  hipStream_t st = cur_stream();
+
+  auto reduce_pull = [&](double *d_buf, uint64_t count, double *host) -> int {
+    if (all_reduce) {
+      OB_HIP(hipStreamSynchronize(st));
+      if (all_reduce(user, d_buf, count) != 0) return fail(OBHIP_ERR_HIP, "all_reduce callback failed");
+    }
+    return d2h(host, d_buf, count * sizeof(double));
+  };
+
+  // total number of rows over all ranks
+  double ntot = (double)n;
+  if (all_reduce) {
+    OB_HIP(hipMemcpyAsync(dpv.p, &ntot, sizeof(double), hipMemcpyHostToDevice, st));
+    OB_TRY(reduce_pull(dpv.p, 1, &ntot));
+  }
+
+  std::vector<double> coeff(p), grad(p), hv(p + 2);
+  OB_TRY(d2h(coeff.data(), d_theta, p * sizeof(double)));
+
+  // lpdfvec::update with compute_val, compute_grad (fit.cpp:323-363)
+  auto update = [&](const std::vector<double> &c, double &val) -> int {
+    OB_HIP(hipMemcpyAsync(din.p, c.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
+    OB_TRY(launch_mm(*b, t, din.p, yhat.p, false));                 // loglik_gauss.cpp:117
+    OB_TRY(launch_resid(yhat.p, d_y, n, e2, r.p, tmp.p));           // :118-124
+    OB_TRY(launch_tmm(*b, t, r.p, dpv.p, false));                   // :125
+    OB_TRY(launch_sum_sumsq(tmp.p, n, dpv.p + p, red));
+    OB_TRY(reduce_pull(dpv.p, p + 2, hv.data()));
+    double pr = 0;
+    for (uint64_t k = 0; k < p; ++k) {
+      grad[k] = hv[k] - c[k] * prec[k];                             // logpr_gauss.cpp:105
+      pr += c[k] * c[k] * prec[k];
+    }
+    val = -0.5 * e2 * hv[p + 1] - ntot * sigma - 0.5 * pr - logsd;  // loglik_gauss.cpp:121
+    return 0;
+  };
+  // lpdfvec::hessmult (fit.cpp:382-392): loglik_gauss.cpp:137-145 + logpr_gauss.cpp:113-115
+  auto hessmult = [&](const std::vector<double> &v, std::vector<double> &out) -> int {
+    OB_HIP(hipMemcpyAsync(din.p, v.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
+    OB_TRY(launch_mm(*b, t, din.p, yhat.p, false));
+    OB_TRY(launch_scale(yhat.p, n, e2));
+    OB_TRY(launch_tmm(*b, t, yhat.p, dpv.p, false));
+    OB_TRY(reduce_pull(dpv.p, p, hv.data()));
+    for (uint64_t k = 0; k < p; ++k) out[k] = hv[k] + prec[k] * v[k];
+    return 0;
+  };
+
+  double val = 0;
+  OB_TRY(update(coeff, val));
+  // m = diaghess(): e^{-2 sigma} sqcolsums + prior (loglik_gauss.cpp:154-157)
+  std::vector<double> mdiag(p);
+  OB_TRY(launch_fill(tmp.p, n, 1.0));
+  OB_TRY(launch_tmm(*b, t, tmp.p, dpv.p, true));
+  OB_TRY(reduce_pull(dpv.p, p, hv.data()));
+  bool finite = true;
+  for (uint64_t k = 0; k < p; ++k) {
+    mdiag[k] = e2 * hv[k] + prec[k];
+    finite = finite && std::isfinite(mdiag[k]) && std::isfinite(grad[k]);
+  }
+  uint64_t k = 0;
+  if (!finite) {
+    val = -std::numeric_limits<double>::infinity();  // fit.cpp:53-56
+  } else {
+    std::vector<double> rm(p), pv(p), q(p);
+    for (uint64_t i = 0; i < p; ++i) pv[i] = rm[i] = grad[i] / mdiag[i];
+    OB_TRY(hessmult(pv, q));
+    double valdiff = 10;
+    for (k = 0; k < maxit; ++k) {  // fit.cpp:71-85
+      double num = 0;
+      for (uint64_t i = 0; i < p; ++i) num += grad[i] * rm[i];
+      if (num < tol && valdiff < tol) break;
+      double denom = 0;
+      for (uint64_t i = 0; i < p; ++i) denom += q[i] * pv[i];
+      const double alpha = num / denom;
+      for (uint64_t i = 0; i < p; ++i) coeff[i] += alpha * pv[i];
+      const double valo = val;
+      OB_TRY(update(coeff, val));
+      valdiff = val - valo;
+      double num2 = 0;
+      for (uint64_t i = 0; i < p; ++i) {
+        rm[i] = grad[i] / mdiag[i];
+        num2 -= (alpha * q[i]) * rm[i];
+      }
+      const double beta = num2 / num;
+      for (uint64_t i = 0; i < p; ++i) pv[i] = rm[i] + beta * pv[i];
+      OB_TRY(hessmult(pv, q));
+    }
+  }
+  OB_HIP(hipMemcpyAsync(d_theta, coeff.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
+  if (d_diagH)
+    OB_HIP(hipMemcpyAsync(d_diagH, mdiag.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
+  OB_HIP(hipStreamSynchronize(st));
+  if (iters_out) *iters_out = k;
+  if (val_out) *val_out = val;
+  return 0;
+}
+
+int obhip_fit_cg(const obhip_basis *b, const obhip_terms *t, const obhip_model *m, const double *y,
+                 double sigma, double rho, double tol, uint64_t maxit, double *theta,
+                 uint64_t *iters_out, double *diagH, double *val_out) {
+  if (!b || !t || !m || !y || !theta) return fail(OBHIP_ERR_INVALID, "fit_cg: null argument");
+  DevBuf<double> dy, dth, ddiag;
+  OB_TRY(dy.upload(y, b->n));
+  OB_TRY(dth.upload(theta, t->p));
+  OB_TRY(ddiag.alloc(t->p));
+  OB_TRY(obhip_fit_cg_dev(b, t, m, dy.p, sigma, rho, tol, maxit, dth.p, iters_out, ddiag.p, val_out,
+                          nullptr, nullptr));
+  OB_TRY(d2h(theta, dth.p, t->p * sizeof(double)));
+  if (diagH) OB_TRY(d2h(diagH, ddiag.p, t->p * sizeof(double)));
+  return 0;
+}
+
+// ---- predictor ------------------------------------------------------------------------
+int obhip_predict_dev(const obhip_model *m, const obhip_terms *t, const double *d_theta,
+                      const double *d_x, uint64_t n, double *d_mean, const double *d_coeffvar,
+                      double sigma, double *d_var) {
+  if (!m || !t || !d_theta || !d_x || !d_mean) return fail(OBHIP_ERR_INVALID, "predict_dev: null argument");
+  OB_TRY(check_compat(m, t));
+  OB_TRY(require_device());
+  return launch_predict(*m, *const_cast<obhip_terms *>(t), d_theta, d_x, n, d_mean, d_coeffvar,
+                        std::exp(2.0 * sigma), d_var);
+}
+
+int obhip_predict(const obhip_model *m, const obhip_terms *t, const double *theta, const double *x,
+                  uint64_t n, uint64_t ldx, double *mean, const double *coeffvar, double sigma,
+                  double *var) {
+  if (!m || !t || !theta || !x || !mean || n == 0 || ldx < n)
+    return fail(OBHIP_ERR_INVALID, "predict: bad argument");
+  OB_TRY(check_compat(m, t));
+  OB_TRY(require_device());
+  DevBuf<double> dx, dth, dmean, dcv, dvar;
+  if (ldx == n) {
+    OB_TRY(dx.upload(x, n * m->d));
+  } else {
+    std::vector<double> xc(n * m->d);
+    for (uint64_t l = 0; l < m->d; ++l) std::memcpy(&xc[l * n], x + l * ldx, n * sizeof(double));
+    OB_TRY(dx.upload(xc.data(), xc.size()));
+  }
+  OB_TRY(dth.upload(theta, t->p));
+  OB_TRY(dmean.alloc(n));
+  const bool do_var = coeffvar && var;
+  if (do_var) {
+    OB_TRY(dcv.upload(coeffvar, t->p));
+    OB_TRY(dvar.alloc(n));
+  }
+  OB_TRY(obhip_predict_dev(m, t, dth.p, dx.p, n, dmean.p, do_var ? dcv.p : nullptr, sigma,
+                           do_var ? dvar.p : nullptr));
+  OB_TRY(d2h(mean, dmean.p, n * sizeof(double)));
+  if (do_var) OB_TRY(d2h(var, dvar.p, n * sizeof(double)));
+  return 0;
+}
+
+// ---- synthetic workload ------------------------------------------------------------------
+int obhip_synth_xy_dev(uint64_t seed, uint64_t row0, uint64_t n, uint64_t d, const int *kinds,
+                       double *d_x, double *d_y) {
+  if (!kinds || !d_x || !d_y || d == 0) return fail(OBHIP_ERR_INVALID, "synth: bad argument");
+  OB_TRY(require_device());
+  DevBuf<int> dk;
+  OB_TRY(dk.upload(kinds, d));
+  OB_TRY(launch_synth(seed, row0, n, d, dk.p, d_x, d_y));
+  OB_HIP(hipStreamSynchronize(cur_stream()));  // dk is a local
+  return 0;
+}
+
+int obhip_sum_sumsq_dev(const double *d_v, uint64_t n, double *d_out2) {
+  if (!d_v || !d_out2) return fail(OBHIP_ERR_INVALID, "null argument");
+  double *red = nullptr;
+  OB_TRY(scratch(&red));
+  return launch_sum_sumsq(d_v, n, d_out2, red);
+}
+
+int obhip_affine_dev(double *d_v, uint64_t n, double cent, double sca) {
+  if (!d_v) return fail(OBHIP_ERR_INVALID, "null argument");
+  return launch_affine(d_v, n, cent, sca);
+}
+
+}  // extern "C"

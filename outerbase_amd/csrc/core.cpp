@@ -1,0 +1,340 @@
+// Library plumbing of libobhip: error string, device/stream selection,
+// per-kernel hipEvent profiling, the device view of a model (ModelDev) and the
+// device tables of a `terms` matrix.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "obhip_internal.h"
+
+namespace obhip {
+
+static thread_local std::string g_err;
+static thread_local hipStream_t g_stream = nullptr;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  char buf[512];
+  std::snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e,
+                hipGetErrorString(e), what, file, line);
+  g_err = buf;
+  return e == hipErrorNoDevice ? OBHIP_ERR_NO_DEVICE : OBHIP_ERR_HIP;
+}
+
+int require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(OBHIP_ERR_NO_DEVICE,
+                "no HIP device visible: libobhip has no CPU fallback");
+  }
+  return 0;
+}
+
+hipStream_t cur_stream() { return g_stream; }
+
+// ---- profiling ----------------------------------------------------------------
+struct ProfEntry {
+  uint64_t launches = 0;
+  double total_ms = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::map<std::string, ProfEntry> g_prof;
+
+ProfScope::ProfScope(const char *n) : name(n) {
+  if (!g_prof_on) return;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+  active = true;
+  (void)hipEventRecord(e0, cur_stream());
+}
+
+ProfScope::~ProfScope() {
+  if (!active) return;
+  (void)hipEventRecord(e1, cur_stream());
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof[name].pending.emplace_back(e0, e1);
+}
+
+static void prof_drain(ProfEntry &pe) {
+  for (auto &ev : pe.pending) {
+    if (hipEventSynchronize(ev.second) == hipSuccess) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+        pe.launches += 1;
+        pe.total_ms += ms;
+      }
+    }
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  pe.pending.clear();
+}
+
+// ---- ModelDev -------------------------------------------------------------------
+int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
+  if (!m.knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  const uint64_t d = m.d;
+  cap.resize(d);
+  dims_h.resize(d);
+  std::vector<double> hka(m.M()), hkb(m.M()), hkc(m.M());
+  std::vector<double> hrot;
+  uint64_t ccol = 1;  // compact column 0 is the all-ones column
+  for (uint64_t l = 0; l < d; ++l) {
+    const uint64_t ml = m.m_of(l), o = m.knotptst[l];
+    int64_t c = cap_in.empty() ? (int64_t)ml - 1 : cap_in[l];
+    if (c < 0) c = 0;
+    if (c > (int64_t)ml - 1) c = (int64_t)ml - 1;
+    cap[l] = c;
+    DimDesc &D = dims_h[l];
+    D.kind = m.kinds[l];
+    D.m = (int)ml;
+    D.koff = (int)o;
+    D.ncol = (int)c + 1;
+    D.ncolp = (D.ncol + 7) / 8 * 8;
+    D.rotoff = (int)hrot.size();
+    D.ccol0 = (int)ccol;
+    D.pad = 0;
+    ccol += (uint64_t)c;
+    const double *hy = &m.hyp[m.hypst[l]];
+    const double a = 2.0, b = 0.25;  // covfuncs.h:42,53-54,66
+    if (D.kind == OBHIP_COV_MAT25) {
+      D.p0 = std::exp(a * hy[0]);  // expLS, covfuncs.cpp:114
+      D.p1 = D.p2 = 0;
+      for (uint64_t j = 0; j < ml; ++j) {
+        const double t = m.knotpt[o + j] / D.p0;
+        hka[o + j] = t;
+        hkb[o + j] = std::exp(t);
+        hkc[o + j] = std::exp(-t);
+      }
+    } else if (D.kind == OBHIP_COV_MAT25POW) {
+      D.p0 = std::exp(b * hy[1]);              // powv, covfuncs.cpp:198
+      D.p1 = std::exp(a * hy[0] + b * hy[1]);  // expLS, :199
+      D.p2 = 0;
+      for (uint64_t j = 0; j < ml; ++j) {
+        const double t = std::pow(m.knotpt[o + j], D.p0) / D.p1;
+        hka[o + j] = t;
+        hkb[o + j] = std::exp(t);
+        hkc[o + j] = std::exp(-t);
+      }
+    } else {
+      D.p0 = std::exp(a * hy[0]);  // expLSs, covfuncs.cpp:290
+      D.p1 = std::exp(a * hy[1]);  // expLSc, :291
+      D.p2 = 0;
+      for (uint64_t j = 0; j < ml; ++j) {
+        hka[o + j] = std::sin(m.knotpt[o + j]) / D.p0;
+        hkb[o + j] = std::cos(m.knotpt[o + j]) / D.p1;
+        hkc[o + j] = 0;
+      }
+    }
+    // rot block [m][ncolp], zero padded
+    hrot.resize(hrot.size() + ml * D.ncolp, 0.0);
+    for (uint64_t j = 0; j < ml; ++j)
+      for (int cc = 0; cc < D.ncol; ++cc)
+        hrot[D.rotoff + j * D.ncolp + cc] = m.rotmat[(o + cc) * m.mmax + j];
+  }
+  Mc = ccol;
+  OB_TRY(dims.upload(dims_h.data(), d));
+  OB_TRY(ka.upload(hka.data(), hka.size()));
+  OB_TRY(kb.upload(hkb.data(), hkb.size()));
+  OB_TRY(kc.upload(hkc.data(), hkc.size()));
+  OB_TRY(rot.upload(hrot.data(), hrot.size()));
+  model_version = m.version;
+  return 0;
+}
+
+}  // namespace obhip
+
+using namespace obhip;
+
+// ---- terms device tables ----------------------------------------------------------
+int obhip_terms::prepare(const std::vector<int64_t> &cap,
+                         const std::vector<DimDesc> &dims) {
+  if (cap == cached_cap && cols.p) return 0;
+  for (uint64_t l = 0; l < d; ++l)
+    if (maxlev[l] > cap[l])
+      return fail(OBHIP_ERR_INVALID,
+                  "terms use level " + std::to_string(maxlev[l]) + " in dimension " +
+                      std::to_string(l + 1) + " but the basis was built with level cap " +
+                      std::to_string(cap[l]));
+  // used compact columns (ones column always first)
+  std::vector<uint32_t> used;
+  used.push_back(0);
+  for (uint64_t l = 0; l < d; ++l) {
+    std::vector<char> seen(maxlev[l] + 1, 0);
+    for (uint64_t k = 0; k < p; ++k) seen[lev[k * d + l]] = 1;
+    for (int64_t t = 1; t <= maxlev[l]; ++t)
+      if (seen[t]) used.push_back((uint32_t)(dims[l].ccol0 + t - 1));
+  }
+  std::sort(used.begin() + 1, used.end());
+  if (used.size() > 65535) return fail(OBHIP_ERR_INVALID, "terms use more than 65535 basis columns");
+  Mu = used.size();
+  std::map<uint32_t, uint16_t> pos;
+  for (size_t u = 0; u < used.size(); ++u) pos[used[u]] = (uint16_t)u;
+  // column lists are read as packed pairs of uint16 (one dword), so W is even;
+  // unused slots point at used-column 0, the all-ones column.
+  W = std::max<uint64_t>(2, (max_nnz + 1) / 2 * 2);
+  p_pad = (p + 255) / 256 * 256;
+  std::vector<uint16_t> hc(p_pad * W, 0);
+  for (uint64_t k = 0; k < p; ++k) {
+    uint64_t w = 0;
+    for (uint64_t l = 0; l < d; ++l) {
+      const uint32_t t = lev[k * d + l];
+      if (t > 0) hc[k * W + w++] = pos[(uint32_t)(dims[l].ccol0 + t - 1)];
+    }
+  }
+  OB_TRY(cols.upload(hc.data(), hc.size()));
+  OB_TRY(ucol.upload(used.data(), used.size()));
+  uint64_t Mc = 1;
+  for (uint64_t l = 0; l < d; ++l) Mc += (uint64_t)cap[l];
+  std::vector<int32_t> hpos(Mc, -1);
+  for (size_t u = 0; u < used.size(); ++u) hpos[used[u]] = (int32_t)u;
+  OB_TRY(cpos.upload(hpos.data(), hpos.size()));
+  cached_cap = cap;
+  return 0;
+}
+
+extern "C" {
+
+int obhip_abi_version(void) { return 1; }
+
+const char *obhip_last_error(void) { return g_err.c_str(); }
+
+int obhip_device_count(int *count) {
+  if (!count) return fail(OBHIP_ERR_INVALID, "null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return 0;
+}
+
+int obhip_set_device(int device) {
+  OB_TRY(require_device());
+  OB_HIP(hipSetDevice(device));
+  return 0;
+}
+
+int obhip_set_stream(void *hip_stream) {
+  g_stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+int obhip_synchronize(void) {
+  OB_TRY(require_device());
+  OB_HIP(hipStreamSynchronize(cur_stream()));
+  return 0;
+}
+
+int obhip_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return 0;
+}
+
+int obhip_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto &kv : g_prof) prof_drain(kv.second);
+  g_prof.clear();
+  return 0;
+}
+
+int obhip_profile_get(const char *kernel, uint64_t *launches, double *total_ms) {
+  if (!kernel) return fail(OBHIP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  auto it = g_prof.find(kernel);
+  if (it == g_prof.end()) {
+    if (launches) *launches = 0;
+    if (total_ms) *total_ms = 0;
+    return 0;
+  }
+  prof_drain(it->second);
+  if (launches) *launches = it->second.launches;
+  if (total_ms) *total_ms = it->second.total_ms;
+  return 0;
+}
+
+int obhip_terms_create(obhip_terms **out, const obhip_model *m,
+                       const uint64_t *terms, uint64_t p) {
+  if (!out || !m || !terms || p == 0) return fail(OBHIP_ERR_INVALID, "terms_create: bad argument");
+  if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  obhip_terms *t = new obhip_terms();
+  t->p = p;
+  t->d = m->d;
+  t->lev.resize(p * m->d);
+  t->maxlev.assign(m->d, 0);
+  for (uint64_t k = 0; k < p; ++k) {
+    uint64_t nnz = 0;
+    for (uint64_t l = 0; l < m->d; ++l) {
+      const uint64_t v = terms[l * p + k];
+      if (v >= m->m_of(l)) {
+        delete t;
+        return fail(OBHIP_ERR_INVALID, "terms_create: level out of range");
+      }
+      t->lev[k * m->d + l] = (uint32_t)v;
+      t->maxlev[l] = std::max<int64_t>(t->maxlev[l], (int64_t)v);
+      nnz += v > 0;
+    }
+    t->nnz_total += nnz;
+    t->max_nnz = std::max(t->max_nnz, nnz);
+  }
+  *out = t;
+  return 0;
+}
+
+int obhip_terms_destroy(obhip_terms *t) {
+  delete t;
+  return 0;
+}
+
+int obhip_terms_info(const obhip_terms *t, uint64_t *p, uint64_t *d,
+                     uint64_t *nnz_total, uint64_t *max_nnz) {
+  if (!t) return fail(OBHIP_ERR_INVALID, "null terms");
+  if (p) *p = t->p;
+  if (d) *d = t->d;
+  if (nnz_total) *nnz_total = t->nnz_total;
+  if (max_nnz) *max_nnz = t->max_nnz;
+  return 0;
+}
+
+int obhip_terms_maxlevels(const obhip_terms *t, int64_t *levels) {
+  if (!t || !levels) return fail(OBHIP_ERR_INVALID, "null argument");
+  std::copy(t->maxlev.begin(), t->maxlev.end(), levels);
+  return 0;
+}
+
+int obhip_malloc(void **d_ptr, uint64_t bytes) {
+  if (!d_ptr) return fail(OBHIP_ERR_INVALID, "null argument");
+  OB_TRY(require_device());
+  OB_HIP(hipMalloc(d_ptr, bytes));
+  return 0;
+}
+
+int obhip_free(void *d_ptr) {
+  if (d_ptr) OB_HIP(hipFree(d_ptr));
+  return 0;
+}
+
+int obhip_memcpy_h2d(void *d_dst, const void *src, uint64_t bytes) {
+  OB_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, cur_stream()));
+  OB_HIP(hipStreamSynchronize(cur_stream()));
+  return 0;
+}
+
+int obhip_memcpy_d2h(void *dst, const void *d_src, uint64_t bytes) {
+  OB_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, cur_stream()));
+  OB_HIP(hipStreamSynchronize(cur_stream()));
+  return 0;
+}
+
+}  // extern "C"

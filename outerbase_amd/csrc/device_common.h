@@ -1,0 +1,155 @@
+// Device-side helpers shared by the HIP kernels of libobhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "obhip_internal.h"
+
+namespace obhip {
+
+// ---- 1-D covariance kernels -----------------------------------------------------
+// k(h) = (1 + h + h^2/3) exp(-h)  (src/covfuncs.cpp:121-124,207-210,306-308).
+//
+// mat25 / mat25pow: h = |t(x) - t(knot_j)| with t(x) = x / expLS (mat25,
+// covfuncs.cpp:114-120) or x^powv / expLS (mat25pow, :198-206).  exp(-h) is
+// separable around the sign of t(x) - t_j, so a row needs two exponentials
+// (exp(+t(x)), exp(-t(x))) instead of one per knot; the knot factors
+// exp(+-t_j) are precomputed on the host (ModelDev::build: ka = t_j,
+// kb = exp(t_j), kc = exp(-t_j)).  |t| <= 1/exp(2*hyplb) ~ 90, far from
+// overflow.
+//
+// mat25ang: h = sqrt((sin x/ls_s - sin k_j/ls_s)^2 + (cos x/ls_c - cos k_j/ls_c)^2)
+// (covfuncs.cpp:285-305): not separable, one exp per knot; ka = sin k_j/ls_s,
+// kb = cos k_j/ls_c.
+template <int KIND>
+__device__ __forceinline__ void kernel_pre(const DimDesc &D, double xv, double &a0, double &a1,
+                                           double &a2) {
+  if (KIND == OBHIP_COV_MAT25) {
+    a0 = xv / D.p0;
+    a1 = exp(a0);
+    a2 = exp(-a0);
+  } else if (KIND == OBHIP_COV_MAT25POW) {
+    a0 = pow(xv, D.p0) / D.p1;
+    a1 = exp(a0);
+    a2 = exp(-a0);
+  } else {
+    a0 = sin(xv) / D.p0;
+    a1 = cos(xv) / D.p1;
+    a2 = 0.0;
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ double kernel_value(double ka, double kb, double kc, double a0,
+                                               double a1, double a2) {
+  double h, eh;
+  if (KIND == OBHIP_COV_MAT25ANG) {
+    const double hs = a0 - ka, hc = a1 - kb;
+    h = sqrt(hs * hs + hc * hc);
+    eh = exp(-h);
+  } else {
+    const double dlt = a0 - ka;
+    h = fabs(dlt);
+    eh = dlt >= 0.0 ? a2 * kb : a1 * kc;
+  }
+  return (1.0 + h + h * h * (1.0 / 3.0)) * eh;
+}
+
+// ---- one dimension of the basis for one row ----------------------------------------
+// One 8-column chunk of (kernel row vector) x rotmat for one dimension.
+// a0..a2 are the per-row precomputed values (kernel_pre).  D and every table
+// index are wave-uniform, so the knot constants and the rotmat entries are
+// scalar loads and the FMAs take them as SGPR operands.
+template <int KIND>
+__device__ __forceinline__ void dim_chunk(const DimDesc &D, const double *__restrict__ ka,
+                                          const double *__restrict__ kb,
+                                          const double *__restrict__ kc,
+                                          const double *__restrict__ rot, double a0,
+                                          double a1, double a2, int c0, double (&acc)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.0;
+  const double *rp = rot + D.rotoff + c0;
+  for (int j = 0; j < D.m; ++j) {
+    double kv = kernel_value<KIND>(ka[D.koff + j], kb[D.koff + j], kc[D.koff + j], a0, a1, a2);
+    const double *r = rp + (size_t)j * D.ncolp;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = fma(kv, r[c], acc[c]);
+  }
+}
+
+// stores level t >= 1 of a dimension (compact column ccol) for this lane's row
+struct StoreGlobal {
+  double *base;  // bm + tile * Mc * 64 + lane
+  __device__ __forceinline__ void operator()(int ccol, double v) const {
+    base[(size_t)ccol * kTileRows] = v;
+  }
+};
+struct StoreLds {
+  double *lds;      // [used column][64]
+  const int *cpos;  // compact column -> used column or -1
+  int lane;
+  __device__ __forceinline__ void operator()(int ccol, double v) const {
+    const int u = cpos[ccol];
+    if (u >= 0) lds[u * kTileRows + lane] = v;
+  }
+};
+
+// R = cov(x, knots) . rotmat for one row and one dimension; levels >= 1 are
+// divided by level 0 (modandbase.cpp:297) and stored, level 0 is returned.
+template <int KIND, typename Store>
+__device__ __forceinline__ double build_dim(const DimDesc &D, const double *ka, const double *kb,
+                                            const double *kc, const double *rot, double xv,
+                                            const Store &store) {
+  double a0, a1, a2;
+  kernel_pre<KIND>(D, xv, a0, a1, a2);
+  double acc[8];
+  double cl = 1.0;
+  for (int c0 = 0; c0 < D.ncolp; c0 += 8) {
+    dim_chunk<KIND>(D, ka, kb, kc, rot, a0, a1, a2, c0, acc);
+    if (c0 == 0) cl = acc[0];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int col = c0 + c;
+      if (col >= 1 && col < D.ncol) store(D.ccol0 + col - 1, acc[c] / cl);
+    }
+  }
+  return cl;
+}
+
+template <typename Store>
+__device__ __forceinline__ double build_dim_any(const DimDesc &D, const double *ka, const double *kb,
+                                                const double *kc, const double *rot, double xv,
+                                                const Store &store) {
+  if (D.kind == OBHIP_COV_MAT25) return build_dim<OBHIP_COV_MAT25>(D, ka, kb, kc, rot, xv, store);
+  if (D.kind == OBHIP_COV_MAT25POW)
+    return build_dim<OBHIP_COV_MAT25POW>(D, ka, kb, kc, rot, xv, store);
+  return build_dim<OBHIP_COV_MAT25ANG>(D, ka, kb, kc, rot, xv, store);
+}
+
+// ---- LDS tile of basemat ----------------------------------------------------------
+// A staged tile holds Mu "used" columns of one 64-row tile: element (u, r) lives
+// at u * 64 + (r ^ swz(u)).  The XOR swizzle keeps the two access patterns of
+// the consumers conflict-free:
+//   - lane = row, column wave-uniform (mm / tmm / getmat): r ^ const is a
+//     bijection of the lanes onto the 64 slots of the column;
+//   - 16 different columns x 4 consecutive rows (Gram MFMA operands): lanes
+//     that share a row differ in u, and swz moves them to different banks
+//     whenever their columns differ mod 16.
+__device__ __forceinline__ int tile_swz(int u) { return (u & 15) << 1; }
+__device__ __forceinline__ int tile_idx(int u, int r) { return u * kTileRows + (r ^ tile_swz(u)); }
+
+// Cooperative copy of one 64-row tile (columns ucol[0..Mu)) from HBM to LDS.
+// SQUARE stages the squared values (basematsq, modandbase.cpp:581).
+template <bool SQUARE, bool SWIZZLE>
+__device__ __forceinline__ void stage_tile(double *__restrict__ lds, const double *__restrict__ bm_tile,
+                                           const uint32_t *__restrict__ ucol, int Mu, int tid,
+                                           int nthreads) {
+  const int total = Mu * kTileRows;
+  for (int e = tid; e < total; e += nthreads) {
+    const int u = e >> 6, r = e & 63;
+    double v = bm_tile[(size_t)ucol[u] * kTileRows + r];
+    if (SQUARE) v *= v;
+    lds[SWIZZLE ? tile_idx(u, r) : e] = v;
+  }
+}
+
+}  // namespace obhip

@@ -1,0 +1,183 @@
+// Small n-vector kernels of libobhip: the synthetic benchmark generator, the
+// standardisation of y (R/fitting.R:55-57) and the residual pieces of
+// loglik_gauss::update / hessmult (src/lpdfs/loglik_gauss.cpp:110-145).
+// All are plain HBM-streaming kernels; reductions are two-stage with a fixed
+// summation order so results are run-to-run reproducible.
+#include "obhip_internal.h"
+
+namespace obhip {
+
+namespace {
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ double synth_u(uint64_t seed, uint64_t i, uint64_t d, uint64_t j) {
+  return (double)(splitmix64(seed + i * d + j) >> 11) * 0x1.0p-53;
+}
+
+// x = 0.02 + 0.96 u (x 6.283185 on mat25ang dims);
+// y = borehole8d(first 8 coordinates) + sum_{j>=8} 20/(j+1) sin(2 pi u_j)
+// (Borehole-8d closed form: R/testfuncs.R:32-46).
+__global__ void k_synth(uint64_t seed, uint64_t row0, uint64_t n, uint64_t d,
+                        const int *__restrict__ kinds, double *__restrict__ x,
+                        double *__restrict__ y) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t i = row0 + r;
+  double b[8];
+  double extra = 0.0;
+  for (uint64_t j = 0; j < d; ++j) {
+    const double u = synth_u(seed, i, d, j);
+    const double xv = 0.02 + 0.96 * u;
+    x[j * n + r] = kinds[j] == OBHIP_COV_MAT25ANG ? xv * 6.283185 : xv;
+    if (j < 8)
+      b[j] = xv;
+    else
+      extra += (20.0 / (double)(j + 1)) * sin(2.0 * 3.141592653589793 * u);
+  }
+  for (uint64_t j = d; j < 8; ++j) b[j] = 0.5;
+  const double rw = b[0] * (0.15 - 0.05) + 0.05;
+  const double rr = b[1] * (50000.0 - 100.0) + 100.0;
+  const double Tu = b[2] * (115600.0 - 63070.0) + 63070.0;
+  const double Hu = b[3] * (1110.0 - 990.0) + 990.0;
+  const double Tl = b[4] * (116.0 - 63.1) + 63.1;
+  const double Hl = b[5] * (820.0 - 700.0) + 700.0;
+  const double L = b[6] * (1680.0 - 1120.0) + 1120.0;
+  const double Kw = b[7] * (12045.0 - 9855.0) + 9855.0;
+  const double m1 = 2.0 * 3.141592653589793 * Tu * (Hu - Hl);
+  const double m2 = log(rr / rw);
+  const double m3 = 1.0 + 2.0 * L * Tu / (m2 * rw * rw * Kw) + Tu / Tl;
+  y[r] = (m1 / m2 / m3 - 77.0) + extra;
+}
+
+constexpr int kRedBlocks = 1024;
+
+// stage 1: per-block partial (sum, sum of squares); stage 2: one block.
+__global__ void __launch_bounds__(256)
+k_sum2_stage1(const double *__restrict__ v, uint64_t n, double *__restrict__ part) {
+  __shared__ double s1[256], s2[256];
+  double a = 0.0, b = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const double t = v[i];
+    a += t;
+    b += t * t;
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      s1[threadIdx.x] += s1[threadIdx.x + off];
+      s2[threadIdx.x] += s2[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = s1[0];
+    part[2 * blockIdx.x + 1] = s2[0];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_sum2_stage2(const double *__restrict__ part, int nblk, double *__restrict__ out2) {
+  __shared__ double s1[256], s2[256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) {
+    a += part[2 * i];
+    b += part[2 * i + 1];
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      s1[threadIdx.x] += s1[threadIdx.x + off];
+      s2[threadIdx.x] += s2[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = s1[0];
+    out2[1] = s2[0];
+  }
+}
+
+__global__ void k_affine(double *__restrict__ v, uint64_t n, double cent, double sca) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (v[i] - cent) / sca;
+}
+
+// r = -e2 * (yhat - y); diff (in place of yhat) kept for the sum of squares
+__global__ void k_resid(const double *__restrict__ yhat, const double *__restrict__ y, uint64_t n,
+                        double e2, double *__restrict__ r, double *__restrict__ diff) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const double dlt = yhat[i] - y[i];
+    diff[i] = dlt;
+    r[i] = -e2 * dlt;
+  }
+}
+
+__global__ void k_scale(double *__restrict__ v, uint64_t n, double c) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] *= c;
+}
+
+__global__ void k_fill(double *__restrict__ v, uint64_t n, double c) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = c;
+}
+
+}  // namespace
+
+int launch_synth(uint64_t seed, uint64_t row0, uint64_t n, uint64_t d, const int *d_kinds,
+                 double *d_x, double *d_y) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_synth, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cur_stream(), seed,
+                     row0, n, d, d_kinds, d_x, d_y);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sum_sumsq(const double *d_v, uint64_t n, double *d_out2, double *d_part /* 2*kRedBlocks */) {
+  const int nblk = (int)std::min<uint64_t>(kRedBlocks, std::max<uint64_t>(1, (n + 255) / 256));
+  hipLaunchKernelGGL(k_sum2_stage1, dim3(nblk), dim3(256), 0, cur_stream(), d_v, n, d_part);
+  hipLaunchKernelGGL(k_sum2_stage2, dim3(1), dim3(256), 0, cur_stream(), d_part, nblk, d_out2);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_affine(double *d_v, uint64_t n, double cent, double sca) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_affine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cur_stream(), d_v, n,
+                     cent, sca);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_resid(const double *d_yhat, const double *d_y, uint64_t n, double e2, double *d_r,
+                 double *d_diff) {
+  hipLaunchKernelGGL(k_resid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cur_stream(), d_yhat,
+                     d_y, n, e2, d_r, d_diff);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_scale(double *d_v, uint64_t n, double c) {
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cur_stream(), d_v, n, c);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_fill(double *d_v, uint64_t n, double c) {
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cur_stream(), d_v, n, c);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace obhip

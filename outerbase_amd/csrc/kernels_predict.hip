@@ -1,0 +1,107 @@
+// Fused predictor for gfx950: basis evaluation at new inputs and the B theta
+// (and B^2 coeffvar) contraction in one kernel; the basis tile only ever exists
+// in LDS.  Replaces predictor$update + $mean + $var of pred_gauss
+// (src/lpdfs/loglik_gauss.cpp:214-227: a fresh outerbase (modandbase.cpp:547)
+// followed by prodmm_ (linalg.cpp:57-131) on basemat and on basematsq).
+//
+// Per 64-row tile: 4 waves evaluate the dimensions (wave w takes w, w+4, ...),
+// lane = row, writing only the columns the terms use into the LDS tile; after
+// one barrier the 4 waves split the terms exactly as k_mm does.
+#include "obhip_internal.h"
+#include "device_common.h"
+
+namespace obhip {
+
+namespace {
+
+template <bool VAR>
+__global__ void __launch_bounds__(256)
+k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
+          const double *__restrict__ kb, const double *__restrict__ kc,
+          const double *__restrict__ rot, const int *__restrict__ cpos, int d, int Mu,
+          const uint32_t *__restrict__ colsw, int W2, int p, const double *__restrict__ theta,
+          const double *__restrict__ coeffvar, double e2sigma, const double *__restrict__ x,
+          uint64_t n, double *__restrict__ mean, double *__restrict__ var) {
+  extern __shared__ double lds[];
+  double *red = lds + (size_t)Mu * kTileRows;  // [4][64] scale partials, then mean partials
+  double *redv = red + 4 * kTileRows;          // [4][64] variance partials
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t row = (uint64_t)blockIdx.x * kTileRows + lane;
+  const bool valid = row < n;
+
+  double sc = 1.0;
+  const StoreLds store{lds, cpos, lane};
+  for (int l = wave; l < d; l += 4) {
+    const DimDesc D = dims[l];
+    const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
+    sc *= build_dim_any(D, ka, kb, kc, rot, xv, store);
+  }
+  if (wave == 0) lds[lane] = 1.0;  // used column 0 = all ones
+  red[wave * kTileRows + lane] = sc;
+  __syncthreads();
+  const double s = (red[lane] * red[64 + lane]) * (red[128 + lane] * red[192 + lane]);
+  __syncthreads();
+
+  double am = 0.0, av = 0.0;
+  for (int k = wave; k < p; k += 4) {
+    const uint32_t *cw = colsw + (size_t)k * W2;
+    double pr = 1.0;
+    for (int w = 0; w < W2; ++w) {
+      const uint32_t c = cw[w];
+      pr *= lds[(c & 0xffffu) * kTileRows + lane];
+      pr *= lds[(c >> 16) * kTileRows + lane];
+    }
+    am = fma(theta[k], pr, am);
+    if (VAR) av = fma(coeffvar[k], pr * pr, av);
+  }
+  red[wave * kTileRows + lane] = am;
+  if (VAR) redv[wave * kTileRows + lane] = av;
+  __syncthreads();
+  if (wave == 0 && valid) {
+    mean[row] = ((red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane])) * s;
+    if (VAR)
+      var[row] = ((redv[lane] + redv[64 + lane]) + (redv[128 + lane] + redv[192 + lane])) * (s * s) +
+                 e2sigma;  // loglik_gauss.cpp:224-225
+  }
+}
+
+}  // namespace
+
+int launch_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, const double *d_x,
+                   uint64_t n, double *d_mean, const double *d_coeffvar, double e2sigma,
+                   double *d_var) {
+  if (t.pred_model != &m || t.pred_md.model_version != m.version) {
+    OB_TRY(t.pred_md.build(m, t.maxlev));
+    t.pred_model = &m;
+  }
+  OB_TRY(t.prepare(t.pred_md.cap, t.pred_md.dims_h));
+  if (t.Mu > 296)
+    return fail(OBHIP_ERR_INVALID, "terms touch too many basis columns for the LDS tile");
+  if (n == 0) return 0;
+  ProfScope ps("predict");
+  const size_t lds = (t.Mu * kTileRows + 8 * kTileRows) * sizeof(double);
+  const dim3 grid((unsigned)((n + kTileRows - 1) / kTileRows));
+  const bool do_var = d_coeffvar != nullptr && d_var != nullptr;
+  if (do_var) {
+    if (lds > 64 * 1024)
+      OB_HIP(hipFuncSetAttribute((const void *)k_predict<true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_predict<true>, grid, dim3(256), lds, cur_stream(), t.pred_md.dims.p,
+                       t.pred_md.ka.p, t.pred_md.kb.p, t.pred_md.kc.p, t.pred_md.rot.p, t.cpos.p,
+                       (int)m.d, (int)t.Mu, (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p,
+                       d_theta, d_coeffvar, e2sigma, d_x, n, d_mean, d_var);
+  } else {
+    if (lds > 64 * 1024)
+      OB_HIP(hipFuncSetAttribute((const void *)k_predict<false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_predict<false>, grid, dim3(256), lds, cur_stream(), t.pred_md.dims.p,
+                       t.pred_md.ka.p, t.pred_md.kb.p, t.pred_md.kc.p, t.pred_md.rot.p, t.cpos.p,
+                       (int)m.d, (int)t.Mu, (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p,
+                       d_theta, d_coeffvar, e2sigma, d_x, n, d_mean, d_var);
+  }
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace obhip

@@ -1,0 +1,223 @@
+// Internal declarations shared by the host logic and the HIP kernels of
+// libobhip.  Nothing here is part of the ABI (include/obhip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/obhip.h"
+
+namespace obhip {
+
+// ---- error plumbing ---------------------------------------------------------
+int fail(int code, const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define OB_HIP(expr)                                                \
+  do {                                                              \
+    hipError_t _e = (expr);                                         \
+    if (_e != hipSuccess) return obhip::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+#define OB_TRY(expr)        \
+  do {                      \
+    int _rc = (expr);       \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+int require_device();
+hipStream_t cur_stream();
+
+// ---- profiling --------------------------------------------------------------
+struct ProfScope {
+  const char *name;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool active = false;
+  explicit ProfScope(const char *n);
+  ~ProfScope();
+};
+
+// ---- device buffer ----------------------------------------------------------
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int alloc(size_t count) {
+    if (count == n && p) return 0;
+    release();
+    if (count == 0) return 0;
+    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    n = count;
+    return 0;
+  }
+  int upload(const T *src, size_t count) {
+    int rc = alloc(count);
+    if (rc) return rc;
+    if (count == 0) return 0;
+    hipError_t e = hipMemcpyAsync(p, src, count * sizeof(T),
+                                  hipMemcpyHostToDevice, cur_stream());
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+    e = hipStreamSynchronize(cur_stream());
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    return 0;
+  }
+};
+
+// ---- covariance functions (host) --------------------------------------------
+constexpr int kNumCov = 3;
+struct CovInfo {
+  int numhyp;
+  double hyp0[2], hyplb[2], hypub[2], hypvar[2];
+  double lowbnd, uppbnd;
+};
+const CovInfo &cov_info(int kind);
+void cov_host(int kind, const double *hyp, const double *x1, uint64_t n1,
+              const double *x2, uint64_t n2, double *out /* n1 x n2 col-major */);
+double cov_hyplpdf_host(int kind, const double *hyp);
+
+// symmetric eigen-decomposition (cyclic Jacobi), eigenvalues ascending like
+// LAPACK dsyev / arma::eig_sym; a is n x n col-major (destroyed), v n x n.
+void jacobi_eigh(int n, std::vector<double> &a, std::vector<double> &w,
+                 std::vector<double> &v);
+
+}  // namespace obhip
+
+// ---- outermod -----------------------------------------------------------------
+struct obhip_model {
+  uint64_t d = 0;
+  std::vector<int> kinds;
+  std::vector<uint64_t> hypst;     // d+1
+  std::vector<double> hyp;
+  bool knots_set = false;
+  std::vector<uint64_t> knotptst;  // d+1
+  std::vector<double> knotpt;      // M
+  uint64_t mmax = 0;
+  std::vector<double> rotmat;      // mmax x M col-major
+  std::vector<double> basisvar;    // M
+  std::vector<int64_t> maxlevel;   // d
+  uint64_t version = 0;            // bumped whenever build() runs
+
+  uint64_t M() const { return knotpt.size(); }
+  uint64_t m_of(uint64_t l) const { return knotptst[l + 1] - knotptst[l]; }
+  int build();
+};
+
+// ---- device view of a model restricted to per-dimension level caps ------------
+namespace obhip {
+
+struct DimDesc {
+  int kind;
+  int m;       // knots in this dim
+  int koff;    // offset into the knot arrays
+  int ncol;    // levels evaluated = cap+1 (level 0 included)
+  int ncolp;   // ncol rounded up to a multiple of 8
+  int rotoff;  // offset into rot (doubles)
+  int ccol0;   // compact column of level 1 (level t -> ccol0 + t - 1)
+  int pad;
+  double p0, p1, p2;  // kernel constants (see kernels_basis.hip)
+};
+
+struct ModelDev {
+  uint64_t model_version = ~0ull;
+  std::vector<int64_t> cap;     // d
+  std::vector<DimDesc> dims_h;
+  uint64_t Mc = 0;              // compact columns incl. the ones column 0
+  DevBuf<DimDesc> dims;
+  DevBuf<double> ka, kb, kc;    // per-knot constants (M each)
+  DevBuf<double> rot;           // per dim [m][ncolp]
+  int build(const obhip_model &m, const std::vector<int64_t> &cap);
+};
+
+}  // namespace obhip
+
+// ---- terms --------------------------------------------------------------------
+struct obhip_terms {
+  uint64_t p = 0, d = 0;
+  std::vector<uint32_t> lev;          // p x d row-major levels
+  std::vector<int64_t> maxlev;        // d
+  uint64_t nnz_total = 0, max_nnz = 0;
+  // device tables, rebuilt when the compact layout (caps) changes
+  std::vector<int64_t> cached_cap;
+  uint64_t W = 0;                     // padded column-list width
+  uint64_t Mu = 0;                    // used compact columns
+  obhip::DevBuf<uint16_t> cols;       // p_pad x W indices into the USED list
+  obhip::DevBuf<uint32_t> ucol;       // Mu compact column ids (used list)
+  obhip::DevBuf<int32_t> cpos;        // compact column -> used index or -1 (Mc)
+  uint64_t p_pad = 0;
+  // device view of the model capped at maxlev, for the fused predictor
+  obhip::ModelDev pred_md;
+  const obhip_model *pred_model = nullptr;
+  int prepare(const std::vector<int64_t> &cap, const std::vector<obhip::DimDesc> &dims);
+};
+
+// ---- outerbase ------------------------------------------------------------------
+struct obhip_basis {
+  const obhip_model *model = nullptr;
+  uint64_t n = 0, n_pad = 0, d = 0;
+  obhip::ModelDev md;
+  obhip::DevBuf<double> x;      // column-major n x d (ld = n)
+  obhip::DevBuf<double> bm;     // tile-blocked [n_pad/64][Mc][64]
+  obhip::DevBuf<double> scale;  // n_pad (0 beyond n)
+  obhip::DevBuf<char> work;     // scratch for split-reduction partials (grown on demand)
+  int device = 0;
+  int workspace(size_t bytes, void **out) {
+    if (work.n < bytes) {
+      // the previous kernels may still be reading the old buffer
+      if (work.p && hipStreamSynchronize(obhip::cur_stream()) != hipSuccess)
+        return obhip::fail(OBHIP_ERR_HIP, "stream sync failed");
+      int rc = work.alloc(bytes + bytes / 4);
+      if (rc) return rc;
+    }
+    *out = work.p;
+    return 0;
+  }
+};
+
+namespace obhip {
+
+constexpr int kTileRows = 64;
+
+// kernels_basis.hip
+int launch_build_basis(obhip_basis &b);
+int launch_getbase(const obhip_basis &b, uint64_t k, double *d_out /* n x m */);
+// kernels_prod.hip
+int launch_getmat(const obhip_basis &b, obhip_terms &t, double *d_out);
+int launch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a,
+              double *d_out, bool squared);
+int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a,
+               double *d_out, bool squared);
+// kernels_gram.hip
+int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G);
+// kernels_chol.hip
+uint64_t newton_workspace_bytes(uint64_t p);
+int launch_newton_solve(uint64_t p, double *d_H, const double *d_rhs,
+                        double *d_theta, void *d_ws, uint64_t ws_bytes);
+int launch_form_hessian(uint64_t p, double *d_G, const double *d_prec,
+                        double e2, double *d_diagH);
+// kernels_predict.hip
+int launch_predict(const obhip_model &m, obhip_terms &t, const double *d_theta,
+                   const double *d_x, uint64_t n, double *d_mean,
+                   const double *d_coeffvar, double e2sigma, double *d_var);
+// small vector kernels (kernels_misc.hip)
+int launch_synth(uint64_t seed, uint64_t row0, uint64_t n, uint64_t d,
+                 const int *d_kinds, double *d_x, double *d_y);
+int launch_sum_sumsq(const double *d_v, uint64_t n, double *d_out2,
+                     double *d_part /* 2048 doubles of scratch */);
+int launch_affine(double *d_v, uint64_t n, double cent, double sca);
+int launch_resid(const double *d_yhat, const double *d_y, uint64_t n, double e2,
+                 double *d_r, double *d_diff);
+int launch_scale(double *d_v, uint64_t n, double c);
+int launch_fill(double *d_v, uint64_t n, double c);
+
+}  // namespace obhip

@@ -1,0 +1,604 @@
+"""Host-side mirror of the reference's Rcpp module `obmod`
+(src/interfaceR.cpp:661-793 of MattPlumlee/outerbase): same class, method and
+field names, same argument meaning (0-based term levels, 1-based getbase), so
+tests read like the reference's own testthat files.  Every method forwards to
+the C ABI in include/obhip.h; nothing is computed in Python except O(p) vector
+algebra on results.
+
+Scope: value paths only -- no hyper-gradient methods
+(`*_gradhyp`), no loglik_gda, no marginal adjustment.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import call, ptr
+
+_KINDS = {"mat25": 0, "mat25pow": 1, "mat25ang": 2}
+_KIND_NAMES = {v: k for k, v in _KINDS.items()}
+_HYPNAMES = {"mat25": ["scale"], "mat25pow": ["scale", "power"],
+             "mat25ang": ["sin.sc", "cos.sc"]}
+
+
+def listcov():
+    """R/fitting.R:6-8"""
+    return ["mat25pow", "mat25", "mat25ang"]
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _fmat(a):
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def _umat(terms):
+    t = np.asarray(terms)
+    if t.ndim != 2:
+        raise ValueError("terms must be a p x d matrix")
+    if np.any(t < 0):
+        raise ValueError("terms must be non-negative levels")
+    return np.asfortranarray(t.astype(np.uint64))
+
+
+# ----------------------------------------------------------------------------
+# covariance function classes (interfaceR.cpp:764-791)
+# ----------------------------------------------------------------------------
+class covf:
+    kind = None
+
+    def __init__(self):
+        k = _KINDS[self.kind]
+        nh = C.c_int(0)
+        call("obhip_cov_numhyp", k, C.byref(nh))
+        nh = nh.value
+        self.hyp0 = np.zeros(nh)
+        self.hyplb = np.zeros(nh)
+        self.hypub = np.zeros(nh)
+        self.hypvar = np.zeros(nh)
+        lo, up = C.c_double(0), C.c_double(0)
+        call("obhip_cov_info", k, ptr(self.hyp0), ptr(self.hyplb), ptr(self.hypub),
+             ptr(self.hypvar), C.byref(lo), C.byref(up))
+        self.lowbnd, self.uppbnd = lo.value, up.value
+        self.hyp = self.hyp0.copy()
+
+    def cov(self, x1, x2):
+        x1, x2 = _f64(x1), _f64(x2)
+        out = np.empty((len(x1), len(x2)), order="F")
+        call("obhip_cov", _KINDS[self.kind], ptr(_f64(self.hyp)), ptr(x1), len(x1), ptr(x2),
+             len(x2), ptr(out))
+        return out
+
+    def covdiag(self, x):
+        return np.ones(len(x))  # covfuncs.cpp:128-132
+
+    def lpdf(self, hyp):
+        out = C.c_double(0)
+        call("obhip_cov_hyplpdf", _KINDS[self.kind], ptr(_f64(hyp)), C.byref(out))
+        return out.value
+
+
+class covf_mat25(covf):
+    kind = "mat25"
+
+
+class covf_mat25pow(covf):
+    kind = "mat25pow"
+
+
+class covf_mat25ang(covf):
+    kind = "mat25ang"
+
+
+# ----------------------------------------------------------------------------
+# outermod (interfaceR.cpp:670-678)
+# ----------------------------------------------------------------------------
+class outermod:
+    def __init__(self):
+        self._h = None
+        self.covnames = []
+        self.d = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib.obhip_model_destroy(self._h)
+            self._h = None
+
+    def _need(self):
+        if not self._h:
+            raise RuntimeError("Need to set cov. funcs before setting knots.")
+
+    # -- queries
+    def dims(self):
+        d, M, mmax, nh = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        call("obhip_model_dims", self._h, C.byref(d), C.byref(M), C.byref(mmax), C.byref(nh))
+        return d.value, M.value, mmax.value, nh.value
+
+    def rotation(self):
+        d, M, mmax, _ = self.dims()
+        rot = np.empty((mmax, M), order="F")
+        bv = np.empty(M)
+        ml = np.empty(d, dtype=np.int64)
+        call("obhip_model_get_rotation", self._h, ptr(rot), ptr(bv), ptr(ml))
+        return rot, bv, ml
+
+    def set_rotation(self, rotmat, basisvar, maxlevel):
+        rot = _fmat(rotmat)
+        bv = _f64(basisvar)
+        ml = np.ascontiguousarray(maxlevel, dtype=np.int64)
+        call("obhip_model_set_rotation", self._h, ptr(rot), ptr(bv), ptr(ml))
+
+    @property
+    def maxlevel(self):
+        return self.rotation()[2]
+
+    @property
+    def basisvar(self):
+        return self.rotation()[1]
+
+    # -- module methods
+    def updatehyp(self, hyp):
+        self._need()
+        hyp = _f64(hyp)
+        call("obhip_model_set_hyp", self._h, ptr(hyp), len(hyp))
+
+    def selectterms(self, numele, seed=0):
+        self._need()
+        d = self.d
+        out = np.empty((int(numele), d), dtype=np.uint64, order="F")
+        call("obhip_model_select_terms", self._h, int(numele), int(seed), ptr(out))
+        return out.astype(np.int64)
+
+    def getvar(self, terms):
+        t = _umat(terms)
+        out = np.empty(t.shape[0])
+        call("obhip_model_term_var", self._h, ptr(t), t.shape[0], ptr(out))
+        return out
+
+    def hyplpdf(self, hyp):
+        hyp = _f64(hyp)
+        out = C.c_double(0)
+        call("obhip_model_hyplpdf", self._h, ptr(hyp), len(hyp), C.byref(out))
+        return out.value
+
+
+def setcovfs(om, covnames):
+    """interfaceR.cpp:53-73"""
+    covnames = [str(c) for c in covnames]
+    for c in covnames:
+        if c not in _KINDS:
+            raise ValueError("need to choose one of the existing cov functions")
+    if om._h:
+        _lib.lib.obhip_model_destroy(om._h)
+        om._h = None
+    kinds = (C.c_int * len(covnames))(*[_KINDS[c] for c in covnames])
+    h = C.c_void_p()
+    call("obhip_model_create", C.byref(h), len(covnames), C.cast(kinds, C.c_void_p))
+    om._h = h
+    om.covnames = covnames
+    om.d = len(covnames)
+
+
+def setknot(om, knotlist):
+    """interfaceR.cpp:94-149"""
+    om._need()
+    if len(knotlist) != om.d:
+        raise ValueError("dim needs to match%d." % om.d)
+    ks = [_f64(k) for k in knotlist]
+    st = np.zeros(om.d + 1, dtype=np.uint64)
+    st[1:] = np.cumsum([len(k) for k in ks])
+    kp = np.concatenate(ks)
+    call("obhip_model_set_knots", om._h, ptr(st), ptr(kp))
+    om._knotptst = st.astype(np.int64)
+
+
+def gethyp(om):
+    """interfaceR.cpp:167-180 -> (values, names)"""
+    om._need()
+    nh = om.dims()[3]
+    out = np.empty(nh)
+    call("obhip_model_get_hyp", om._h, ptr(out))
+    return out
+
+
+def hypnames(om):
+    names = []
+    for l, c in enumerate(om.covnames):
+        names += ["inpt%d.%s" % (l + 1, h) for h in _HYPNAMES[c]]
+    return names
+
+
+def getpara(logpdf):
+    """interfaceR.cpp:193-199"""
+    return np.array(logpdf.para, dtype=np.float64)
+
+
+# ----------------------------------------------------------------------------
+# terms handle cache
+# ----------------------------------------------------------------------------
+class _Terms:
+    def __init__(self, om, terms):
+        self.array = np.asarray(terms).astype(np.int64)
+        t = _umat(terms)
+        if t.shape[1] != om.d:
+            raise ValueError("terms must have one column per input dimension")
+        h = C.c_void_p()
+        call("obhip_terms_create", C.byref(h), om._h, ptr(t), t.shape[0])
+        self._h = h
+        self.p = t.shape[0]
+        self.d = t.shape[1]
+
+    def maxlevels(self):
+        out = np.empty(self.d, dtype=np.int64)
+        call("obhip_terms_maxlevels", self._h, ptr(out))
+        return out
+
+    def info(self):
+        p, d, nnz, mx = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        call("obhip_terms_info", self._h, C.byref(p), C.byref(d), C.byref(nnz), C.byref(mx))
+        return dict(p=p.value, d=d.value, nnz_total=nnz.value, max_nnz=mx.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib.obhip_terms_destroy(self._h)
+            self._h = None
+
+
+def _terms_of(om, terms):
+    return terms if isinstance(terms, _Terms) else _Terms(om, terms)
+
+
+# ----------------------------------------------------------------------------
+# outerbase (interfaceR.cpp:680-694)
+# ----------------------------------------------------------------------------
+class outerbase:
+    def __init__(self, om, x, levelcap=None):
+        om._need()
+        self.om = om
+        x = _fmat(x)
+        if x.ndim != 2 or x.shape[1] != om.d:
+            raise ValueError("x must be n x d")
+        self.xp = x
+        self.n_row = x.shape[0]
+        cap = None if levelcap is None else np.ascontiguousarray(levelcap, dtype=np.int64)
+        h = C.c_void_p()
+        call("obhip_basis_create", C.byref(h), om._h, ptr(x), x.shape[0], x.shape[0], ptr(cap))
+        self._h = h
+        # OpenMP schedule fields of the reference (modandbase.cpp:504-513) have
+        # no meaning on the device; kept readable for drop-in scripts.
+        self.nthreads = 1
+        self.vertpl = False
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib.obhip_basis_destroy(self._h)
+            self._h = None
+
+    def build(self):
+        call("obhip_basis_rebuild", self._h)
+
+    def getbase(self, k):
+        m = int(np.diff(self.om._knotptst)[k - 1]) if 1 <= k <= self.om.d else 0
+        if m == 0:
+            raise ValueError("dimension out of range (1-based)")
+        out = np.empty((self.n_row, m), order="F")
+        call("obhip_basis_getbase", self._h, int(k), ptr(out))
+        return out
+
+    def getmat(self, terms):
+        t = _terms_of(self.om, terms)
+        out = np.empty((self.n_row, t.p), order="F")
+        call("obhip_basis_getmat", self._h, t._h, ptr(out))
+        return out
+
+    def _mm(self, fn, terms, a, nin, nout):
+        t = _terms_of(self.om, terms)
+        a = _fmat(a)
+        vec = a.ndim == 1
+        a2 = a.reshape(-1, 1, order="F") if vec else a
+        if a2.shape[0] != (t.p if nin == "p" else self.n_row):
+            raise ValueError("non-conformable arguments")
+        rows = self.n_row if nout == "n" else t.p
+        out = np.empty((rows, a2.shape[1]), order="F")
+        call(fn, self._h, t._h, ptr(a2), a2.shape[1], ptr(out))
+        return out[:, 0].copy() if vec else out
+
+    def matmul(self, terms, a):
+        return self._mm("obhip_basis_mm", terms, a, "p", "n")
+
+    def tmatmul(self, terms, a):
+        return self._mm("obhip_basis_tmm", terms, a, "n", "p")
+
+    def sqmm(self, terms, a):
+        return self._mm("obhip_basis_sqmm", terms, a, "p", "n")
+
+    def sqtmm(self, terms, a):
+        return self._mm("obhip_basis_sqtmm", terms, a, "n", "p")
+
+    def sqcolsums(self, terms):
+        t = _terms_of(self.om, terms)
+        out = np.empty(t.p)
+        call("obhip_basis_sqcolsums", self._h, t._h, ptr(out))
+        return out
+
+    def residvar(self, terms):
+        t = _terms_of(self.om, terms)
+        out = np.empty(self.n_row)
+        call("obhip_basis_residvar", self._h, t._h, self.om._h, ptr(out))
+        return out
+
+
+def rvar(y):
+    y = np.asarray(y, dtype=np.float64)
+    return float(np.sum((y - y.mean()) ** 2) / (len(y) - 1))
+
+
+# ----------------------------------------------------------------------------
+# lpdf family (interfaceR.cpp:696-762), value paths
+# ----------------------------------------------------------------------------
+class lpdf:
+    def __init__(self):
+        self.val = 0.0
+        self.coeff = np.zeros(0)
+        self.grad = np.zeros(0)
+        self.para = np.zeros(0)
+        self.nterms = 0
+        self.fullhess = False
+        self.compute_val = True
+        self.compute_grad = True
+        self.paranames = []
+
+    def setnthreads(self, k):  # fit.h:57 (no-op on the device)
+        return None
+
+    def paralpdf(self, parap):
+        parap = np.asarray(parap, dtype=np.float64)
+        if len(parap) != len(self.para0):
+            return -np.inf
+        return float(-0.5 * np.sum((parap - self.para0) ** 2 / self.paravar))  # fit.cpp:133-139
+
+
+class logpr_gauss(lpdf):
+    """src/lpdfs/logpr_gauss.cpp:41-158"""
+
+    def __init__(self, om, terms):
+        super().__init__()
+        self.om = om
+        self.terms = np.asarray(terms).astype(np.int64)
+        self.para0 = np.array([6.0])
+        self.paravar = np.array([4.0])
+        self.paranames = ["coeffscale"]
+        self.para = self.para0.copy()
+        self.nterms = self.terms.shape[0]
+        self.updateom()
+
+    def updateom(self):
+        self.coeffsd = np.sqrt(self.om.getvar(self.terms))
+
+    def updatepara(self, para):
+        self.para = np.array(para, dtype=np.float64).reshape(-1)
+
+    def updateterms(self, terms):
+        self.terms = np.asarray(terms).astype(np.int64)
+        self.nterms = self.terms.shape[0]
+        self.updateom()
+
+    def update(self, coeff):
+        self.coeff = np.array(coeff, dtype=np.float64)
+        sca = math.exp(self.para[0])
+        stdresid = self.coeff / (self.coeffsd * sca)
+        self.val = float(-0.5 * np.sum(stdresid ** 2) - np.sum(np.log(self.coeffsd * sca)))
+        self.grad = -1.0 * stdresid / (self.coeffsd * sca)
+
+    def diaghess(self):
+        return 1.0 / np.square(self.coeffsd * math.exp(self.para[0]))
+
+    def hessmult(self, g):
+        return np.asarray(g) / np.square(self.coeffsd * math.exp(self.para[0]))
+
+
+class _loglik(lpdf):
+    def __init__(self, om, terms, y, x):
+        super().__init__()
+        self.om = om
+        self.y = _f64(y)
+        self.x = _fmat(x)
+        self._t = _Terms(om, terms)
+        self.terms = self._t.array
+        self.nterms = self._t.p
+        self.para0 = np.array([math.log(0.01 * rvar(self.y))])  # loglik_std.cpp:51
+        self.paravar = np.array([1.0])
+        self.paranames = ["noisescale"]
+        self.para = self.para0.copy()
+        # the basis is evaluated up to the highest level the terms use
+        self.ob = outerbase(om, self.x, levelcap=self._t.maxlevels())
+        self.yhat = np.zeros(len(self.y))
+
+    def updateom(self):
+        self.ob.build()
+
+    def updatepara(self, para):
+        self.para = np.array(para, dtype=np.float64).reshape(-1)
+
+    def updateterms(self, terms):
+        self._t = _Terms(self.om, terms)
+        self.terms = self._t.array
+        self.nterms = self._t.p
+        self.ob = outerbase(self.om, self.x, levelcap=self._t.maxlevels())
+
+    def update(self, coeff):
+        # loglik_gauss.cpp:110-130 / loglik_std.cpp:100-120
+        self.coeff = np.array(coeff, dtype=np.float64)
+        s = self.para[0]
+        self.yhat = self.ob.matmul(self._t, self.coeff)
+        resid = math.exp(-s) * (self.yhat - self.y)
+        self.val = float(-0.5 * np.sum(resid ** 2) - len(self.y) * s)
+        self.grad = self.ob.tmatmul(self._t, -math.exp(-s) * resid)
+
+    def hessmult(self, g):
+        v = self.ob.matmul(self._t, np.asarray(g, dtype=np.float64))
+        return self.ob.tmatmul(self._t, math.exp(-2 * self.para[0]) * v)
+
+    def diaghess(self):
+        return math.exp(-2 * self.para[0]) * self.ob.sqcolsums(self._t)
+
+
+class loglik_gauss(_loglik):
+    """src/lpdfs/loglik_gauss.cpp:41-157 (matrix-free)"""
+
+
+class loglik_std(_loglik):
+    """src/lpdfs/loglik_std.cpp:41-173.  The reference materialises the design
+    matrix; here it stays factored and hess() runs the fused Gram kernel."""
+
+    def hess(self):
+        G = _gram_host(self.ob, self._t)
+        return math.exp(-2 * self.para[0]) * G
+
+
+def _gram_host(ob, t):
+    """B^T B through the device Gram kernel, returned to the host."""
+    import torch
+    if not torch.cuda.is_available():
+        raise _lib.ObhipError(2, "no HIP device visible: libobhip has no CPU fallback")
+    G = torch.empty((t.p, t.p), dtype=torch.float64, device="cuda")
+    call("obhip_gram_dev", ob._h, t._h, None, ptr(G), None)
+    torch.cuda.synchronize()
+    return G.cpu().numpy()
+
+
+class lpdfvec(lpdf):
+    """src/fit.cpp:174-363 for a (likelihood, prior) pair, domarg = False."""
+
+    def __init__(self, a, b):
+        super().__init__()
+        liks = [o for o in (a, b) if isinstance(o, _loglik)]
+        prs = [o for o in (a, b) if isinstance(o, logpr_gauss)]
+        if len(liks) != 1 or len(prs) != 1:
+            raise ValueError("lpdfvec needs one likelihood and one logpr_gauss")
+        self.lpdflist = [a, b]
+        self.loglik, self.logpr = liks[0], prs[0]
+        self.terms = self.loglik.terms
+        self.nterms = self.loglik.nterms
+        self.para = np.concatenate([a.para, b.para])
+        self.paranames = a.paranames + b.paranames
+        self.domarg = False
+        self.coeff = np.zeros(self.nterms)
+        self.totdiaghess = None
+        self.tothess = None
+
+    def _sigma_rho(self):
+        return float(self.loglik.para[0]), float(self.logpr.para[0])
+
+    def updateom(self):
+        for o in self.lpdflist:
+            o.updateom()
+
+    def updatepara(self, para):
+        para = np.array(para, dtype=np.float64).reshape(-1)
+        n0 = len(self.lpdflist[0].para)
+        self.lpdflist[0].updatepara(para[:n0])
+        self.lpdflist[1].updatepara(para[n0:])
+        self.para = para
+
+    def updateterms(self, terms):
+        for o in self.lpdflist:
+            o.updateterms(terms)
+        self.terms = self.loglik.terms
+        self.nterms = self.loglik.nterms
+        self.coeff = np.zeros(self.nterms)
+
+    def update(self, coeff):
+        self.coeff = np.array(coeff, dtype=np.float64)
+        for o in self.lpdflist:
+            o.update(self.coeff)
+        self.val = sum(o.val for o in self.lpdflist)
+        self.grad = self.lpdflist[0].grad + self.lpdflist[1].grad
+
+    def hessmult(self, g):
+        return self.lpdflist[0].hessmult(g) + self.lpdflist[1].hessmult(g)
+
+    def diaghess(self):
+        return self.lpdflist[0].diaghess() + self.lpdflist[1].diaghess()
+
+    def hess(self):
+        H = self.loglik.hess()
+        H[np.diag_indices_from(H)] += self.logpr.diaghess()
+        return H
+
+    def optnewton(self):
+        """lpdf::optnewton (fit.cpp:98-131): Gram + Cholesky on the device."""
+        if not isinstance(self.loglik, loglik_std):
+            raise RuntimeError("optnewton needs a loglik_std (loglik_gauss never builds a Hessian)")
+        self.fullhess = True
+        sigma, rho = self._sigma_rho()
+        p = self.nterms
+        theta = np.zeros(p)
+        diagH = np.zeros(p)
+        call("obhip_fit_newton", self.loglik.ob._h, self.loglik._t._h, self.loglik.om._h,
+             ptr(self.loglik.y), sigma, rho, ptr(theta), ptr(diagH), None)
+        self.totdiaghess = diagH
+        self.update(theta)
+
+    def optcg(self, tol, maxepch):
+        """lpdf::optcg (fit.cpp:37-96): matrix-free PCG on the device."""
+        self.fullhess = False
+        sigma, rho = self._sigma_rho()
+        p = self.nterms
+        theta = np.array(self.coeff if len(self.coeff) == p else np.zeros(p), dtype=np.float64)
+        diagH = np.zeros(p)
+        iters = C.c_uint64(0)
+        val = C.c_double(0)
+        call("obhip_fit_cg", self.loglik.ob._h, self.loglik._t._h, self.loglik.om._h,
+             ptr(self.loglik.y), sigma, rho, float(tol), int(maxepch), ptr(theta), C.byref(iters),
+             ptr(diagH), C.byref(val))
+        self.totdiaghess = diagH
+        self.cgiters = iters.value
+        self.update(theta)
+
+
+class predictor:
+    """interfaceR.cpp:725-731; pred_gauss (loglik_gauss.cpp:196-227)."""
+
+    def __init__(self, logpdf):
+        lik = logpdf.loglik if isinstance(logpdf, lpdfvec) else logpdf
+        if not isinstance(lik, _loglik):
+            raise ValueError("cannot produce a predictor from this obj.")  # fit.h:53
+        self.om = lik.om
+        self._t = lik._t
+        self.coeff = np.array(lik.coeff if len(lik.coeff) == lik.nterms
+                              else np.zeros(lik.nterms), dtype=np.float64)
+        self.sigma = float(lik.para[0])
+        td = getattr(logpdf, "totdiaghess", None)
+        self.coeffvar = (1.0 / np.asarray(td)) if td is not None else np.zeros(lik.nterms)
+        self.x = lik.x
+        self._mean = None
+        self._var = None
+
+    def setnthreads(self, k):
+        return None
+
+    def update(self, x):
+        x = _fmat(x)
+        if x.ndim != 2 or x.shape[1] != self.om.d:
+            raise ValueError("x must be n x d")
+        n = x.shape[0]
+        self._mean = np.empty(n)
+        self._var = np.empty(n)
+        cv = _f64(self.coeffvar)
+        call("obhip_predict", self.om._h, self._t._h, ptr(_f64(self.coeff)), ptr(x), n, n,
+             ptr(self._mean), ptr(cv), self.sigma, ptr(self._var))
+        self.x = x
+
+    def mean(self):
+        if self._mean is None:
+            self.update(self.x)
+        return self._mean
+
+    def var(self):
+        if self._var is None:
+            self.update(self.x)
+        return self._var
