@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""Benchmark of the outerbase hot path on MI355X: fit + predict points/sec.
+
+One "step" = one full pass of the hot path over one synthetic batch that is
+already resident in HBM (BASELINE.md sections 2-3):
+
+  fit      standardise y (R/fitting.R:55-57) -> basis build (outerbase::build)
+           -> Gram B^T B on the FP64 matrix cores + B^T y -> [all-reduce over
+           ranks] -> H = e^{-2 sigma} G + prior, Cholesky, two triangular solves
+           (lpdf::optnewton, "back end A")
+  predict  fused basis build at n fresh rows + B theta (predictor$update/$mean)
+
+Default workload: BASELINE.json configs[2] = d=20, n=1e6, p=4096, Matern-5/2 in
+every dimension, 40 knots per dimension, rows sharded over ranks (weak
+scaling: every rank owns n rows).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix (dense); see DESIGN.md
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1_000_000, help="rows per GPU")
+    ap.add_argument("--d", type=int, default=20)
+    ap.add_argument("--p", type=int, default=4096)
+    ap.add_argument("--knots", type=int, default=40)
+    ap.add_argument("--backend", choices=["newton", "cg"], default="newton")
+    ap.add_argument("--kinds", default="mat25", help="comma list cycled over dimensions")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=20000)
+    return ap.parse_args()
+
+
+def check_against_oracle(hp, rows=2000):
+    """Untimed parity of THIS run against the CPU oracle (test infrastructure):
+    (a) device predictions on the first rows of the prediction shard vs the
+    oracle's basis build + B theta with the device's theta; (b) Newton
+    stationarity of the device theta, H theta = e^{-2 sigma} B^T y, evaluated with
+    the matrix-free device kernels (independent of the Gram/Cholesky kernels)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ob_oracle as O
+    from outerbase_amd._lib import call
+    rows = min(rows, hp.n)
+    om = O.OuterMod()
+    om.setcovfs(hp.kinds)
+    om.setknot(O.bench_knots(hp.kinds, hp.m))
+    rot, bv, ml = hp.om.rotation()
+    om.rotmat, om.basisvar, om.maxlevel = rot, bv, ml   # share the device model's rotation
+    theta = hp.theta.cpu().numpy()
+    xnew = hp.xnew[:, :rows].cpu().numpy().T
+    want = hp.y_cent + hp.y_sca * O.predict_mean(om, hp.terms, theta, xnew)
+    got = hp.mean[:rows].cpu().numpy()
+    out = {"rows": rows,
+           "predict_max_rel_err": float(np.max(np.abs(got - want)) / np.max(np.abs(want)))}
+    if hp.backend == "newton" and hp.world == 1:
+        e2 = math.exp(-2 * hp.sigma)
+        tmp = torch.empty(hp.n, dtype=torch.float64, device="cuda")
+        hv = torch.empty(hp.p, dtype=torch.float64, device="cuda")
+        call("obhip_basis_mm_dev", hp.basis, hp.t._h, hp.theta.data_ptr(), tmp.data_ptr(), 0)
+        call("obhip_basis_tmm_dev", hp.basis, hp.t._h, tmp.data_ptr(), hv.data_ptr(), 0)
+        torch.cuda.synchronize()
+        prec = 1.0 / (hp.om.getvar(hp.terms) * math.exp(2 * hp.rho))
+        lhs = e2 * hv.cpu().numpy() + prec * theta
+        rhs = e2 * hp.g.cpu().numpy()
+        out["newton_residual_rel"] = float(np.linalg.norm(lhs - rhs) / np.linalg.norm(rhs))
+    return out
+
+
+def cpu_baseline(hp, ns, threads=16):
+    """The oracle (NumPy restatement of the reference, BLAS for B^T B and the
+    solve) timed on the host cores on a bounded row sample of the same workload;
+    extrapolated to the full n: row-proportional work scales with n, the p x p
+    solve does not."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ob_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    threads = min(threads, os.cpu_count() or 1)
+    ns = min(ns, hp.n)
+
+    def run():
+        om = O.OuterMod()
+        om.setcovfs(hp.kinds)
+        om.setknot(O.bench_knots(hp.kinds, hp.m))
+        x, y = O.synth_xy(42, 0, ns, hp.kinds)
+        xnew, _ = O.synth_xy(43, 0, ns, hp.kinds)
+        y = (y - y.mean()) / y.std(ddof=1)
+        t = {}
+        t0 = time.perf_counter()
+        ob = O.OuterBase(om, x)                        # outerbase::build, all knots
+        t["build"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        B = O.ob_getmat(ob, hp.terms)                  # getm_ (loglik_std ctor)
+        t["getmat"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sigma = O.default_sigma(y)
+        H = math.exp(-2 * sigma) * (B.T @ B)           # loglik_std::hess
+        g = math.exp(-2 * sigma) * (B.T @ y)
+        H[np.diag_indices_from(H)] += O.prior_prec(om, hp.terms, hp.rho)
+        t["gram"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        theta = np.linalg.solve(H, g)                  # fit.cpp:120
+        t["solve"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.predict_mean(om, hp.terms, theta, xnew)      # predictor update + mean
+        t["predict"] = time.perf_counter() - t0
+        return t
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=threads):
+            t = run()
+    else:
+        t = run()
+    per_row = (t["build"] + t["getmat"] + t["gram"] + t["predict"]) / ns
+    full = per_row * hp.n + t["solve"]
+    return {"value": hp.n / full, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": "oracle/ob_oracle.py (NumPy + BLAS, %d threads) on %d rows of the same "
+                      "workload: build %.2fs getmat %.2fs gram %.2fs solve %.2fs predict %.2fs; "
+                      "row work scaled to n=%d, solve counted once"
+                      % (threads, ns, t["build"], t["getmat"], t["gram"], t["solve"], t["predict"],
+                         hp.n)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0 and world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (libobhip has no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import outerbase_amd as ob
+    from outerbase_amd import _lib
+    from outerbase_amd.driver import HotPath
+
+    kinds = [k.strip() for k in args.kinds.split(",")]
+    kinds = [kinds[i % len(kinds)] for i in range(args.d)]
+    hp = HotPath(kinds, args.knots, args.p, args.n, rank=rank, world=world,
+                 backend=args.backend)
+    hp.setup()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        hp.step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hp.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel timing (hipEvents on the launch stream), outside the timed region
+    _lib.call("obhip_profile_reset")
+    _lib.call("obhip_profile_enable", 1)
+    nprof = 2
+    for _ in range(nprof):
+        hp.step()
+    torch.cuda.synchronize()
+    prof = {}
+    for name in ["build_basis", "gram", "gram_reduce", "tmm", "mm", "sqtmm", "form_hessian",
+                 "cholesky", "backsolve", "predict"]:
+        cnt, ms = C.c_uint64(0), C.c_double(0)
+        _lib.call("obhip_profile_get", name.encode(), C.byref(cnt), C.byref(ms))
+        if cnt.value:
+            prof[name] = dict(launches=cnt.value, avg_ms=ms.value / cnt.value,
+                              ms_per_step=ms.value / nprof)
+    _lib.call("obhip_profile_enable", 0)
+
+    # parity of this very run against the oracle on a row sample (cheap, untimed)
+    check = check_against_oracle(hp) if rank == 0 else None
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n, p = args.n, args.p
+    pts = float(n) * world * args.steps
+    ms_per_step = elapsed / args.steps * 1e3
+    out = {
+        "metric": "fit+predict points/sec, d=%d n=%g p=%d" % (args.d, n, p),
+        "value": pts / elapsed,
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[2]: d=%d n=%d rows/GPU p=%d, %s, %d knots/dim, "
+                        "fit (Gram+Cholesky) + predict on n fresh rows"
+                        % (args.d, n, p, "/".join(sorted(set(kinds))), args.knots),
+            "backend": args.backend,
+            "rows_per_gpu": n, "d": args.d, "p": p,
+            "terms_nnz": hp.terms_info["nnz_total"], "basis_columns": hp.ncols,
+            "parallelism": "rows sharded over %d rank(s); all-reduce of G and g" % world,
+        },
+        "kernels_ms": prof,
+        "parity_check": check,
+    }
+    if "gram" in prof and args.backend == "newton":
+        flops = float(n) * p * (p + 1)  # p(p+1) flop per point
+        ach = flops / (prof["gram"]["avg_ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "k_gram", "achieved": ach,
+                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "avg_launch_ms": prof["gram"]["avg_ms"]}
+    elif "mm" in prof:
+        byts = float(n) * 8 * (hp.ncols + 1)
+        ach = byts / (prof["mm"]["avg_ms"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_mm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "avg_launch_ms": prof["mm"]["avg_ms"]}
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(hp, args.cpu_sample)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -252,6 +252,7 @@ int obhip_malloc(void **d_ptr, uint64_t bytes);
 int obhip_free(void *d_ptr);
 int obhip_memcpy_h2d(void *d_dst, const void *src, uint64_t bytes);
 int obhip_memcpy_d2h(void *dst, const void *d_src, uint64_t bytes);
+int obhip_memcpy_d2d(void *d_dst, const void *d_src, uint64_t bytes); /* async */
 
 #ifdef __cplusplus
 }

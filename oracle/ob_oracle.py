@@ -687,7 +687,7 @@ def synth_xy(seed, row0, nrows, kinds):
 def bench_knots(kinds, m=40):
     out = []
     for kd in kinds:
-        g = 0.001 + 0.025 * np.arange(m)
+        g = 0.001 + 0.025 * np.arange(m) if m <= 40 else np.linspace(0.001, 0.976, m)
         if kd == "mat25ang":
             g = g * 6.283185
         out.append(g)

@@ -9,6 +9,15 @@ import ctypes as C
 import os
 import re
 
+# torch bundles its own HIP runtime; it must be the first (and only) libamdhip64
+# in the process, otherwise device enumeration fails in whichever library
+# initialised second.  torch is this package's device-memory / collective
+# plumbing anyway.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - host-only use (model, term selection)
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "obhip.h")
 LIB_PATH = os.path.join(_HERE, "libobhip.so")

@@ -331,6 +331,11 @@ int obhip_memcpy_h2d(void *d_dst, const void *src, uint64_t bytes) {
   return 0;
 }
 
+int obhip_memcpy_d2d(void *d_dst, const void *d_src, uint64_t bytes) {
+  OB_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, cur_stream()));
+  return 0;
+}
+
 int obhip_memcpy_d2h(void *dst, const void *d_src, uint64_t bytes) {
   OB_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, cur_stream()));
   OB_HIP(hipStreamSynchronize(cur_stream()));

@@ -26,6 +26,7 @@ __device__ __forceinline__ double synth_u(uint64_t seed, uint64_t i, uint64_t d,
 __global__ void k_synth(uint64_t seed, uint64_t row0, uint64_t n, uint64_t d,
                         const int *__restrict__ kinds, double *__restrict__ x,
                         double *__restrict__ y) {
+#pragma clang fp contract(off)  // x must be bit-identical on every rank and on the host
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const uint64_t i = row0 + r;

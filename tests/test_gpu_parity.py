@@ -1,0 +1,350 @@
+"""GPU parity tests: every kernel behind the C ABI against the CPU oracle on the
+same seeded inputs.  All arithmetic is FP64; tolerances are stated per test.
+The reference's own identities (tests/testthat/test-obombasic.R) are restated
+through the device path in test_reference_identities.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import KNOTS_REF, knots_for, make_pair, sample_x
+
+pytestmark = pytest.mark.gpu
+
+MIXED = ["mat25pow", "mat25", "mat25ang", "mat25", "mat25pow", "mat25ang", "mat25", "mat25"]
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, np.max(np.abs(b))))
+
+
+def random_terms(rng, p, d, maxlev, max_nnz):
+    """terms with a controlled number of non-zero levels (incl. the constant)."""
+    t = np.zeros((p, d), dtype=np.int64)
+    for k in range(1, p):
+        nnz = int(rng.integers(1, max_nnz + 1))
+        dims = rng.choice(d, size=nnz, replace=False)
+        t[k, dims] = rng.integers(1, maxlev + 1, size=nnz)
+    return t
+
+
+@pytest.fixture(scope="module")
+def mixed_pair():
+    return make_pair(MIXED, knots_for(MIXED), hyp=None)
+
+
+def test_getbase_all_kernels(mixed_pair):
+    """covf::cov x rotmat for all three kernels, every level (covfuncs.cpp:113-310,
+    modandbase.cpp:285-298,634-639).  The sum over knots cancels catastrophically for
+    trailing levels (rotmat ~ 1/lambda), so the tolerance is relative to
+    sum_j |k_j| |rot_jc| per column."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    om_o, om_d = mixed_pair
+    rng = np.random.default_rng(1)
+    x = sample_x(rng, 100, MIXED)
+    bo = O.OuterBase(om_o, x)
+    bd = ob.outerbase(om_d, x)
+    for k in range(1, len(MIXED) + 1):
+        got = bd.getbase(k)
+        want = bo.getbase(k)
+        o = om_o.knotptst[k - 1]
+        m = om_o.knotptst[k] - o
+        K = O.cov(MIXED[k - 1], x[:, k - 1], om_o.knots_of(k - 1), om_o.hyp_of(k - 1))
+        bound = np.abs(K) @ np.abs(om_o.rotmat[:m, o:o + m])
+        assert np.all(np.abs(got - want) <= 1e-13 * bound + 1e-300), "dim %d" % k
+
+
+@pytest.mark.parametrize("hyp_shift", [0.0, 0.3])
+def test_getmat_matmul_tmatmul(hyp_shift):
+    import ob_oracle as O
+    import outerbase_amd as ob
+    hyp = None
+    if hyp_shift:
+        o0, _ = make_pair(MIXED, knots_for(MIXED))
+        hyp = o0.hyp + hyp_shift * np.linspace(-1, 1, len(o0.hyp))
+    om_o, om_d = make_pair(MIXED, knots_for(MIXED), hyp=hyp)
+    rng = np.random.default_rng(2)
+    n = 333
+    x = sample_x(rng, n, MIXED)
+    terms = om_o.selectterms(150)
+    assert np.array_equal(terms, om_d.selectterms(150))
+    bo = O.OuterBase(om_o, x)
+    bd = ob.outerbase(om_d, x)
+    B = O.ob_getmat(bo, terms)
+    assert relerr(bd.getmat(terms), B) < 1e-11
+    a = rng.standard_normal(150)
+    v = rng.standard_normal(n)
+    assert relerr(bd.matmul(terms, a), O.ob_mm(bo, terms, a)) < 1e-11
+    assert relerr(bd.tmatmul(terms, v), O.ob_tmm(bo, terms, v)) < 1e-11
+    assert relerr(bd.sqmm(terms, np.abs(a)), O.ob_sqmm(bo, terms, np.abs(a))) < 1e-11
+    assert relerr(bd.sqtmm(terms, v), O.ob_sqtmm(bo, terms, v)) < 1e-11
+    assert relerr(bd.sqcolsums(terms), O.ob_sqcolsums(bo, terms)) < 1e-11
+    assert np.max(np.abs(bd.residvar(terms) - O.ob_residvar(bo, terms))) < 1e-11
+    # matrix forms (linalg.cpp:481-637)
+    A = rng.standard_normal((150, 3))
+    V = rng.standard_normal((n, 2))
+    assert relerr(bd.matmul(terms, A), O.ob_mm(bo, terms, A)) < 1e-11
+    assert relerr(bd.tmatmul(terms, V), O.ob_tmm(bo, terms, V)) < 1e-11
+
+
+def test_reference_identities():
+    """tests/testthat/test-obombasic.R:21-78 through the device path: n=15, d=8,
+    p=20, knots seq(.001,.999,.025), covs mat25pow + 7 x mat25; summed absolute
+    differences below 0.01 (the reference's tolerance), plus the intended
+    tmatmul identity the reference forgot to check (test-obombasic.R:60)."""
+    import outerbase_amd as ob
+    d = 8
+    kinds = ["mat25pow"] + ["mat25"] * (d - 1)
+    om = ob.outermod()
+    ob.setcovfs(om, kinds)
+    ob.setknot(om, [KNOTS_REF] * d)
+    om.updatehyp(ob.gethyp(om))
+    rng = np.random.default_rng(42)
+    x = rng.random((15, d))
+    terms = om.selectterms(20)
+    b = ob.outerbase(om, x)
+    theta = np.sqrt(om.getvar(terms) / 20) * rng.standard_normal(20)
+    viabase = np.ones((15, 20))
+    for k in range(1, d + 1):
+        viabase *= b.getbase(k)[:, terms[:, k - 1]]
+    B = b.getmat(terms)
+    assert np.sum(np.abs(B - viabase)) < 0.01
+    v1 = B @ theta
+    assert np.sum(np.abs(v1 - b.matmul(terms, theta))) < 0.01
+    assert np.sum(np.abs(B.T @ v1 - b.tmatmul(terms, v1))) < 0.01
+    # and far tighter than the reference asks
+    assert relerr(B, viabase) < 1e-10
+    assert relerr(b.matmul(terms, theta), v1) < 1e-12
+
+
+@pytest.mark.parametrize("n,p", [(200, 100), (10000, 100), (200, 1000), (10000, 2000)])
+def test_shapes_of_reference_gradient_tests(n, p):
+    """the four (n, p) shapes test-obomgrad.R:72-105 uses to hit both OpenMP
+    schedules of the reference; here they hit single/multi tile and
+    single/multi term-block paths."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25"] * 8
+    om_o, om_d = make_pair(kinds, [np.arange(0.001, 0.999, 0.05)] * 8)  # test-lpdf.R:89
+    rng = np.random.default_rng(n + p)
+    x = rng.random((n, 8))
+    terms = om_o.selectterms(p)
+    bo = O.OuterBase(om_o, x)
+    bd = ob.outerbase(om_d, x, levelcap=terms.max(axis=0))
+    a = rng.standard_normal(p)
+    v = rng.standard_normal(n)
+    # 20 knots per dimension: 1000+ terms reach levels with eigenvalue ratio ~1e-8,
+    # i.e. rotmat entries ~1e6, so the sum over knots cancels 6 digits in BOTH
+    # implementations; agreement is limited by that conditioning, not by the kernels.
+    assert relerr(bd.matmul(terms, a), O.ob_mm(bo, terms, a)) < 1e-7
+    assert relerr(bd.tmatmul(terms, v), O.ob_tmm(bo, terms, v)) < 1e-7
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 130])
+@pytest.mark.parametrize("p", [1, 129, 300])
+def test_ragged_sizes(n, p):
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25", "mat25pow", "mat25ang"]
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 20))
+    rng = np.random.default_rng(7 * n + p)
+    x = sample_x(rng, n, kinds)
+    terms = om_o.selectterms(p)
+    bo = O.OuterBase(om_o, x)
+    bd = ob.outerbase(om_d, x)
+    a = rng.standard_normal(p)
+    v = rng.standard_normal(n)
+    # 3 dimensions x 20 knots: 129+ terms climb to levels with rotmat ~1e5
+    # (see test_shapes_of_reference_gradient_tests); p = 1 is exact to rounding.
+    tol = 1e-12 if p == 1 else 1e-7
+    assert relerr(bd.matmul(terms, a), O.ob_mm(bo, terms, a)) < tol
+    assert relerr(bd.tmatmul(terms, v), O.ob_tmm(bo, terms, v)) < tol
+    if n > 1:
+        lik = ob.loglik_std(om_d, terms, v, x)
+        G = lik.hess() * math.exp(2 * lik.para[0])
+        B = O.ob_getmat(bo, terms)
+        assert relerr(G, B.T @ B) < tol
+        assert np.array_equal(G, G.T)
+
+
+@pytest.mark.parametrize("max_nnz", [1, 2, 3, 5, 6, 8])
+def test_gram_term_widths(max_nnz):
+    """Gram kernel template widths W = 2, 4, 6, 8 (non-zero levels per term)."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25"] * 10
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 24))
+    rng = np.random.default_rng(max_nnz)
+    n, p = 500, 200
+    x = sample_x(rng, n, kinds)
+    terms = random_terms(rng, p, 10, 6, max_nnz)
+    bo = O.OuterBase(om_o, x)
+    y = rng.standard_normal(n)
+    lik = ob.loglik_std(om_d, terms, y, x)
+    G = lik.hess() * math.exp(2 * lik.para[0])
+    B = O.ob_getmat(bo, terms)
+    # 24 knots, levels up to 6 (eigenvalue ratio ~3e-7): ~1e-10 agreement
+    assert relerr(G, B.T @ B) < 2e-9
+    a = rng.standard_normal(p)
+    assert relerr(lik.ob.matmul(terms, a), B @ a) < 2e-9
+    assert relerr(lik.ob.tmatmul(terms, y), B.T @ y) < 2e-9
+
+
+def test_gram_rejects_wide_terms():
+    import outerbase_amd as ob
+    kinds = ["mat25"] * 12
+    _, om_d = make_pair(kinds, knots_for(kinds, 16))
+    rng = np.random.default_rng(3)
+    x = sample_x(rng, 100, kinds)
+    terms = np.zeros((5, 12), dtype=np.int64)
+    terms[1, :9] = 1
+    lik = ob.loglik_std(om_d, terms, rng.standard_normal(100), x)
+    with pytest.raises(ob.ObhipError):
+        lik.hess()
+    # the matrix-free path has no such limit
+    assert np.all(np.isfinite(lik.ob.matmul(terms, np.ones(5))))
+
+
+def _fit_case(rng, kinds, n, p, m=40):
+    import ob_oracle as O
+    om_o, om_d = make_pair(kinds, knots_for(kinds, m))
+    x, y = O.synth_xy(42, 0, n, kinds)
+    y = (y - y.mean()) / y.std(ddof=1)
+    xnew, _ = O.synth_xy(43, 0, 257, kinds)
+    terms = om_o.selectterms(p)
+    return om_o, om_d, x, y, xnew, terms
+
+
+@pytest.mark.parametrize("kinds,n,p", [
+    (["mat25pow"] * 8, 1000, 256),                      # BASELINE config 1
+    (["mat25"] * 10, 3000, 300),
+    (["mat25", "mat25pow", "mat25ang"] * 3, 2000, 200),
+])
+def test_newton_fit_and_predict(kinds, n, p):
+    """optnewton (fit.cpp:98-131) + predictor (loglik_gauss.cpp:214-227):
+    predictions within 1e-6 relative of the oracle (north_star tolerance)."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    rng = np.random.default_rng(5)
+    om_o, om_d, x, y, xnew, terms = _fit_case(rng, kinds, n, p)
+    bo = O.OuterBase(om_o, x)
+    theta_o, H_o = O.fit_newton(bo, terms, y)
+    lik = ob.loglik_std(om_d, terms, y, x)
+    pr = ob.logpr_gauss(om_d, terms)
+    lp = ob.lpdfvec(lik, pr)
+    lp.optnewton()
+    # Hessian itself
+    assert relerr(lp.hess(), H_o) < 1e-10
+    # predictions at new inputs and at the training inputs
+    pred = ob.predictor(lp)
+    pred.update(xnew)
+    mean_o = O.predict_mean(om_o, terms, theta_o, xnew)
+    assert relerr(pred.mean(), mean_o) < 1e-6
+    assert relerr(lik.yhat, O.ob_mm(bo, terms, theta_o)) < 1e-6
+    # pred_gauss variance from the diagonal of H (loglik_gauss.cpp:223-227)
+    var_o = O.predict_var_gauss(om_o, terms, np.diag(H_o), O.default_sigma(y), xnew)
+    assert relerr(pred.var(), var_o) < 1e-9
+    # Newton stationarity: H theta = e^{-2 sigma} B^T y
+    rhs = math.exp(-2 * O.default_sigma(y)) * O.ob_tmm(bo, terms, y)
+    assert relerr(H_o @ lp.coeff, rhs) < 1e-7
+
+
+def test_cg_fit_matches_oracle_iterations():
+    """optcg (fit.cpp:37-96): same iteration count and iterate as the oracle at
+    the reference's iteration cap (.getsteps, R/fitting.R:188-195); and at tight
+    tolerance the CG solution converges to the Newton one."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25"] * 8
+    rng = np.random.default_rng(6)
+    om_o, om_d, x, y, xnew, terms = _fit_case(rng, kinds, 2000, 150)
+    bo = O.OuterBase(om_o, x)
+    steps = O.getsteps(150, 2000, O.rvar(y) / math.exp(2 * O.default_sigma(y)))
+    th_o, it_o, m_o = O.fit_cg(bo, terms, y, tol=1e-3, maxit=steps)
+    lik = ob.loglik_gauss(om_d, terms, y, x)
+    pr = ob.logpr_gauss(om_d, terms)
+    lp = ob.lpdfvec(pr, lik)
+    lp.optcg(1e-3, steps)
+    assert lp.cgiters == it_o
+    assert relerr(lp.totdiaghess, m_o) < 1e-10
+    assert relerr(lik.yhat, O.ob_mm(bo, terms, th_o)) < 1e-6
+    # tight CG == Newton on predictions
+    lp.optcg(1e-14, 2000)
+    th_n, _ = O.fit_newton(bo, terms, y)
+    assert relerr(lik.yhat, O.ob_mm(bo, terms, th_n)) < 1e-6
+
+
+def test_level_caps_do_not_change_results():
+    import outerbase_amd as ob
+    kinds = ["mat25"] * 6
+    _, om_d = make_pair(kinds, knots_for(kinds, 30))
+    rng = np.random.default_rng(8)
+    x = sample_x(rng, 400, kinds)
+    terms = om_d.selectterms(120)
+    full = ob.outerbase(om_d, x)
+    capped = ob.outerbase(om_d, x, levelcap=terms.max(axis=0))
+    a = rng.standard_normal(120)
+    assert np.array_equal(full.matmul(terms, a), capped.matmul(terms, a))
+    with pytest.raises(ob.ObhipError):
+        ob.outerbase(om_d, x, levelcap=np.zeros(6, dtype=np.int64)).matmul(terms, a)
+
+
+def test_rebuild_after_hyp_change():
+    """vignettes/learning.Rmd:48-54: an outerbase does not follow the outermod
+    until build() is called again."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25", "mat25pow", "mat25"]
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 20), share_rotation=False)
+    rng = np.random.default_rng(9)
+    x = sample_x(rng, 100, kinds)
+    terms = om_d.selectterms(30)
+    b = ob.outerbase(om_d, x)
+    before = b.getmat(terms)
+    om_d.updatehyp(ob.gethyp(om_d) + 0.2)
+    assert np.array_equal(b.getmat(terms), before)
+    b.build()
+    after = b.getmat(terms)
+    assert relerr(after, before) > 1e-3
+    om_o.hyp_set(om_o.hyp + 0.2)
+    om_d.set_rotation(om_o.rotmat, om_o.basisvar, om_o.maxlevel)
+    b.build()
+    assert relerr(b.getmat(terms), O.ob_getmat(O.OuterBase(om_o, x), terms)) < 1e-10
+
+
+def test_own_eigensolver_low_levels():
+    """Without sharing the rotation: the library's Jacobi eigen-solver against
+    LAPACK on the levels term selection actually uses (well separated
+    eigenvalues); trailing levels are numerically undetermined in both."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25"] * 5
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 40), share_rotation=False)
+    rng = np.random.default_rng(10)
+    x = sample_x(rng, 200, kinds)
+    terms = om_o.selectterms(300)
+    assert np.array_equal(terms, om_d.selectterms(300))
+    assert terms.max() <= 12
+    got = ob.outerbase(om_d, x, levelcap=terms.max(axis=0)).getmat(terms)
+    want = O.ob_getmat(O.OuterBase(om_o, x), terms)
+    assert relerr(got, want) < 1e-6
+
+
+def test_synthetic_generator_matches_oracle():
+    import ctypes as C
+    import torch
+    import ob_oracle as O
+    from outerbase_amd import _lib
+    kinds = ["mat25", "mat25ang", "mat25pow"] * 4
+    kid = {"mat25": 0, "mat25pow": 1, "mat25ang": 2}
+    n, d = 1000, len(kinds)
+    x = torch.empty((d, n), dtype=torch.float64, device="cuda")
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    arr = (C.c_int * d)(*[kid[k] for k in kinds])
+    _lib.call("obhip_synth_xy_dev", 42, 5000, n, d, C.cast(arr, C.c_void_p), x.data_ptr(), y.data_ptr())
+    torch.cuda.synchronize()
+    xo, yo = O.synth_xy(42, 5000, n, kinds)
+    assert np.array_equal(x.cpu().numpy().T, xo)
+    assert relerr(y.cpu().numpy(), yo) < 1e-13
