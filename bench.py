@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--knots", type=int, default=40)
     ap.add_argument("--backend", choices=["newton", "cg"], default="newton")
     ap.add_argument("--kinds", default="mat25", help="comma list cycled over dimensions")
+    ap.add_argument("--gram-backend", type=int, default=0,
+                    help="0 auto, 1 FP64 matrix cores, 2 FP64 vector pipe")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000)
     return ap.parse_args()
@@ -169,6 +171,7 @@ def main():
     hp = HotPath(kinds, args.knots, args.p, args.n, rank=rank, world=world,
                  backend=args.backend)
     hp.setup()
+    _lib.call("obhip_set_gram_backend", args.gram_backend)
 
     def sync():
         torch.cuda.synchronize()

@@ -238,6 +238,12 @@ int obhip_gram_dev(const obhip_basis *b, const obhip_terms *t, const double *d_y
   return 0;
 }
 
+int obhip_set_gram_backend(int backend) {
+  if (backend < 0 || backend > 2) return fail(OBHIP_ERR_INVALID, "gram backend must be 0, 1 or 2");
+  set_gram_backend(backend);
+  return 0;
+}
+
 int obhip_newton_workspace_bytes(uint64_t p, uint64_t *bytes) {
   if (!bytes) return fail(OBHIP_ERR_INVALID, "null argument");
   // z + info (Cholesky) + prior precision + scaled right-hand side

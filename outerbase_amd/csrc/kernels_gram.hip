@@ -25,6 +25,8 @@
 
 namespace obhip {
 
+int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, double *d_G);
+
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -172,19 +174,32 @@ int run_gram(const obhip_basis &b, obhip_terms &t, double *d_G) {
                        ntiles, tps, part);
     OB_HIP(hipGetLastError());
   }
-  {
-    ProfScope ps("gram_reduce");
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)npairs), dim3(256), 0, cur_stream(), part,
-                       npairs, (int)nsplit, nb, (int)t.p, d_G);
-    OB_HIP(hipGetLastError());
-  }
-  return 0;
+  return launch_gram_reduce(part, npairs, (int)nsplit, nb, (int)t.p, d_G);
 }
 
 }  // namespace
 
+int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, double *d_G) {
+  ProfScope ps("gram_reduce");
+  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)npairs), dim3(256), 0, cur_stream(), part, npairs,
+                     nsplit, nb, p, d_G);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gram_valu(const obhip_basis &b, obhip_terms &t, double *d_G);
+bool gram_valu_supports(const obhip_terms &t);
+
+// 0 = automatic (vector pipe when the terms fit it, else matrix cores),
+// 1 = v_mfma_f64_16x16x4_f64 kernel, 2 = v_fma_f64 register-tiled kernel
+static int g_gram_backend = 0;
+void set_gram_backend(int b) { g_gram_backend = b; }
+int get_gram_backend() { return g_gram_backend; }
+
 int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  if (g_gram_backend == 2 || (g_gram_backend == 0 && gram_valu_supports(t)))
+    return launch_gram_valu(b, t, d_G);
   if (t.Mu > 300)
     return fail(OBHIP_ERR_INVALID, "terms touch too many basis columns for the LDS tile");
   // the column-list table is padded to a multiple of 256 terms, which covers

@@ -199,6 +199,8 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a,
                double *d_out, bool squared);
 // kernels_gram.hip
 int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G);
+void set_gram_backend(int b);
+int get_gram_backend();
 // kernels_chol.hip
 uint64_t newton_workspace_bytes(uint64_t p);
 int launch_newton_solve(uint64_t p, double *d_H, const double *d_rhs,

@@ -169,9 +169,42 @@ def test_ragged_sizes(n, p):
         assert np.array_equal(G, G.T)
 
 
+@pytest.fixture
+def gram_backend(request):
+    """1 = FP64 matrix-core kernel, 2 = FP64 vector-pipe kernel, 0 = automatic."""
+    from outerbase_amd import _lib
+    _lib.call("obhip_set_gram_backend", request.param)
+    yield request.param
+    _lib.call("obhip_set_gram_backend", 0)
+
+
+@pytest.mark.parametrize("gram_backend", [1, 2], indirect=True)
+@pytest.mark.parametrize("n,p", [(2, 1), (65, 127), (200, 128), (1000, 129), (5000, 700)])
+def test_gram_backends(gram_backend, n, p):
+    """both Gram kernels on single/multi tile pairs, ragged edges and multiple
+    row splits, against B^T B of the oracle; exact symmetry of the result."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25", "mat25pow", "mat25ang", "mat25"]
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 40))
+    rng = np.random.default_rng(n + 31 * p)
+    x = sample_x(rng, n, kinds)
+    terms = om_o.selectterms(p)
+    y = rng.standard_normal(n)
+    lik = ob.loglik_std(om_d, terms, y, x)
+    G = lik.hess() * math.exp(2 * lik.para[0])
+    B = O.ob_getmat(O.OuterBase(om_o, x), terms)
+    # 700 terms in 4 dimensions reach level ~10 (eigenvalue ratio ~1e-9): both sides
+    # lose digits in the knot sum; low-level cases agree to ~1e-13
+    assert relerr(G, B.T @ B) < (1e-7 if p > 200 else 1e-11)
+    assert np.array_equal(G, G.T)
+
+
+@pytest.mark.parametrize("gram_backend", [1, 2], indirect=True)
 @pytest.mark.parametrize("max_nnz", [1, 2, 3, 5, 6, 8])
-def test_gram_term_widths(max_nnz):
-    """Gram kernel template widths W = 2, 4, 6, 8 (non-zero levels per term)."""
+def test_gram_term_widths(gram_backend, max_nnz):
+    """terms with 1..8 non-zero levels (MFMA kernel template widths W = 2, 4, 6,
+    8; runtime width in the vector-pipe kernel)."""
     import ob_oracle as O
     import outerbase_amd as ob
     kinds = ["mat25"] * 10
@@ -192,19 +225,32 @@ def test_gram_term_widths(max_nnz):
     assert relerr(lik.ob.tmatmul(terms, y), B.T @ y) < 2e-9
 
 
-def test_gram_rejects_wide_terms():
+def test_gram_wide_terms():
+    """a term with 9 non-zero levels: the matrix-core kernel (widths up to 8)
+    refuses it loudly, the vector-pipe kernel and the matrix-free path take it."""
+    import ob_oracle as O
     import outerbase_amd as ob
+    from outerbase_amd import _lib
     kinds = ["mat25"] * 12
-    _, om_d = make_pair(kinds, knots_for(kinds, 16))
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 16))
     rng = np.random.default_rng(3)
     x = sample_x(rng, 100, kinds)
     terms = np.zeros((5, 12), dtype=np.int64)
     terms[1, :9] = 1
+    terms[2, 3] = 2
     lik = ob.loglik_std(om_d, terms, rng.standard_normal(100), x)
-    with pytest.raises(ob.ObhipError):
-        lik.hess()
-    # the matrix-free path has no such limit
-    assert np.all(np.isfinite(lik.ob.matmul(terms, np.ones(5))))
+    B = O.ob_getmat(O.OuterBase(om_o, x), terms)
+    try:
+        for backend in (0, 1, 2):
+            _lib.call("obhip_set_gram_backend", backend)
+            with pytest.raises(ob.ObhipError):
+                lik.hess()
+    finally:
+        _lib.call("obhip_set_gram_backend", 0)
+    # the matrix-free path (and with it the CG fit) has no such limit
+    assert relerr(lik.ob.matmul(terms, np.ones(5)), B @ np.ones(5)) < 1e-11
+    v = rng.standard_normal(100)
+    assert relerr(lik.ob.tmatmul(terms, v), B.T @ v) < 1e-11
 
 
 def _fit_case(rng, kinds, n, p, m=40):
