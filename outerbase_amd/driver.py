@@ -34,6 +34,30 @@ def bench_knots(kinds, m=40):
     return out
 
 
+def shard_rows(rank, rows_per_rank):
+    """Row block of the counter-based synthetic stream owned by `rank`
+    (contiguous row blocks, no data exchange)."""
+    return rank * rows_per_rank, rows_per_rank
+
+
+def global_standardise(local_sum, centre_and_sumsq, n_total, reduce_floats):
+    """Mean and sd (n-1 denominator, R/fitting.R:55-57) of a vector sharded over
+    ranks, two-pass for accuracy.  local_sum() -> sum of the local shard;
+    centre_and_sumsq(cent) subtracts cent from the local shard and returns its sum
+    of squares; reduce_floats(list) -> element-wise sums over all ranks."""
+    cent = reduce_floats([local_sum()])[0] / n_total
+    ss = reduce_floats([centre_and_sumsq(cent)])[0]
+    return cent, math.sqrt(ss / (n_total - 1.0))
+
+
+def merge_normal_equations(G, g, all_reduce):
+    """Back end A's only exchange: sum the per-rank Gram and right-hand side
+    (SURVEY.md section 8e).  all_reduce(tensor) sums in place over ranks."""
+    all_reduce(G)
+    all_reduce(g)
+    return G, g
+
+
 class HotPath:
     def __init__(self, kinds, knots_per_dim, p, n, rank=0, world=1, backend="newton",
                  seed_train=42, seed_pred=43, rho=DEFAULT_RHO, cg_tol=1e-10, cg_maxit=None):
@@ -84,7 +108,7 @@ class HotPath:
         self.ws = torch.empty(wsb.value, dtype=torch.uint8, device=dev)
         self.wsb = wsb.value
         kid = (C.c_int * d)(*[KIND_ID[k] for k in self.kinds])
-        row0 = self.rank * n
+        row0, _ = shard_rows(self.rank, n)
         scratch = torch.empty(n, dtype=f64, device=dev)
         call("obhip_synth_xy_dev", self.seed_train, row0, n, d, C.cast(kid, C.c_void_p),
              self.x.data_ptr(), self.y_raw.data_ptr())
@@ -117,16 +141,26 @@ class HotPath:
 
     # -- y = (y - mean) / sd over ALL ranks (R/fitting.R:55-57) ------------------------
     def standardise(self):
-        torch = self.torch
         n_tot = float(self.n * self.world)
         self.y.copy_(self.y_raw)
-        call("obhip_sum_sumsq_dev", self.y.data_ptr(), self.n, self.stats.data_ptr())
-        self._allreduce(self.stats)
-        cent = float(self.stats[0].item()) / n_tot
-        call("obhip_affine_dev", self.y.data_ptr(), self.n, cent, 1.0)
-        call("obhip_sum_sumsq_dev", self.y.data_ptr(), self.n, self.stats.data_ptr())
-        self._allreduce(self.stats)
-        sd = math.sqrt(float(self.stats[1].item()) / (n_tot - 1.0))
+
+        def local_sum():
+            call("obhip_sum_sumsq_dev", self.y.data_ptr(), self.n, self.stats.data_ptr())
+            return float(self.stats[0].item())
+
+        def centre_and_sumsq(cent):
+            call("obhip_affine_dev", self.y.data_ptr(), self.n, cent, 1.0)
+            call("obhip_sum_sumsq_dev", self.y.data_ptr(), self.n, self.stats.data_ptr())
+            return float(self.stats[1].item())
+
+        def reduce_floats(vals):
+            if self.world == 1:
+                return vals
+            t = self.torch.tensor(vals, dtype=self.torch.float64, device=self.stats.device)
+            self._allreduce(t)
+            return [float(v) for v in t.tolist()]
+
+        cent, sd = global_standardise(local_sum, centre_and_sumsq, n_tot, reduce_floats)
         call("obhip_affine_dev", self.y.data_ptr(), self.n, 0.0, sd)
         self.y_cent, self.y_sca = cent, sd
         # loglik_std.cpp:51: para0 = log(0.01 * var(y)); var of the standardised y is 1
@@ -146,8 +180,7 @@ class HotPath:
         if self.backend == "newton":
             call("obhip_gram_dev", self.basis, self.t._h, self.y.data_ptr(), self.G.data_ptr(),
                  self.g.data_ptr())
-            self._allreduce(self.G)
-            self._allreduce(self.g)
+            merge_normal_equations(self.G, self.g, self._allreduce)
             call("obhip_newton_solve_dev", self.om._h, self.t._h, self.G.data_ptr(),
                  self.g.data_ptr(), self.sigma, self.rho, self.theta.data_ptr(),
                  self.diagH.data_ptr(), self.ws.data_ptr(), self.wsb)

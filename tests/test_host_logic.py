@@ -1,0 +1,197 @@
+"""CPU-side tests of libobhip: the ABI surface, the host logic behind it
+(covariances on knots, eigen-model, term selection, variances, priors, error
+behaviour) against the oracle, and the loud failure without a GPU.  No device
+arithmetic is called here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ob_oracle as O
+from conftest import KNOTS_REF, make_pair
+
+
+def test_library_exports_every_declared_symbol():
+    from outerbase_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 55
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    missing = sorted(set(protos) - exported)
+    assert not missing, "declared in include/obhip.h but not exported: %s" % missing
+    extra = sorted(s for s in exported if s.startswith("obhip_") and s not in protos)
+    assert not extra, "exported but not declared: %s" % extra
+    assert _lib.lib.obhip_abi_version() == 1
+
+
+def test_header_cites_reference_for_every_entry_point():
+    from outerbase_amd import _lib
+    src = open(_lib.HEADER).read()
+    for token in ("interfaceR.cpp", "modandbase.cpp", "linalg.cpp", "covfuncs.cpp", "fit.cpp",
+                  "loglik_std.cpp", "loglik_gauss.cpp", "logpr_gauss.cpp"):
+        assert token in src
+
+
+@pytest.mark.parametrize("kind", ["mat25", "mat25pow", "mat25ang"])
+def test_cov_host_matches_oracle(kind):
+    import outerbase_amd as ob
+    cls = {"mat25": ob.covf_mat25, "mat25pow": ob.covf_mat25pow, "mat25ang": ob.covf_mat25ang}[kind]
+    c = cls()
+    info = O.COV_INFO[kind]
+    assert np.allclose(c.hyp0, info["hyp0"]) and np.allclose(c.hyplb, info["hyplb"])
+    assert np.allclose(c.hypub, info["hypub"]) and np.allclose(c.hypvar, info["hypvar"])
+    assert c.lowbnd == info["lowbnd"] and c.uppbnd == info["uppbnd"]
+    rng = np.random.default_rng(0)
+    x1 = info["lowbnd"] + (info["uppbnd"] - info["lowbnd"]) * (0.01 + 0.98 * rng.random(17))
+    x2 = info["lowbnd"] + (info["uppbnd"] - info["lowbnd"]) * (0.01 + 0.98 * rng.random(9))
+    c.hyp = np.asarray(info["hyp0"]) + 0.3
+    assert np.allclose(c.cov(x1, x2), O.cov(kind, x1, x2, c.hyp), rtol=1e-14, atol=1e-15)
+    assert np.allclose(np.diag(c.cov(x1, x1)), c.covdiag(x1))
+    assert abs(c.lpdf(c.hyp) - O.cov_hyp_lpdf(kind, c.hyp)) < 1e-12
+    assert c.lpdf(np.asarray(info["hypub"]) + 1.0) == -np.inf
+
+
+def test_eigenmodel_matches_lapack_on_leading_levels():
+    """outermod::build (modandbase.cpp:210-255) with the library's Jacobi solver
+    vs the oracle's LAPACK: eigenvalues to 1e-9 relative and rotation columns to
+    1e-7 on the levels with lambda_j / lambda_0 > 1e-9; maxlevel identical."""
+    kinds = ["mat25pow", "mat25", "mat25ang"]
+    om_o, om_d = make_pair(kinds, O.bench_knots(kinds, 40), share_rotation=False)
+    rot, bv, ml = om_d.rotation()
+    assert rot.shape == om_o.rotmat.shape
+    for l in range(3):
+        o = om_o.knotptst[l]
+        lam = np.exp(om_o.basisvar[o:o + 40])
+        good = np.nonzero(lam / lam[0] > 1e-9)[0]
+        assert len(good) >= 8
+        assert np.allclose(bv[o + good], om_o.basisvar[o + good], atol=1e-7)
+        if kinds[l] == "mat25ang":
+            # the periodic kernel has (near-)degenerate sin/cos eigen-pairs: only the
+            # eigenvalues are determined, the basis inside a pair is not
+            continue
+        num = np.abs(rot[:, o + good] - om_o.rotmat[:, o + good]).max(axis=0)
+        den = np.abs(om_o.rotmat[:, o + good]).max(axis=0)
+        assert np.all(num / den < 1e-5)
+    assert np.all(np.abs(ml - om_o.maxlevel) <= 2)
+    assert np.all(ml >= 8)
+
+
+@pytest.mark.parametrize("kinds,m,p", [
+    (["mat25pow"] + ["mat25"] * 7, None, 20),          # test-obombasic.R
+    (["mat25"] * 10, 40, 1024),                        # BASELINE config 2
+    (["mat25", "mat25pow", "mat25ang"] * 2, 24, 500),
+])
+def test_selectterms_equals_oracle(kinds, m, p):
+    knots = [KNOTS_REF] * len(kinds) if m is None else O.bench_knots(kinds, m)
+    om_o, om_d = make_pair(kinds, knots)
+    got = om_d.selectterms(p)
+    assert np.array_equal(got, om_o.selectterms(p))
+    assert np.allclose(om_d.getvar(got), om_o.getvar(got), rtol=1e-13)
+    # the seeded variant (stand-in for the reference's R-RNG shuffle) keeps the invariants
+    rnd = om_d.selectterms(p, seed=12345)
+    assert np.array_equal(rnd, om_d.selectterms(p, seed=12345))
+    seen = set()
+    for t in rnd:
+        tt = tuple(int(v) for v in t)
+        for l in range(len(kinds)):
+            if t[l] > 0:
+                par = list(tt)
+                par[l] -= 1
+                assert tuple(par) in seen
+        seen.add(tt)
+    assert len(seen) == p
+
+
+def test_headline_terms_statistics():
+    """the deterministic selection used by bench.py for BASELINE config 3."""
+    kinds = ["mat25"] * 20
+    _, om_d = make_pair(kinds, O.bench_knots(kinds, 40), share_rotation=False)
+    terms = om_d.selectterms(4096)
+    assert terms.shape == (4096, 20)
+    assert terms.max() == 5
+    nnz = (terms > 0).sum(axis=1)
+    assert nnz.max() == 4 and int(nnz.sum()) == 12177
+
+
+def test_hyp_and_prior_plumbing():
+    import outerbase_amd as ob
+    kinds = ["mat25pow", "mat25", "mat25ang"]
+    om_o, om_d = make_pair(kinds, O.bench_knots(kinds, 16), share_rotation=False)
+    hyp = ob.gethyp(om_d)
+    assert np.array_equal(hyp, om_o.hyp) and len(hyp) == 5
+    assert ob.hypnames(om_d) == ["inpt1.scale", "inpt1.power", "inpt2.scale", "inpt3.sin.sc",
+                                 "inpt3.cos.sc"]
+    h2 = hyp + np.array([0.1, -0.05, 0.2, 0.0, -0.3])
+    assert abs(om_d.hyplpdf(h2) - om_o.hyplpdf(h2)) < 1e-12
+    assert om_d.hyplpdf(hyp[:3]) == -np.inf
+    om_d.updatehyp(h2)
+    om_o.hyp_set(h2)
+    assert np.allclose(om_d.basisvar[:5], om_o.basisvar[:5], atol=1e-9)
+    t = om_o.selectterms(40)
+    pr = ob.logpr_gauss(om_d, t)
+    pr.update(np.linspace(-1, 1, 40))
+    coeffsd = np.sqrt(om_o.getvar(t))
+    sca = np.exp(6.0)
+    sr = np.linspace(-1, 1, 40) / (coeffsd * sca)
+    assert abs(pr.val - (-0.5 * np.sum(sr ** 2) - np.sum(np.log(coeffsd * sca)))) < 1e-6 * abs(pr.val)
+    assert np.allclose(pr.diaghess(), O.prior_prec(om_o, t, 6.0), rtol=1e-6)
+    assert np.array_equal(ob.getpara(pr), [6.0])
+
+
+def test_error_behaviour_matches_reference():
+    import outerbase_amd as ob
+    from outerbase_amd import _lib
+    om = ob.outermod()
+    with pytest.raises(RuntimeError):          # interfaceR.cpp:95-98
+        ob.setknot(om, [KNOTS_REF])
+    with pytest.raises(ValueError):
+        ob.setcovfs(om, ["mat52"])
+    ob.setcovfs(om, ["mat25", "mat25"])
+    with pytest.raises(ValueError):            # interfaceR.cpp:99-106 dims
+        ob.setknot(om, [KNOTS_REF])
+    with pytest.raises(ob.ObhipError) as e:    # interfaceR.cpp:107-119 bounds
+        ob.setknot(om, [KNOTS_REF, KNOTS_REF + 0.5])
+    assert "knot point needs to be between" in str(e.value)
+    with pytest.raises(ob.ObhipError):         # selectterms before knots
+        om.selectterms(5)
+    ob.setknot(om, [KNOTS_REF, KNOTS_REF])
+    with pytest.raises(ob.ObhipError):         # modandbase.cpp:171-176 (check the reference commented out)
+        om.updatehyp([0.0])
+    with pytest.raises(ob.ObhipError):         # level beyond the knots
+        om.getvar(np.array([[0, 99]]))
+    assert _lib.lib.obhip_last_error() != b""
+
+
+def test_no_gpu_fails_loudly():
+    """Without a device every device-touching entry point returns
+    OBHIP_ERR_NO_DEVICE; there is no CPU fallback to fall into."""
+    import torch
+    import outerbase_amd as ob
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    assert ob.device_count() == 0
+    om = ob.outermod()
+    ob.setcovfs(om, ["mat25"] * 3)
+    ob.setknot(om, [KNOTS_REF] * 3)
+    x = np.random.default_rng(0).random((10, 3))
+    with pytest.raises(ob.ObhipError) as e:
+        ob.outerbase(om, x)
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+    t = om.selectterms(8)
+    with pytest.raises(ob.ObhipError):
+        ob.loglik_gauss(om, t, x[:, 0], x)
+    from outerbase_amd import _lib
+    p = C.c_void_p()
+    assert _lib.lib.obhip_malloc(C.byref(p), 64) == 2
+
+
+def test_product_path_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "outerbase_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "ob_oracle" not in txt and "oracle/" not in txt, f
