@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--backend", choices=["newton", "cg"], default="newton")
     ap.add_argument("--kinds", default="mat25", help="comma list cycled over dimensions")
     ap.add_argument("--gram-backend", type=int, default=0,
-                    help="0 auto, 1 FP64 matrix cores, 2 FP64 vector pipe")
+                    help="0 auto, 1 MFMA 16x16x4, 2 vector pipe, 3 MFMA 4x4x4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000)
     return ap.parse_args()

@@ -185,10 +185,11 @@ int obhip_basis_tmm_dev(const obhip_basis *b, const obhip_terms *t,
  * NULL (then d_g is untouched). */
 int obhip_gram_dev(const obhip_basis *b, const obhip_terms *t,
                    const double *d_y, double *d_G, double *d_g);
-/* Which kernel forms G: 0 = automatic, 1 = FP64 matrix cores
- * (v_mfma_f64_16x16x4_f64), 2 = FP64 vector pipe (register-tiled v_fma_f64).
- * Both give the same G up to summation order; see DESIGN.md for the measured
- * pipe rates that make 2 the default on MI355X. */
+/* Which kernel forms G: 0 = automatic, 1 = FP64 matrix cores with
+ * v_mfma_f64_16x16x4_f64, 2 = FP64 vector pipe (register-tiled v_fma_f64),
+ * 3 = FP64 matrix cores with v_mfma_f64_4x4x4_4b_f64.  All give the same G up to
+ * summation order; DESIGN.md has the measured pipe rates that make 3 the
+ * default on MI355X. */
 int obhip_set_gram_backend(int backend);
 /* bytes of device workspace obhip_newton_solve_dev needs for p terms */
 int obhip_newton_workspace_bytes(uint64_t p, uint64_t *bytes);

@@ -125,6 +125,50 @@ __device__ __forceinline__ double build_dim_any(const DimDesc &D, const double *
   return build_dim<OBHIP_COV_MAT25ANG>(D, ka, kb, kc, rot, xv, store);
 }
 
+// ---- term tables in registers ---------------------------------------------------------
+// A wave works on 64 terms at a time: lane j holds the packed column list of
+// term k0 + j (W2 dwords, two uint16 used-column indices each); inside an
+// unrolled 64-term loop the entries are broadcast with v_readlane.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+
+template <int W2>
+__device__ __forceinline__ void load_cw(uint32_t (&cw)[W2], const uint32_t *__restrict__ colsw,
+                                        int k) {
+#pragma unroll
+  for (int w = 0; w < W2; ++w) cw[w] = colsw[(size_t)k * W2 + w];
+}
+
+// v * product of the staged columns ([column][64 rows] LDS tile) of the term held
+// by lane t, for this lane's row
+template <int W2>
+__device__ __forceinline__ double term_prod_rl(const double *__restrict__ lds,
+                                               const uint32_t (&cw)[W2], int t, int lane, double v) {
+#pragma unroll
+  for (int w = 0; w < W2; ++w) {
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cw[w], t);
+    v *= lds[(c & 0xffffu) * 64 + lane];
+    v *= lds[(c >> 16) * 64 + lane];
+  }
+  return v;
+}
+
+// generic fallback (more than 8 columns per term): column words from memory
+__device__ __forceinline__ double term_prod_mem(const double *__restrict__ lds,
+                                                const uint32_t *__restrict__ cw, int W2, int lane,
+                                                double v) {
+  for (int w = 0; w < W2; ++w) {
+    const uint32_t c = cw[w];
+    v *= lds[(c & 0xffffu) * 64 + lane];
+    v *= lds[(c >> 16) * 64 + lane];
+  }
+  return v;
+}
+
 // ---- LDS tile of basemat ----------------------------------------------------------
 // A staged tile holds Mu "used" columns of one 64-row tile: element (u, r) lives
 // at u * 64 + (r ^ swz(u)).  The XOR swizzle keeps the two access patterns of

@@ -6,7 +6,8 @@
 //
 // Per 64-row tile: 4 waves evaluate the dimensions (wave w takes w, w+4, ...),
 // lane = row, writing only the columns the terms use into the LDS tile; after
-// one barrier the 4 waves split the terms exactly as k_mm does.
+// one barrier the 4 waves split the terms in groups of 64 with register-resident
+// term tables, exactly as k_mm does.
 #include "obhip_internal.h"
 #include "device_common.h"
 
@@ -14,12 +15,12 @@ namespace obhip {
 
 namespace {
 
-template <bool VAR>
+template <int W2, bool VAR>
 __global__ void __launch_bounds__(256)
 k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
           const double *__restrict__ kb, const double *__restrict__ kc,
           const double *__restrict__ rot, const int *__restrict__ cpos, int d, int Mu,
-          const uint32_t *__restrict__ colsw, int W2, int p, const double *__restrict__ theta,
+          const uint32_t *__restrict__ colsw, int W2rt, int p, const double *__restrict__ theta,
           const double *__restrict__ coeffvar, double e2sigma, const double *__restrict__ x,
           uint64_t n, double *__restrict__ mean, double *__restrict__ var) {
   extern __shared__ double lds[];
@@ -44,16 +45,36 @@ k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
   __syncthreads();
 
   double am = 0.0, av = 0.0;
-  for (int k = wave; k < p; k += 4) {
-    const uint32_t *cw = colsw + (size_t)k * W2;
-    double pr = 1.0;
-    for (int w = 0; w < W2; ++w) {
-      const uint32_t c = cw[w];
-      pr *= lds[(c & 0xffffu) * kTileRows + lane];
-      pr *= lds[(c >> 16) * kTileRows + lane];
+  if constexpr (W2 > 0) {
+    const int ngroups = (p + 63) / 64;
+    uint32_t cw[W2];
+    for (int g = wave; g < ngroups; g += 4) {
+      const int k0 = g * 64, cnt = min(64, p - k0);
+      const int kk = min(k0 + lane, p - 1);
+      load_cw(cw, colsw, k0 + lane);
+      const double th = theta[kk];
+      const double cv = VAR ? coeffvar[kk] : 0.0;
+      if (cnt == 64) {
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+          const double pr = term_prod_rl<W2>(lds, cw, t, lane, 1.0);
+          am = fma(readlane_f64(th, t), pr, am);
+          if (VAR) av = fma(readlane_f64(cv, t), pr * pr, av);
+        }
+      } else {
+        for (int t = 0; t < cnt; ++t) {
+          const double pr = term_prod_rl<W2>(lds, cw, t, lane, 1.0);
+          am = fma(readlane_f64(th, t), pr, am);
+          if (VAR) av = fma(readlane_f64(cv, t), pr * pr, av);
+        }
+      }
     }
-    am = fma(theta[k], pr, am);
-    if (VAR) av = fma(coeffvar[k], pr * pr, av);
+  } else {
+    for (int k = wave; k < p; k += 4) {
+      const double pr = term_prod_mem(lds, colsw + (size_t)k * W2rt, W2rt, lane, 1.0);
+      am = fma(theta[k], pr, am);
+      if (VAR) av = fma(coeffvar[k], pr * pr, av);
+    }
   }
   red[wave * kTileRows + lane] = am;
   if (VAR) redv[wave * kTileRows + lane] = av;
@@ -63,6 +84,35 @@ k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
     if (VAR)
       var[row] = ((redv[lane] + redv[64 + lane]) + (redv[128 + lane] + redv[192 + lane])) * (s * s) +
                  e2sigma;  // loglik_gauss.cpp:224-225
+  }
+}
+
+template <int W2, bool VAR>
+int run_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, const double *d_x,
+                uint64_t n, double *d_mean, const double *d_coeffvar, double e2sigma, double *d_var) {
+  const size_t lds = (t.Mu * kTileRows + 8 * kTileRows) * sizeof(double);
+  if (lds > 64 * 1024)
+    OB_HIP(hipFuncSetAttribute((const void *)k_predict<W2, VAR>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_predict<W2, VAR>), dim3((unsigned)((n + kTileRows - 1) / kTileRows)),
+                     dim3(256), lds, cur_stream(), t.pred_md.dims.p, t.pred_md.ka.p, t.pred_md.kb.p,
+                     t.pred_md.kc.p, t.pred_md.rot.p, t.cpos.p, (int)m.d, (int)t.Mu,
+                     (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p, d_theta, d_coeffvar,
+                     e2sigma, d_x, n, d_mean, d_var);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+template <bool VAR>
+int dispatch_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, const double *d_x,
+                     uint64_t n, double *d_mean, const double *d_coeffvar, double e2sigma,
+                     double *d_var) {
+  switch (t.W / 2) {
+    case 1: return run_predict<1, VAR>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
+    case 2: return run_predict<2, VAR>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
+    case 3: return run_predict<3, VAR>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
+    case 4: return run_predict<4, VAR>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
+    default: return run_predict<0, VAR>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
   }
 }
 
@@ -80,28 +130,9 @@ int launch_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, 
     return fail(OBHIP_ERR_INVALID, "terms touch too many basis columns for the LDS tile");
   if (n == 0) return 0;
   ProfScope ps("predict");
-  const size_t lds = (t.Mu * kTileRows + 8 * kTileRows) * sizeof(double);
-  const dim3 grid((unsigned)((n + kTileRows - 1) / kTileRows));
-  const bool do_var = d_coeffvar != nullptr && d_var != nullptr;
-  if (do_var) {
-    if (lds > 64 * 1024)
-      OB_HIP(hipFuncSetAttribute((const void *)k_predict<true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_predict<true>, grid, dim3(256), lds, cur_stream(), t.pred_md.dims.p,
-                       t.pred_md.ka.p, t.pred_md.kb.p, t.pred_md.kc.p, t.pred_md.rot.p, t.cpos.p,
-                       (int)m.d, (int)t.Mu, (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p,
-                       d_theta, d_coeffvar, e2sigma, d_x, n, d_mean, d_var);
-  } else {
-    if (lds > 64 * 1024)
-      OB_HIP(hipFuncSetAttribute((const void *)k_predict<false>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_predict<false>, grid, dim3(256), lds, cur_stream(), t.pred_md.dims.p,
-                       t.pred_md.ka.p, t.pred_md.kb.p, t.pred_md.kc.p, t.pred_md.rot.p, t.cpos.p,
-                       (int)m.d, (int)t.Mu, (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p,
-                       d_theta, d_coeffvar, e2sigma, d_x, n, d_mean, d_var);
-  }
-  OB_HIP(hipGetLastError());
-  return 0;
+  if (d_coeffvar != nullptr && d_var != nullptr)
+    return dispatch_predict<true>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
+  return dispatch_predict<false>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
 }
 
 }  // namespace obhip

@@ -7,12 +7,18 @@
 // All three stage one 64-row tile of the used basemat columns in LDS
 // ([column][row], one 512-byte run per column, straight from the tile-blocked
 // HBM layout) and map lane = row, so every LDS read in the Hadamard product is
-// a conflict-free ds_read_b64 with a wave-uniform column, and the term tables
-// (column lists, coefficients) are wave-uniform scalar loads.
+// a conflict-free ds_read_b64 at a wave-uniform column.
+//
+// Term tables: a wave works on 64 terms at a time.  Lane j holds the packed
+// column list (and for mm the coefficient) of term k0 + j in registers, loaded
+// with one coalesced vector load per group; inside the fully unrolled 64-term
+// loop the entries are broadcast with v_readlane into SGPRs.  No scalar memory
+// load -- and therefore no load latency -- sits in the inner loop.
 //
 // tmm keeps a 64-term x 64-row block of partial sums in registers per wave
-// (acc[t], lane = row mod 64) across all its row tiles and only reduces across
-// lanes once at the end, so the per-element cost equals mm's.
+// (acc[t], lane = row mod 64) across all its row tiles and reduces across lanes
+// once at the end, so its per-element cost equals mm's; the next tile's global
+// loads are in flight while the current tile is consumed.
 #include "obhip_internal.h"
 #include "device_common.h"
 
@@ -21,11 +27,32 @@ namespace obhip {
 namespace {
 
 constexpr int kMaxMuLds = 304;  // 304 * 64 * 8 B = 152 KiB of the 160 KiB LDS
+constexpr int kMaxW2 = 4;       // register-resident column lists: up to 8 columns per term
 
-// product of the staged columns of term k for this lane's row
-__device__ __forceinline__ double term_prod(const double *__restrict__ lds,
-                                            const uint32_t *__restrict__ cw, int W2, int lane,
-                                            double v) {
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+
+// product of the staged columns of the term held by lane t, for this lane's row
+template <int W2>
+__device__ __forceinline__ double term_prod_rl(const double *__restrict__ lds,
+                                               const uint32_t (&cw)[W2], int t, int lane, double v) {
+#pragma unroll
+  for (int w = 0; w < W2; ++w) {
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cw[w], t);
+    v *= lds[(c & 0xffffu) * kTileRows + lane];
+    v *= lds[(c >> 16) * kTileRows + lane];
+  }
+  return v;
+}
+
+// generic fallback (more than 8 columns per term): column words from memory
+__device__ __forceinline__ double term_prod_mem(const double *__restrict__ lds,
+                                                const uint32_t *__restrict__ cw, int W2, int lane,
+                                                double v) {
   for (int w = 0; w < W2; ++w) {
     const uint32_t c = cw[w];
     v *= lds[(c & 0xffffu) * kTileRows + lane];
@@ -34,79 +61,168 @@ __device__ __forceinline__ double term_prod(const double *__restrict__ lds,
   return v;
 }
 
-template <bool SQ>
+template <int W2>
+__device__ __forceinline__ void load_cw(uint32_t (&cw)[W2], const uint32_t *__restrict__ colsw,
+                                        int k) {
+#pragma unroll
+  for (int w = 0; w < W2; ++w) cw[w] = colsw[(size_t)k * W2 + w];
+}
+
+// ---- mm / getmat -----------------------------------------------------------------------
+// MODE 0: out = B a;  MODE 1: out = B^2 a;  MODE 2: materialise B (a unused)
+template <int W2, int MODE>
 __global__ void __launch_bounds__(256)
 k_mm(const double *__restrict__ bm, const double *__restrict__ scale,
      const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc, const uint32_t *__restrict__ colsw,
-     int W2, int p, const double *__restrict__ a, double *__restrict__ out, uint64_t n) {
+     int W2rt, int p, const double *__restrict__ a, double *__restrict__ out, uint64_t n) {
   extern __shared__ double lds[];
   double *red = lds + (size_t)Mu * kTileRows;  // [4][64]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint64_t tile = blockIdx.x;
-  stage_tile<SQ, false>(lds, bm + tile * Mc * kTileRows, ucol, Mu, threadIdx.x, 256);
+  const uint64_t row = tile * kTileRows + lane;
+  if (MODE == 1)
+    stage_tile<true, false>(lds, bm + tile * Mc * kTileRows, ucol, Mu, threadIdx.x, 256);
+  else
+    stage_tile<false, false>(lds, bm + tile * Mc * kTileRows, ucol, Mu, threadIdx.x, 256);
   __syncthreads();
+  const double s = row < n ? scale[row] : 0.0;
   double acc = 0.0;
-  for (int k = wave; k < p; k += 4) acc += term_prod(lds, colsw + (size_t)k * W2, W2, lane, a[k]);
-  red[wave * kTileRows + lane] = acc;
-  __syncthreads();
-  if (wave == 0) {
-    const uint64_t row = tile * kTileRows + lane;
-    if (row < n) {
-      const double s = scale[row];
-      out[row] = ((red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane])) * (SQ ? s * s : s);
+  const int ngroups = (p + 63) / 64;
+  if constexpr (W2 > 0) {
+    uint32_t cw[W2], cwn[W2];
+    double av = 0.0, avn = 0.0;
+    int g = wave;
+    if (g < ngroups) {
+      const int k = min(g * 64 + lane, p - 1);  // the table is padded, a[] is not
+      load_cw(cw, colsw, g * 64 + lane);
+      if (MODE != 2) av = a[k];
+    }
+    for (; g < ngroups; g += 4) {
+      const int gn = g + 4;
+      if (gn < ngroups) {  // next group's table while this one is consumed
+        load_cw(cwn, colsw, gn * 64 + lane);
+        if (MODE != 2) avn = a[min(gn * 64 + lane, p - 1)];
+      }
+      const int k0 = g * 64;
+      const int cnt = min(64, p - k0);
+      if (cnt == 64) {
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+          if (MODE == 2) {
+            const double v = term_prod_rl<W2>(lds, cw, t, lane, s);
+            if (row < n) out[(uint64_t)(k0 + t) * n + row] = v;
+          } else {
+            acc += term_prod_rl<W2>(lds, cw, t, lane, readlane_f64(av, t));
+          }
+        }
+      } else {
+        for (int t = 0; t < cnt; ++t) {
+          if (MODE == 2) {
+            const double v = term_prod_rl<W2>(lds, cw, t, lane, s);
+            if (row < n) out[(uint64_t)(k0 + t) * n + row] = v;
+          } else {
+            acc += term_prod_rl<W2>(lds, cw, t, lane, readlane_f64(av, t));
+          }
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < W2; ++w) cw[w] = cwn[w];
+      av = avn;
+    }
+  } else {
+    for (int k = wave; k < p; k += 4) {
+      if (MODE == 2) {
+        const double v = term_prod_mem(lds, colsw + (size_t)k * W2rt, W2rt, lane, s);
+        if (row < n) out[(uint64_t)k * n + row] = v;
+      } else {
+        acc += term_prod_mem(lds, colsw + (size_t)k * W2rt, W2rt, lane, a[k]);
+      }
     }
   }
-}
-
-__global__ void __launch_bounds__(256)
-k_getmat(const double *__restrict__ bm, const double *__restrict__ scale,
-         const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc, const uint32_t *__restrict__ colsw,
-         int W2, int p, double *__restrict__ out, uint64_t n) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint64_t tile = blockIdx.x;
-  stage_tile<false, false>(lds, bm + tile * Mc * kTileRows, ucol, Mu, threadIdx.x, 256);
+  if (MODE == 2) return;
+  red[wave * kTileRows + lane] = acc;
   __syncthreads();
-  const uint64_t row = tile * kTileRows + lane;
-  const double s = row < n ? scale[row] : 0.0;
-  for (int k = wave; k < p; k += 4) {
-    const double v = term_prod(lds, colsw + (size_t)k * W2, W2, lane, s);
-    if (row < n) out[(uint64_t)k * n + row] = v;
-  }
+  if (wave == 0 && row < n)
+    out[row] = ((red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane])) *
+               (MODE == 1 ? s * s : s);
 }
 
+// ---- tmm -----------------------------------------------------------------------------------
 // grid = (row splits, p_pad / 256); wave w of a block owns terms
-// blockIdx.y*256 + w*64 ... +63.
-template <bool SQ>
+// blockIdx.y*256 + w*64 ... +63.  kPre registers per thread hold the next tile.
+constexpr int kTmmPre = 32;  // doubles per thread => Mu <= 128 with prefetch
+
+template <int W2, bool SQ, bool PREFETCH>
 __global__ void __launch_bounds__(256)
 k_tmm(const double *__restrict__ bm, const double *__restrict__ scale,
       const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc, const uint32_t *__restrict__ colsw,
-      int W2, const double *__restrict__ a, uint64_t n, uint64_t ntiles, uint64_t tiles_per_split,
-      uint64_t p_pad, double *__restrict__ part) {
+      int W2rt, const double *__restrict__ a, uint64_t n, uint64_t ntiles,
+      uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ part) {
   extern __shared__ double lds[];
+  int *lu = (int *)(lds + (size_t)Mu * kTileRows);  // [Mu] ucol[u] * 64
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int k0 = blockIdx.y * 256 + wave * 64;
   const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
   const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+  for (int u = threadIdx.x; u < Mu; u += 256) lu[u] = (int)ucol[u] * kTileRows;
+  __syncthreads();
+
+  uint32_t cw[W2 > 0 ? W2 : 1];
+  if constexpr (W2 > 0) load_cw(cw, colsw, k0 + lane);
   double acc[64];
 #pragma unroll
   for (int t = 0; t < 64; ++t) acc[t] = 0.0;
-  for (uint64_t tile = t0; tile < t1; ++tile) {
-    __syncthreads();
-    stage_tile<SQ, false>(lds, bm + tile * Mc * kTileRows, ucol, Mu, threadIdx.x, 256);
-    __syncthreads();
+
+  // element (u, r) of a tile: thread t moves row r = t & 63 of columns u = (t >> 6) + 4 q
+  double pre[PREFETCH ? kTmmPre : 1];
+  double prevs = 0.0;
+  auto fetch = [&](uint64_t tile) {
+    const double *src = bm + tile * Mc * kTileRows + lane;
+#pragma unroll
+    for (int q = 0; q < kTmmPre; ++q) {
+      const int u = wave + 4 * q;
+      pre[q] = u < Mu ? src[lu[u]] : 0.0;
+    }
     const uint64_t row = tile * kTileRows + lane;
-    double vs = 0.0;
+    prevs = 0.0;
     if (row < n) {
       const double s = scale[row];
-      vs = a[row] * (SQ ? s * s : s);  // b = basescale % a, linalg.cpp:305
+      prevs = a[row] * (SQ ? s * s : s);  // b = basescale % a, linalg.cpp:305
     }
+  };
+  if (PREFETCH && t0 < t1) fetch(t0);
+
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    __syncthreads();  // every wave is done with the previous tile
+    double vs;
+    if (PREFETCH) {
 #pragma unroll
-    for (int t = 0; t < 64; ++t)
-      acc[t] += term_prod(lds, colsw + (size_t)(k0 + t) * W2, W2, lane, vs);
+      for (int q = 0; q < kTmmPre; ++q) {
+        const int u = wave + 4 * q;
+        if (u < Mu) lds[u * kTileRows + lane] = SQ ? pre[q] * pre[q] : pre[q];
+      }
+      vs = prevs;
+    } else {
+      stage_tile<SQ, false>(lds, bm + tile * Mc * kTileRows, ucol, Mu, threadIdx.x, 256);
+      const uint64_t row = tile * kTileRows + lane;
+      vs = 0.0;
+      if (row < n) {
+        const double s = scale[row];
+        vs = a[row] * (SQ ? s * s : s);
+      }
+    }
+    __syncthreads();
+    if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
+    if constexpr (W2 > 0) {
+#pragma unroll
+      for (int t = 0; t < 64; ++t) acc[t] += term_prod_rl<W2>(lds, cw, t, lane, vs);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 64; ++t)
+        acc[t] += term_prod_mem(lds, colsw + (size_t)(k0 + t) * W2rt, W2rt, lane, vs);
+    }
   }
   // cross-lane reduction, lane t keeps the total of term k0 + t
   double mine = 0.0;
@@ -145,46 +261,76 @@ int check_mu(const obhip_terms &t) {
   return 0;
 }
 
+template <int W2, int MODE>
+int run_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out) {
+  const size_t lds = (t.Mu * kTileRows + 4 * kTileRows) * sizeof(double);
+  OB_TRY(set_lds(k_mm<W2, MODE>, lds));
+  hipLaunchKernelGGL((k_mm<W2, MODE>), dim3((unsigned)(b.n_pad / kTileRows)), dim3(256), lds,
+                     cur_stream(), b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc,
+                     (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p, d_a, d_out, b.n);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int MODE>
+int dispatch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out) {
+  switch (t.W / 2) {
+    case 1: return run_mm<1, MODE>(b, t, d_a, d_out);
+    case 2: return run_mm<2, MODE>(b, t, d_a, d_out);
+    case 3: return run_mm<3, MODE>(b, t, d_a, d_out);
+    case 4: return run_mm<4, MODE>(b, t, d_a, d_out);
+    default: return run_mm<0, MODE>(b, t, d_a, d_out);
+  }
+}
+
+template <int W2, bool SQ, bool PF>
+int run_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *part, dim3 grid,
+            uint64_t ntiles, uint64_t tps) {
+  const size_t lds = t.Mu * kTileRows * sizeof(double) + t.Mu * sizeof(int);
+  OB_TRY(set_lds(k_tmm<W2, SQ, PF>, lds));
+  hipLaunchKernelGGL((k_tmm<W2, SQ, PF>), grid, dim3(256), lds, cur_stream(), b.bm.p, b.scale.p,
+                     t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, (int)(t.W / 2), d_a,
+                     b.n, ntiles, tps, t.p_pad, part);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+template <bool SQ>
+int dispatch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *part, dim3 grid,
+                 uint64_t ntiles, uint64_t tps) {
+  const bool pf = t.Mu <= 4 * (uint64_t)kTmmPre;
+  switch (t.W / 2) {
+    case 1: return pf ? run_tmm<1, SQ, true>(b, t, d_a, part, grid, ntiles, tps)
+                      : run_tmm<1, SQ, false>(b, t, d_a, part, grid, ntiles, tps);
+    case 2: return pf ? run_tmm<2, SQ, true>(b, t, d_a, part, grid, ntiles, tps)
+                      : run_tmm<2, SQ, false>(b, t, d_a, part, grid, ntiles, tps);
+    case 3: return pf ? run_tmm<3, SQ, true>(b, t, d_a, part, grid, ntiles, tps)
+                      : run_tmm<3, SQ, false>(b, t, d_a, part, grid, ntiles, tps);
+    case 4: return pf ? run_tmm<4, SQ, true>(b, t, d_a, part, grid, ntiles, tps)
+                      : run_tmm<4, SQ, false>(b, t, d_a, part, grid, ntiles, tps);
+    default: return run_tmm<0, SQ, false>(b, t, d_a, part, grid, ntiles, tps);
+  }
+}
+
 }  // namespace
 
 int launch_getmat(const obhip_basis &b, obhip_terms &t, double *d_out) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   OB_TRY(check_mu(t));
   ProfScope ps("getmat");
-  const size_t lds = t.Mu * kTileRows * sizeof(double);
-  OB_TRY(set_lds(k_getmat, lds));
-  hipLaunchKernelGGL(k_getmat, dim3((unsigned)(b.n_pad / kTileRows)), dim3(256), lds, cur_stream(),
-                     b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,
-                     (int)(t.W / 2), (int)t.p, d_out, b.n);
-  OB_HIP(hipGetLastError());
-  return 0;
+  return dispatch_mm<2>(b, t, nullptr, d_out);
 }
 
 int launch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, bool squared) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   OB_TRY(check_mu(t));
   ProfScope ps(squared ? "sqmm" : "mm");
-  const size_t lds = (t.Mu * kTileRows + 4 * kTileRows) * sizeof(double);
-  const dim3 grid((unsigned)(b.n_pad / kTileRows));
-  if (squared) {
-    OB_TRY(set_lds(k_mm<true>, lds));
-    hipLaunchKernelGGL(k_mm<true>, grid, dim3(256), lds, cur_stream(), b.bm.p, b.scale.p, t.ucol.p,
-                       (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p,
-                       d_a, d_out, b.n);
-  } else {
-    OB_TRY(set_lds(k_mm<false>, lds));
-    hipLaunchKernelGGL(k_mm<false>, grid, dim3(256), lds, cur_stream(), b.bm.p, b.scale.p, t.ucol.p,
-                       (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p,
-                       d_a, d_out, b.n);
-  }
-  OB_HIP(hipGetLastError());
-  return 0;
+  return squared ? dispatch_mm<1>(b, t, d_a, d_out) : dispatch_mm<0>(b, t, d_a, d_out);
 }
 
 int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, bool squared) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   OB_TRY(check_mu(t));
-  ProfScope ps(squared ? "sqtmm" : "tmm");
   const uint64_t ntiles = b.n_pad / kTileRows;
   const uint64_t pblocks = (t.p + 255) / 256;
   // enough blocks to fill 256 CUs a few times over, each with >= 4 tiles
@@ -195,20 +341,14 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *
   const uint64_t p_pad = t.p_pad;  // multiple of 256 (obhip_terms::prepare)
   double *part = nullptr;
   OB_TRY(const_cast<obhip_basis &>(b).workspace(nsplit * p_pad * sizeof(double), (void **)&part));
-  const size_t lds = t.Mu * kTileRows * sizeof(double);
   const dim3 grid((unsigned)nsplit, (unsigned)pblocks);
-  if (squared) {
-    OB_TRY(set_lds(k_tmm<true>, lds));
-    hipLaunchKernelGGL(k_tmm<true>, grid, dim3(256), lds, cur_stream(), b.bm.p, b.scale.p, t.ucol.p,
-                       (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, (int)(t.W / 2), d_a, b.n,
-                       ntiles, tps, p_pad, part);
-  } else {
-    OB_TRY(set_lds(k_tmm<false>, lds));
-    hipLaunchKernelGGL(k_tmm<false>, grid, dim3(256), lds, cur_stream(), b.bm.p, b.scale.p, t.ucol.p,
-                       (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, (int)(t.W / 2), d_a, b.n,
-                       ntiles, tps, p_pad, part);
+  {
+    ProfScope ps(squared ? "sqtmm" : "tmm");
+    if (squared)
+      OB_TRY(dispatch_tmm<true>(b, t, d_a, part, grid, ntiles, tps));
+    else
+      OB_TRY(dispatch_tmm<false>(b, t, d_a, part, grid, ntiles, tps));
   }
-  OB_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 255) / 256)), dim3(256), 0, cur_stream(),
                      part, (int)nsplit, p_pad, (int)t.p, d_out);
   OB_HIP(hipGetLastError());

@@ -103,7 +103,7 @@ class outermod:
         self.d = 0
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.lib.obhip_model_destroy(self._h)
             self._h = None
 
@@ -242,7 +242,7 @@ class _Terms:
         return dict(p=p.value, d=d.value, nnz_total=nnz.value, max_nnz=mx.value)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.lib.obhip_terms_destroy(self._h)
             self._h = None
 
@@ -273,7 +273,7 @@ class outerbase:
         self.vertpl = False
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.lib.obhip_basis_destroy(self._h)
             self._h = None
 

@@ -31,16 +31,16 @@ def test_device_reproduces_golden(path):
     b = ob.outerbase(om, g["x"])
     for k in range(1, len(kinds) + 1):
         want = g["basemat"][:, st[k - 1]:st[k - 1] + 6] * g["basescalemat"][:, k - 1:k]
-        assert relerr(b.getbase(k)[:, :6], want) < 1e-12
-    assert relerr(b.getmat(terms), g["B"]) < 1e-12
-    assert relerr(b.matmul(terms, g["a"]), g["Ba"]) < 1e-12
-    assert relerr(b.tmatmul(terms, g["v"]), g["Btv"]) < 1e-12
-    assert relerr(b.sqmm(terms, np.abs(g["a"])), g["sqBa"]) < 1e-12
-    assert relerr(b.sqcolsums(terms), g["sqcolsums"]) < 1e-12
+        assert relerr(b.getbase(k)[:, :6], want) < 2e-9
+    assert relerr(b.getmat(terms), g["B"]) < 2e-9
+    assert relerr(b.matmul(terms, g["a"]), g["Ba"]) < 2e-9
+    assert relerr(b.tmatmul(terms, g["v"]), g["Btv"]) < 2e-9
+    assert relerr(b.sqmm(terms, np.abs(g["a"])), g["sqBa"]) < 2e-9
+    assert relerr(b.sqcolsums(terms), g["sqcolsums"]) < 2e-9
     lik = ob.loglik_std(om, terms, g["y"], g["x"])
     assert abs(lik.para[0] - float(g["sigma"])) < 1e-13
     lp = ob.lpdfvec(lik, ob.logpr_gauss(om, terms))
-    assert relerr(lp.hess(), g["H"]) < 1e-12
+    assert relerr(lp.hess(), g["H"]) < 2e-9
     lp.optnewton()
     pred = ob.predictor(lp)
     pred.update(g["xnew"])
@@ -50,5 +50,5 @@ def test_device_reproduces_golden(path):
     lpg = ob.lpdfvec(ob.logpr_gauss(om, terms), likg)
     lpg.optcg(1e-12, 25)
     assert lpg.cgiters == int(g["cg_iters"])
-    assert relerr(lpg.totdiaghess, g["diagH"]) < 1e-12
+    assert relerr(lpg.totdiaghess, g["diagH"]) < 2e-9
     assert relerr(likg.yhat, g["B"] @ g["theta_cg"]) < 1e-6

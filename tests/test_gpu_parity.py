@@ -171,14 +171,15 @@ def test_ragged_sizes(n, p):
 
 @pytest.fixture
 def gram_backend(request):
-    """1 = FP64 matrix-core kernel, 2 = FP64 vector-pipe kernel, 0 = automatic."""
+    """1 = 16x16x4 matrix-core kernel, 2 = vector-pipe kernel, 3 = 4x4x4 matrix-core
+    kernel, 0 = automatic."""
     from outerbase_amd import _lib
     _lib.call("obhip_set_gram_backend", request.param)
     yield request.param
     _lib.call("obhip_set_gram_backend", 0)
 
 
-@pytest.mark.parametrize("gram_backend", [1, 2], indirect=True)
+@pytest.mark.parametrize("gram_backend", [1, 2, 3], indirect=True)
 @pytest.mark.parametrize("n,p", [(2, 1), (65, 127), (200, 128), (1000, 129), (5000, 700)])
 def test_gram_backends(gram_backend, n, p):
     """both Gram kernels on single/multi tile pairs, ragged edges and multiple
@@ -200,7 +201,7 @@ def test_gram_backends(gram_backend, n, p):
     assert np.array_equal(G, G.T)
 
 
-@pytest.mark.parametrize("gram_backend", [1, 2], indirect=True)
+@pytest.mark.parametrize("gram_backend", [1, 2, 3], indirect=True)
 @pytest.mark.parametrize("max_nnz", [1, 2, 3, 5, 6, 8])
 def test_gram_term_widths(gram_backend, max_nnz):
     """terms with 1..8 non-zero levels (MFMA kernel template widths W = 2, 4, 6,
@@ -241,7 +242,7 @@ def test_gram_wide_terms():
     lik = ob.loglik_std(om_d, terms, rng.standard_normal(100), x)
     B = O.ob_getmat(O.OuterBase(om_o, x), terms)
     try:
-        for backend in (0, 1, 2):
+        for backend in (0, 1, 2, 3):
             _lib.call("obhip_set_gram_backend", backend)
             with pytest.raises(ob.ObhipError):
                 lik.hess()

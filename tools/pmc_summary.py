@@ -1,0 +1,14 @@
+"""Sums rocprofv3 --pmc counter_collection.csv per kernel (tuning aid)."""
+import collections, csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+pat = sys.argv[2] if len(sys.argv) > 2 else "gram"
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+n = collections.Counter()
+for r in rows:
+    if pat in r["Kernel_Name"]:
+        k = r["Kernel_Name"].split("(")[0][-40:]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+for k, v in agg.items():
+    print(k)
+    for a, b in sorted(v.items()):
+        print("   %-28s %.4g" % (a, b))
