@@ -15,13 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ob_oracle as O  # noqa: E402
 
+LEAD = 8   # leading levels of each dimension's basemat block kept in the fixture
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
 CASES = {
     # name: (kinds, knots per dim, n, p, hyp shift, seed)
     "ref_basic_d8": (["mat25pow"] + ["mat25"] * 7, None, 15, 20, 0.0, 42),   # test-obombasic.R
-    "mixed_d3": (["mat25", "mat25pow", "mat25ang"], 24, 64, 40, 0.15, 7),
-    "mat25_d8": (["mat25"] * 8, 40, 50, 36, -0.2, 11),
+    "mixed_d3": (["mat25", "mat25pow", "mat25ang"], 24, 300, 40, 0.15, 7),
+    "mat25_d8": (["mat25"] * 8, 40, 300, 36, -0.2, 11),
 }
 
 
@@ -62,7 +63,8 @@ def make(name):
         kinds=np.array(kinds), knotpt=om.knotpt, knotptst=om.knotptst, hyp=om.hyp,
         rotmat=om.rotmat, basisvar=om.basisvar, maxlevel=om.maxlevel,
         x=x, terms=terms, termvar=om.getvar(terms),
-        basemat=ob.basemat, basescale=ob.basescale, basescalemat=ob.basescalemat,
+        basemat_lead=np.stack([ob.basemat[:, om.knotptst[l]:om.knotptst[l] + LEAD] for l in range(d)], axis=1),
+        basescale=ob.basescale, basescalemat=ob.basescalemat,
         B=B, a=a, Ba=O.ob_mm(ob, terms, a), v=v, Btv=O.ob_tmm(ob, terms, v),
         sqBa=O.ob_sqmm(ob, terms, np.abs(a)), sqcolsums=O.ob_sqcolsums(ob, terms),
         G=G, g=g, y=y, sigma=sigma, rho=O.DEFAULT_RHO, H=H, theta=theta,

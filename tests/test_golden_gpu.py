@@ -30,7 +30,7 @@ def test_device_reproduces_golden(path):
     assert relerr(om.getvar(terms), g["termvar"]) < 1e-14
     b = ob.outerbase(om, g["x"])
     for k in range(1, len(kinds) + 1):
-        want = g["basemat"][:, st[k - 1]:st[k - 1] + 6] * g["basescalemat"][:, k - 1:k]
+        want = g["basemat_lead"][:, k - 1, :6] * g["basescalemat"][:, k - 1:k]
         assert relerr(b.getbase(k)[:, :6], want) < 2e-9
     assert relerr(b.getmat(terms), g["B"]) < 2e-9
     assert relerr(b.matmul(terms, g["a"]), g["Ba"]) < 2e-9
