@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000, help="rows per GPU")
+    ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="rows per GPU")
     ap.add_argument("--d", type=int, default=20)
     ap.add_argument("--p", type=int, default=4096)
     ap.add_argument("--knots", type=int, default=40)
@@ -157,10 +157,18 @@ def main():
             sys.exit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (libobhip has no CPU fallback)")
-    torch.cuda.set_device(local)
+    # one rank per GPU; OBHIP_DIST_BACKEND=gloo lets several ranks rehearse the N > 1 path
+    # on a single GPU (gloo stages CUDA tensors through the host)
+    backend = os.environ.get("OBHIP_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev = local if backend == "nccl" else local % max(1, ndev)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     import outerbase_amd as ob
     from outerbase_amd import _lib
