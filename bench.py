@@ -255,9 +255,19 @@ def main():
     if "gram" in prof and args.backend == "newton":
         flops = float(n) * p * (p + 1)  # p(p+1) flop per point
         ach = flops / (prof["gram"]["avg_ms"] * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "k_gram", "achieved": ach,
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE,
+        # WRITE_SIZE) on this exact workload; see the file for the command and caveats
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_gram_traffic.json")
+        if os.path.exists(tf) and args.gram_backend in (0, 3):
+            tj = json.load(open(tf))
+            c = tj["config"]
+            if (c["d"], c["rows"], c["p"], c["knots"]) == (args.d, n, p, args.knots):
+                traffic = tj["traffic_bytes_per_launch"]
+        out["roofline"] = {"bound": "mfma", "kernel": "k_gram_mfma4", "achieved": ach,
                            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                           "traffic_unit": "bytes per launch (PMC, separate pass)",
                            "avg_launch_ms": prof["gram"]["avg_ms"]}
     elif "mm" in prof:
         byts = float(n) * 8 * (hp.ncols + 1)

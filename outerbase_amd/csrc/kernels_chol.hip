@@ -43,10 +43,21 @@ k_chol_panel(double *__restrict__ H, double *__restrict__ z, int p, int j0, int 
   const int jb = min(NB, p - j0);
 
   // diagonal block -> LDS (identity padding beyond jb)
-  for (int r = 0; r < NB; ++r) {
-    double v = (r == lane) ? 1.0 : 0.0;
-    if (r < jb && lane < jb) v = H[(size_t)(j0 + r) * p + j0 + lane];
-    Ld[r * LDP + lane] = v;
+  // (branch-free clamped addresses, 16 row loads in flight per batch: a load /
+  // wait / store per row would cost one L2 round trip per row)
+  {
+    const double *src = H + (size_t)j0 * p + j0 + min(lane, jb - 1);
+#pragma unroll
+    for (int rb = 0; rb < NB; rb += 16) {
+      double t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = src[(size_t)min(rb + i, jb - 1) * p];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = rb + i;
+        Ld[r * LDP + lane] = (r < jb && lane < jb) ? t[i] : ((r == lane) ? 1.0 : 0.0);
+      }
+    }
   }
   __syncthreads();
   double a[NB];
@@ -84,10 +95,21 @@ k_chol_panel(double *__restrict__ H, double *__restrict__ z, int p, int j0, int 
   const bool is_z = blockIdx.x == gridDim.x - 1;
   const int r0 = j0 + NB * (int)blockIdx.x;
   const int nrows = is_z ? 1 : min(NB, p - r0);
-  for (int r = 0; r < NB; ++r) {
-    double v = 0.0;
-    if (r < nrows && lane < jb) v = is_z ? z[j0 + lane] : H[(size_t)(r0 + r) * p + j0 + lane];
-    P[r * LDP + lane] = v;
+  {
+    const int lc = min(lane, jb - 1);
+    const double *src = is_z ? z + j0 + lc : H + (size_t)min(r0, p - 1) * p + j0 + lc;
+    const int rmax = is_z ? 0 : min(NB, p - r0) - 1;  // clamp row offsets into the matrix
+#pragma unroll
+    for (int rb = 0; rb < NB; rb += 16) {
+      double t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = src[(size_t)min(rb + i, max(rmax, 0)) * p];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = rb + i;
+        P[r * LDP + lane] = (r < nrows && lane < jb) ? t[i] : 0.0;
+      }
+    }
   }
   __syncthreads();
   double x[NB];
@@ -183,11 +205,19 @@ k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__rest
   __shared__ double Ld[NB * LDP];
   __shared__ double th[NB];
   const int jb = min(NB, p - j0);
-  for (int e = threadIdx.x; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    double v = (r == c) ? 1.0 : 0.0;
-    if (r < jb && c < jb && c <= r) v = L[(size_t)(j0 + r) * p + j0 + c];
-    Ld[r * LDP + c] = v;
+  {
+    double t[NB * NB / 256];
+#pragma unroll
+    for (int i = 0; i < NB * NB / 256; ++i) {
+      const int e = threadIdx.x + i * 256;
+      t[i] = L[(size_t)(j0 + min(e / NB, jb - 1)) * p + j0 + min(e % NB, jb - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < NB * NB / 256; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / NB, c = e % NB;
+      Ld[r * LDP + c] = (r < jb && c < jb && c <= r) ? t[i] : ((r == c) ? 1.0 : 0.0);
+    }
   }
   __syncthreads();
   if (threadIdx.x < 64) {
