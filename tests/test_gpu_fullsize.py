@@ -1,0 +1,112 @@
+"""BASELINE.json configs[2] at FULL size (d=20, n=1e6, p=4096) through
+size-independent properties: the oracle cannot produce a reference at this size
+in seconds, but the kernels must agree with EACH OTHER (the Gram / Cholesky
+kernels vs the matrix-free kernels vs the fused predictor)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hot():
+    import torch
+    from outerbase_amd.driver import HotPath
+    hp = HotPath(["mat25"] * 20, 40, 4096, 1_000_000)
+    hp.setup()
+    hp.step()
+    torch.cuda.synchronize()
+    yield hp
+    hp.close()
+
+
+def _vec(torch, n):
+    return torch.empty(n, dtype=torch.float64, device="cuda")
+
+
+def test_standardised_targets(hot):
+    y = hot.y.cpu().numpy()
+    assert abs(y.mean()) < 1e-12
+    assert abs(y.var(ddof=1) - 1.0) < 1e-12
+
+
+def test_gram_is_consistent_with_matrix_free_kernels(hot):
+    import torch
+    from outerbase_amd._lib import call
+    p, n = hot.p, hot.n
+    G = torch.empty((p, p), dtype=torch.float64, device="cuda")
+    g = _vec(torch, p)
+    call("obhip_gram_dev", hot.basis, hot.t._h, hot.y.data_ptr(), G.data_ptr(), g.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(G, G.T)
+    # diag(B^T B) == column sums of B^2 (modandbase.cpp:863-867)
+    ones = torch.ones(n, dtype=torch.float64, device="cuda")
+    sq = _vec(torch, p)
+    call("obhip_basis_tmm_dev", hot.basis, hot.t._h, ones.data_ptr(), sq.data_ptr(), 1)
+    torch.cuda.synchronize()
+    assert float(((torch.diagonal(G) - sq).abs() / sq).max()) < 1e-11
+    # G a == B^T (B a)
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy(rng.standard_normal(p)).cuda()
+    Ba, BtBa = _vec(torch, n), _vec(torch, p)
+    call("obhip_basis_mm_dev", hot.basis, hot.t._h, a.data_ptr(), Ba.data_ptr(), 0)
+    call("obhip_basis_tmm_dev", hot.basis, hot.t._h, Ba.data_ptr(), BtBa.data_ptr(), 0)
+    torch.cuda.synchronize()
+    Ga = G @ a
+    assert float((Ga - BtBa).abs().max() / Ga.abs().max()) < 1e-11
+    # g == B^T y through an independent launch
+    g2 = _vec(torch, p)
+    call("obhip_basis_tmm_dev", hot.basis, hot.t._h, hot.y.data_ptr(), g2.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(g, g2)
+
+
+def test_mm_is_linear(hot):
+    import torch
+    from outerbase_amd._lib import call
+    rng = np.random.default_rng(1)
+    a = torch.from_numpy(rng.standard_normal(hot.p)).cuda()
+    b = torch.from_numpy(rng.standard_normal(hot.p)).cuda()
+    outs = []
+    for v in (a, b, 2.0 * a - 3.0 * b):
+        o = _vec(torch, hot.n)
+        call("obhip_basis_mm_dev", hot.basis, hot.t._h, v.data_ptr(), o.data_ptr(), 0)
+        outs.append(o)
+    torch.cuda.synchronize()
+    err = (outs[2] - (2.0 * outs[0] - 3.0 * outs[1])).abs().max() / outs[2].abs().max()
+    assert float(err) < 1e-12
+
+
+def test_newton_solution_is_stationary(hot):
+    """H theta = e^{-2 sigma} B^T y with H applied matrix-free: checks the Gram,
+    Cholesky and triangular-solve kernels at p = 4096 against mm / tmm."""
+    import torch
+    from outerbase_amd._lib import call
+    e2 = math.exp(-2 * hot.sigma)
+    tmp, hv = _vec(torch, hot.n), _vec(torch, hot.p)
+    call("obhip_basis_mm_dev", hot.basis, hot.t._h, hot.theta.data_ptr(), tmp.data_ptr(), 0)
+    call("obhip_basis_tmm_dev", hot.basis, hot.t._h, tmp.data_ptr(), hv.data_ptr(), 0)
+    torch.cuda.synchronize()
+    prec = torch.from_numpy(1.0 / (hot.om.getvar(hot.terms) * math.exp(2 * hot.rho))).cuda()
+    lhs = e2 * hv + prec * hot.theta
+    rhs = e2 * hot.g
+    assert float((lhs - rhs).norm() / rhs.norm()) < 1e-10
+
+
+def test_fused_predictor_equals_stored_basis_path(hot):
+    """predict at the TRAINING rows through k_predict (basis rebuilt in LDS) must
+    equal k_mm on the stored basemat."""
+    import torch
+    from outerbase_amd._lib import call
+    via_mm, via_pred = _vec(torch, hot.n), _vec(torch, hot.n)
+    call("obhip_basis_mm_dev", hot.basis, hot.t._h, hot.theta.data_ptr(), via_mm.data_ptr(), 0)
+    call("obhip_predict_dev", hot.om._h, hot.t._h, hot.theta.data_ptr(), hot.x.data_ptr(), hot.n,
+         via_pred.data_ptr(), None, hot.sigma, None)
+    torch.cuda.synchronize()
+    assert float((via_mm - via_pred).abs().max() / via_mm.abs().max()) < 1e-12
+    # and the fit explains the data: residual variance well below the prior noise guess
+    resid = via_mm - hot.y
+    assert float(resid.var()) < 0.5
