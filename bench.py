@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--backend", choices=["newton", "cg"], default="newton")
     ap.add_argument("--kinds", default="mat25", help="comma list cycled over dimensions")
     ap.add_argument("--gram-backend", type=int, default=0,
-                    help="0 auto, 1 MFMA 16x16x4, 2 vector pipe, 3 MFMA 4x4x4")
+                    help="0 auto, 1 MFMA 16x16x4, 2 vector pipe, 3 fused MFMA 4x4x4, 4 materialised-B MFMA 4x4x4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-backend", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=200000)
     return ap.parse_args()
 
@@ -160,6 +161,10 @@ def cpu_baseline(hp, ns, threads=16):
                          t["predict"], hp.n)}
 
 
+def n_rows_all(hp):
+    return hp.n * hp.world
+
+
 def main():
     args = parse()
     import numpy as np
@@ -236,6 +241,28 @@ def main():
     # parity of this very run against the oracle on a row sample (cheap, untimed)
     check = check_against_oracle(hp) if rank == 0 else None
 
+    # the other back end on the same inputs, for the record (untimed region; every rank
+    # takes part because the fit all-reduces): B = matrix-free PCG, what obfit() runs
+    alt = None
+    if args.backend == "newton" and not args.no_alt_backend:
+        import numpy as np
+        theta_newton = hp.theta.clone()
+        mean_newton = hp.mean.clone()
+        hp.backend = "cg"
+        hp.step()
+        sync()
+        t0 = time.perf_counter()
+        hp.step()
+        sync()
+        dt = time.perf_counter() - t0
+        rel = float((hp.mean - mean_newton).abs().max() / mean_newton.abs().max())
+        alt = {"backend": "cg (lpdf::optcg, tol 1e-10, cap .getsteps)", "ms_per_step": dt * 1e3,
+               "points_per_s": float(n_rows_all(hp)) / dt, "cg_iterations": hp.cg_iters,
+               "max_rel_diff_of_predictions_vs_newton": rel}
+        hp.backend = "newton"
+        hp.theta.copy_(theta_newton)
+        hp.mean.copy_(mean_newton)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -268,6 +295,7 @@ def main():
         },
         "kernels_ms": prof,
         "parity_check": check,
+        "alt_backend": alt,
     }
     if "gram" in prof and args.backend == "newton":
         flops = float(n) * p * (p + 1)  # p(p+1) flop per point

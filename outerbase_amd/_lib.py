@@ -36,7 +36,7 @@ def _ctype(decl):
     stars = decl.count("*")
     base = decl.replace("*", " ").split()[0]
     if base == "obhip_allreduce_fn":
-        return ALLREDUCE_FN
+        return C.c_void_p  # pass ctypes.cast(ALLREDUCE_FN(f), c_void_p) or None
     if base in _HANDLES:
         return C.c_void_p if stars == 1 else C.POINTER(C.c_void_p)
     if base == "char" and stars == 1:

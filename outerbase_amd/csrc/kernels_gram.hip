@@ -192,15 +192,21 @@ bool gram_valu_supports(const obhip_terms &t);
 int launch_gram_mfma4(const obhip_basis &b, obhip_terms &t, double *d_G);
 bool gram_mfma4_supports(const obhip_terms &t);
 
-// 0 = automatic (4x4x4 matrix-core kernel when the terms fit it, else 16x16x4),
+int launch_gram_panel(const obhip_basis &b, obhip_terms &t, double *d_G);
+bool gram_panel_supports(const obhip_basis &b, const obhip_terms &t);
+
+// 0 = automatic (materialised-B 4x4x4 matrix-core kernel when n x p doubles fit in
+// half of the free HBM, else the fused 4x4x4 kernel when the terms fit it, else 16x16x4),
 // 1 = v_mfma_f64_16x16x4_f64 kernel, 2 = v_fma_f64 register-tiled kernel,
-// 3 = v_mfma_f64_4x4x4_4b_f64 kernel
+// 3 = fused v_mfma_f64_4x4x4_4b_f64 kernel, 4 = materialised-B 4x4x4 kernel
 static int g_gram_backend = 0;
 void set_gram_backend(int b) { g_gram_backend = b; }
 int get_gram_backend() { return g_gram_backend; }
 
 int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  if (g_gram_backend == 4 || (g_gram_backend == 0 && gram_panel_supports(b, t)))
+    return launch_gram_panel(b, t, d_G);
   if (g_gram_backend == 3 || (g_gram_backend == 0 && gram_mfma4_supports(t)))
     return launch_gram_mfma4(b, t, d_G);
   if (g_gram_backend == 2) return launch_gram_valu(b, t, d_G);

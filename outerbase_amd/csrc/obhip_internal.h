@@ -170,6 +170,8 @@ struct obhip_basis {
   obhip::DevBuf<double> bm;     // tile-blocked [n_pad/64][Mc][64]
   obhip::DevBuf<double> scale;  // n_pad (0 beyond n)
   obhip::DevBuf<char> work;     // scratch for split-reduction partials (grown on demand)
+  obhip::DevBuf<double> bmat;   // row-major design matrix [n_pad][p_pad], staging of the
+                                // materialised-B Gram kernel (allocated on first use)
   int device = 0;
   int workspace(size_t bytes, void **out) {
     if (work.n < bytes) {

@@ -193,7 +193,7 @@ class HotPath:
             call("obhip_fit_cg_dev", self.basis, self.t._h, self.om._h, self.y.data_ptr(),
                  self.sigma, self.rho, self.cg_tol, int(maxit), self.theta.data_ptr(),
                  C.byref(iters), self.diagH.data_ptr(), C.byref(val),
-                 self._cb, None)
+                 C.cast(self._cb, C.c_void_p) if self._cb is not None else None, None)
             self.cg_iters = iters.value
 
     def predict(self):

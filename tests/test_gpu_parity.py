@@ -171,15 +171,15 @@ def test_ragged_sizes(n, p):
 
 @pytest.fixture
 def gram_backend(request):
-    """1 = 16x16x4 matrix-core kernel, 2 = vector-pipe kernel, 3 = 4x4x4 matrix-core
-    kernel, 0 = automatic."""
+    """1 = 16x16x4 matrix-core kernel, 2 = vector-pipe kernel, 3 = fused 4x4x4
+    matrix-core kernel, 4 = materialised-B 4x4x4 matrix-core kernel, 0 = automatic."""
     from outerbase_amd import _lib
     _lib.call("obhip_set_gram_backend", request.param)
     yield request.param
     _lib.call("obhip_set_gram_backend", 0)
 
 
-@pytest.mark.parametrize("gram_backend", [1, 2, 3], indirect=True)
+@pytest.mark.parametrize("gram_backend", [1, 2, 3, 4], indirect=True)
 @pytest.mark.parametrize("n,p", [(2, 1), (65, 127), (200, 128), (1000, 129), (5000, 700)])
 def test_gram_backends(gram_backend, n, p):
     """both Gram kernels on single/multi tile pairs, ragged edges and multiple
@@ -201,7 +201,7 @@ def test_gram_backends(gram_backend, n, p):
     assert np.array_equal(G, G.T)
 
 
-@pytest.mark.parametrize("gram_backend", [1, 2, 3], indirect=True)
+@pytest.mark.parametrize("gram_backend", [1, 2, 3, 4], indirect=True)
 @pytest.mark.parametrize("max_nnz", [1, 2, 3, 5, 6, 8])
 def test_gram_term_widths(gram_backend, max_nnz):
     """terms with 1..8 non-zero levels (MFMA kernel template widths W = 2, 4, 6,
@@ -227,8 +227,9 @@ def test_gram_term_widths(gram_backend, max_nnz):
 
 
 def test_gram_wide_terms():
-    """a term with 9 non-zero levels: the matrix-core kernel (widths up to 8)
-    refuses it loudly, the vector-pipe kernel and the matrix-free path take it."""
+    """a term with 9 non-zero levels: the fused kernels (widths up to 8) refuse it
+    loudly; the materialised-B kernel (and with it the automatic choice) and the
+    matrix-free path take it."""
     import ob_oracle as O
     import outerbase_amd as ob
     from outerbase_amd import _lib
@@ -242,10 +243,14 @@ def test_gram_wide_terms():
     lik = ob.loglik_std(om_d, terms, rng.standard_normal(100), x)
     B = O.ob_getmat(O.OuterBase(om_o, x), terms)
     try:
-        for backend in (0, 1, 2, 3):
+        for backend in (1, 2, 3):
             _lib.call("obhip_set_gram_backend", backend)
             with pytest.raises(ob.ObhipError):
                 lik.hess()
+        for backend in (0, 4):
+            _lib.call("obhip_set_gram_backend", backend)
+            G = lik.hess() * math.exp(2 * lik.para[0])
+            assert relerr(G, B.T @ B) < 1e-11
     finally:
         _lib.call("obhip_set_gram_backend", 0)
     # the matrix-free path (and with it the CG fit) has no such limit

@@ -17,4 +17,14 @@ for it in range(3):
     _lib.call("obhip_gram_dev", h, hp.t._h, None, hp.G.data_ptr(), None)
     torch.cuda.synchronize(); t1 = time.perf_counter()
 ms = (t1 - t0) * 1e3
+_lib.call("obhip_profile_reset")
+_lib.call("obhip_profile_enable", 1)
+_lib.call("obhip_gram_dev", h, hp.t._h, None, hp.G.data_ptr(), None)
+torch.cuda.synchronize()
+for name in ("materialize_B", "gram", "gram_reduce"):
+    cnt, pm = C.c_uint64(), C.c_double()
+    _lib.call("obhip_profile_get", name.encode(), C.byref(cnt), C.byref(pm))
+    if cnt.value:
+        print("  %-14s %.3f ms" % (name, pm.value / cnt.value))
+_lib.call("obhip_profile_enable", 0)
 print("backend %d n=%d gram %.2f ms  %.2f TFLOP/s (dbg=%s)" % (backend, n, ms, n * 4096.0 * 4097 / ms / 1e9, os.environ.get("OBHIP_GRAM_DBG")))
