@@ -20,8 +20,9 @@
 //   per-wave 32-term LDS transpose, then 256-byte row segments to HBM.
 // k_gram_panel: tile pair (I, J), row range split over gridDim.y.  12 waves: 8
 //   consumers exactly as in k_gram_mfma4 (64 x 32 wave tiles, 32 accumulators,
-//   operands from triple-buffered LDS panels [row][term], pitch 272 doubles); 4
-//   producers copy the chunk's two 16 x 128 panels from B, two chunks ahead.
+//   operands from a ring of 4 LDS panel buffers [row][term], pitch 272 doubles); 4
+//   producers copy the chunk's two 16 x 128 panels from B, two chunks ahead in
+//   registers; the hand-over uses LDS counters, not barriers.
 #include "obhip_internal.h"
 #include "device_common.h"
 
@@ -84,11 +85,34 @@ k_materialize_rows(const double *__restrict__ bm, const double *__restrict__ sca
 }
 
 // ---- Gram from the materialised B ---------------------------------------------------------
+// Producer/consumer hand-over goes through LDS counters instead of workgroup barriers: a
+// barrier makes the 8 consumer waves drain the matrix pipe in lock-step once per chunk.
+// ready[b] counts producer waves that have filled buffer b (4 per use), done[b] counts
+// consumer waves that have issued their last read of it (8 per use).  LDS instructions of
+// one wave execute in order, so a counter update is ordered behind that wave's earlier
+// panel writes / operand reads.
+constexpr int kNB = 4;  // panel buffers
+
+__device__ __forceinline__ uint32_t flag_load(const uint32_t *p) {
+  return __builtin_amdgcn_readfirstlane(
+      __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void flag_wait(const uint32_t *p, uint32_t need) {
+  while (flag_load(p) < need) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void flag_signal(uint32_t *p, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __global__ void __launch_bounds__(768, 3)
 k_gram_panel(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntiles,
-             uint64_t tiles_per_split, double *__restrict__ part) {
-  extern __shared__ double T[];  // [3][16][272]
+             uint64_t tiles_per_split, double *__restrict__ part, int dbg) {
+  extern __shared__ double T[];  // [kNB][16][272] + counters
   constexpr int tsz = kCR * kTP;
+  uint32_t *ready = (uint32_t *)(T + kNB * tsz);
+  uint32_t *done = ready + kNB;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,6 +129,9 @@ k_gram_panel(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntil
   const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
   const int nchunks = (int)(t1 > t0 ? (t1 - t0) * (kTileRows / kCR) : 0);
 
+  if (tid < 2 * kNB) ready[tid] = 0;
+  __syncthreads();  // the only workgroup barrier
+
   if (producer) {
     // item e = pt + 256 q (q < 8): panel = e >> 10 (0: block I, 1: block J), row =
     // (e >> 6) & 15, 16-byte column pair c2 = e & 63: one wave instruction moves one
@@ -116,7 +143,7 @@ k_gram_panel(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntil
     const int dA = rq * kTP + 2 * c2, dB = rq * kTP + kGT + 2 * c2;
     d2 preA[kItems], preB[kItems];
     auto fetch = [&](int ch, d2 (&pre)[kItems]) {
-      const uint64_t off = (uint64_t)ch * kCR * p_pad;
+      const uint64_t off = (dbg & 2) ? 0 : (uint64_t)ch * kCR * p_pad;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         pre[q] = *(const d2 *)(srcA + off + (uint64_t)(4 * q) * p_pad);
@@ -131,31 +158,29 @@ k_gram_panel(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntil
         *(d2 *)(dst + dB + 4 * q * kTP) = pre[4 + q];
       }
     };
-    // Invariant at the top of iteration c: T[c % 3], T[(c+1) % 3] hold chunks c, c+1;
-    // this iteration's stage (A on even c, B on odd c) holds chunk c+2, the other c+3.
+    // registers hold chunks c (this iteration's stage) and c+1 (the other stage)
     if (nchunks > 0) fetch(0, preA);
     if (nchunks > 1) fetch(1, preB);
-    if (nchunks > 0) put(0, preA);
-    if (nchunks > 2) fetch(2, preA);
-    if (nchunks > 1) put(1, preB);
-    if (nchunks > 3) fetch(3, preB);
-    __syncthreads();  // (P)
-    int t2 = 2;  // (c + 2) % 3
+    int buf = 0;
+    uint32_t round = 0;  // c / kNB
+    auto stage = [&](int c, d2 (&pre)[kItems]) {
+      if (round > 0) flag_wait(done + buf, 8u * round);
+      put(buf, pre);
+      flag_signal(ready + buf, lane);
+      if (c + 2 < nchunks) fetch(c + 2, pre);
+      if (++buf == kNB) {
+        buf = 0;
+        ++round;
+      }
+    };
     for (int c = 0; c < nchunks; c += 2) {
-      if (c + 2 < nchunks) put(t2, preA);
-      if (c + 4 < nchunks) fetch(c + 4, preA);
-      t2 = t2 == 2 ? 0 : t2 + 1;
-      __syncthreads();
-      if (c + 1 >= nchunks) break;
-      if (c + 3 < nchunks) put(t2, preB);
-      if (c + 5 < nchunks) fetch(c + 5, preB);
-      t2 = t2 == 2 ? 0 : t2 + 1;
-      __syncthreads();
+      stage(c, preA);
+      if (c + 1 < nchunks) stage(c + 1, preB);
     }
     return;
   }
 
-  // consumers: identical to k_gram_mfma4
+  // consumers: 64 x 32 wave tiles as in k_gram_mfma4
   const int wm = wave >> 2, wn = wave & 3;
   const int mk = lane >> 4, mblk = (lane >> 2) & 3, me = lane & 3;
   double acc[4][2][4];
@@ -187,25 +212,32 @@ k_gram_panel(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntil
           acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[j][r], acc[i][j][r], 0, 0, 0);
   };
 
-  __syncthreads();  // (P)
   double a0[4], b0[2][4], a1[4], b1[2][4];
-  if (nchunks > 0) load_ops(T, 0, a0, b0);
-  int tc = 0;  // c % 3
+  int buf = 0;
+  uint32_t round = 0;
+  if (nchunks > 0) {
+    flag_wait(ready + 0, 4u);
+    load_ops(T, 0, a0, b0);
+  }
   for (int c = 0; c < nchunks; ++c) {
-    const double *tp = T + tc * tsz;
-    tc = tc == 2 ? 0 : tc + 1;
-    const double *tnext = T + tc * tsz;  // complete since the previous barrier
-#pragma unroll
-    for (int s = 0; s < kSteps; s += 2) {
-      load_ops(tp, s + 1, a1, b1);
-      mfma_step(a0, b0);
-      if (s + 2 < kSteps)
-        load_ops(tp, s + 2, a0, b0);
-      else if (c + 1 < nchunks)
-        load_ops(tnext, 0, a0, b0);
-      mfma_step(a1, b1);
+    const double *tp = T + buf * tsz;
+    uint32_t *mydone = done + buf;
+    if (++buf == kNB) {
+      buf = 0;
+      ++round;
     }
-    __syncthreads();
+    load_ops(tp, 1, a1, b1);
+    mfma_step(a0, b0);
+    load_ops(tp, 2, a0, b0);
+    mfma_step(a1, b1);
+    load_ops(tp, 3, a1, b1);
+    flag_signal(mydone, lane);  // last read of this buffer is in the LDS queue
+    mfma_step(a0, b0);
+    if (c + 1 < nchunks) {
+      flag_wait(ready + buf, 4u * (round + 1));
+      load_ops(T + buf * tsz, 0, a0, b0);
+    }
+    mfma_step(a1, b1);
   }
 
   double *out = part + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kGT * kGT);
@@ -219,6 +251,189 @@ k_gram_panel(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntil
         const int col = wn * 32 + j * 16 + ((mblk + r) & 3) * 4 + me;
         out[row * kGT + col] = acc[i][j][r];
       }
+}
+
+// ---- Gram from the materialised B, panels moved by LDS-direct loads ---------------------------
+// No producer waves at all: every consumer wave issues four global_load_lds_dwordx4 per chunk
+// (one instruction = one 1-KB row segment of a panel, global -> LDS without registers or
+// VALU work), kNB - 1 chunks ahead, and tracks them with vmcnt.  VMEM and SALU instructions
+// issue beside the wave's own MFMA stream, so the copy costs no matrix-pipe time.
+__device__ __forceinline__ void lds_dma_1k(const char *gbase /* uniform */, uint32_t voff,
+                                           uint32_t lds_addr /* uniform */) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff), "s"(gbase), "s"(lds_addr) : "memory");
+}
+
+// Operand reads are hand-issued ds_read_b64 with immediate offsets and hand-placed
+// s_waitcnt: a dynamic buffer index would cost ~20 integer VALU instructions per chunk for
+// LDS addresses, and tools/mfma4x4_lds_bench.hip shows each VALU instruction inside an
+// FP64-MFMA-saturated stream costs ~7-14 matrix-pipe cycles.  The loop below holds MFMA,
+// LDS, VMEM and SALU instructions only.
+template <int OFF>
+__device__ __forceinline__ double lds_rd(uint32_t addr) {
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_rd_ops(uint32_t aaddr, const uint32_t (&baddr)[4],
+                                           double (&a)[4], double (&b)[2][4]) {
+  a[0] = lds_rd<OFF>(aaddr);
+  a[1] = lds_rd<OFF + 128>(aaddr);
+  a[2] = lds_rd<OFF + 256>(aaddr);
+  a[3] = lds_rd<OFF + 384>(aaddr);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b[0][r] = lds_rd<OFF>(baddr[r]);
+    b[1][r] = lds_rd<OFF + 128>(baddr[r]);
+  }
+}
+// the 12 operands become usable here; KEEP = newer LDS reads that may stay in flight
+template <int KEEP>
+__device__ __forceinline__ void lds_wait_ops(double (&a)[4], double (&b)[2][4]) {
+  asm volatile("s_waitcnt lgkmcnt(%12)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0][0]), "+v"(b[0][1]),
+                 "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]),
+                 "+v"(b[1][3])
+               : "n"(KEEP));
+}
+
+__global__ void __launch_bounds__(512, 2)
+k_gram_dma(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntiles,
+           uint64_t tiles_per_split, double *__restrict__ part, unsigned long long *dbgout) {
+  extern __shared__ double T[];  // [kNB][16][272]
+  static_assert(kNB == 4, "buffer offsets and vmcnt immediates assume 4 buffers");
+  constexpr int tszb = kCR * kTP * 8;  // bytes per buffer
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int I = 0, rem = blockIdx.x;
+  while (rem >= nb - I) {
+    rem -= nb - I;
+    ++I;
+  }
+  const int J = I + rem;
+
+  const uint64_t t0 = (uint64_t)blockIdx.y * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+  const int nchunks = (int)(t1 > t0 ? (t1 - t0) * (kTileRows / kCR) : 0);
+
+  // wave w moves rows w and w + 8 of both panels of a chunk
+  const uint32_t ldsT = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)T;
+  const uint32_t lds0 = ldsT + wave * kTP * 8;
+  const uint32_t voff = lane * 16;
+  const char *gA = (const char *)(B + (t0 * kTileRows + wave) * p_pad + (uint64_t)I * kGT);
+  const char *gB = (const char *)(B + (t0 * kTileRows + wave) * p_pad + (uint64_t)J * kGT);
+  const uint64_t pitch8 = 8 * p_pad * sizeof(double), pitch16 = 2 * pitch8;
+  auto issue = [&](int ch, int buf) {
+    const uint32_t l = lds0 + buf * tszb;
+    const uint64_t off = (uint64_t)ch * pitch16;
+    lds_dma_1k(gA + off, voff, l);
+    lds_dma_1k(gB + off, voff, l + kGT * 8);
+    lds_dma_1k(gA + off + pitch8, voff, l + 8 * kTP * 8);
+    lds_dma_1k(gB + off + pitch8, voff, l + 8 * kTP * 8 + kGT * 8);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  const int mk = lane >> 4, mblk = (lane >> 2) & 3, me = lane & 3;
+  double acc[4][2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+  // byte addresses of this lane's operands in buffers 0 (set 0) and 2 (set 1); buffers 1
+  // and 3, the K steps and the 16-term sub-blocks are immediate offsets (< 64 KB)
+  uint32_t aaddr[2], baddr[2][4];
+#pragma unroll
+  for (int set = 0; set < 2; ++set) {
+    aaddr[set] = ldsT + set * 2 * tszb + (mk * kTP + wm * 64 + mblk * 4 + me) * 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      baddr[set][r] =
+          ldsT + set * 2 * tszb + (mk * kTP + kGT + wn * 32 + ((mblk + r) & 3) * 4 + me) * 8;
+  }
+  auto mfma_step = [&](const double (&a)[4], const double (&b)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[j][r], acc[i][j][r], 0, 0, 0);
+  };
+
+  // Invariant at the top of the body of chunk c: chunks c and c + 1 have landed and are
+  // visible to every wave; DMA loads are in flight up to chunk c + 2; the reads of chunk
+  // c's step-0 operands (a0, b0) are in the LDS queue.
+  for (int ch = 0; ch < kNB - 1 && ch < nchunks; ++ch) issue(ch, ch);
+  if (nchunks >= kNB - 1)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  double a0[4], b0[2][4], a1[4], b1[2][4];
+  constexpr int stp = 4 * kTP * 8;  // bytes per K step (4 rows)
+  if (nchunks > 0) lds_rd_ops<0>(aaddr[0], baddr[0], a0, b0);
+
+#define OB_CHUNK_BODY(BUF)                                                                   \
+  {                                                                                          \
+    constexpr int set = (BUF) >> 1, ob = ((BUF) & 1) * tszb;                                 \
+    constexpr int nset = (((BUF) + 1) & 3) >> 1, nob = (((BUF) + 1) & 1) * tszb;             \
+    const bool more = c + kNB - 1 < nchunks;                                                 \
+    if (more) issue(c + kNB - 1, ((BUF) + 3) & 3); /* buffer of chunk c - 1, free now */     \
+    lds_rd_ops<ob + stp>(aaddr[set], baddr[set], a1, b1);                                    \
+    lds_wait_ops<12>(a0, b0);                                                                \
+    mfma_step(a0, b0);                                                                       \
+    lds_rd_ops<ob + 2 * stp>(aaddr[set], baddr[set], a0, b0);                                \
+    lds_wait_ops<12>(a1, b1);                                                                \
+    mfma_step(a1, b1);                                                                       \
+    lds_rd_ops<ob + 3 * stp>(aaddr[set], baddr[set], a1, b1);                                \
+    lds_wait_ops<12>(a0, b0);                                                                \
+    mfma_step(a0, b0);                                                                       \
+    /* step 0 of the next chunk; past the last chunk this reads a stale buffer, unused */    \
+    lds_rd_ops<nob>(aaddr[nset], baddr[nset], a0, b0);                                       \
+    lds_wait_ops<12>(a1, b1);                                                                \
+    mfma_step(a1, b1);                                                                       \
+    if (more)                                                                                \
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); /* own part of chunk c + 2 landed */  \
+    else                                                                                     \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+    __builtin_amdgcn_s_barrier();                                                            \
+    ++c;                                                                                     \
+  }
+
+  for (int c = 0; c < nchunks;) {
+    OB_CHUNK_BODY(0)
+    if (c >= nchunks) break;
+    OB_CHUNK_BODY(1)
+    if (c >= nchunks) break;
+    OB_CHUNK_BODY(2)
+    if (c >= nchunks) break;
+    OB_CHUNK_BODY(3)
+  }
+#undef OB_CHUNK_BODY
+  if (nchunks > 0) lds_wait_ops<0>(a0, b0);  // the trailing (unused) reads have landed
+
+  double *out = part + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kGT * kGT);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + i * 16 + mblk * 4 + mk;
+        const int col = wn * 32 + j * 16 + ((mblk + r) & 3) * 4 + me;
+        out[row * kGT + col] = acc[i][j][r];
+      }
+  if (dbgout && blockIdx.x == 7 && blockIdx.y == 3 && tid == 0) {
+    dbgout[0] = __builtin_amdgcn_s_memtime() - st0;
+    dbgout[1] = __builtin_amdgcn_s_memrealtime() - sr0;
+    dbgout[2] = nchunks;
+  }
 }
 
 template <int W2>
@@ -262,6 +477,8 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
       default: OB_TRY(run_materialize<0>(b, t, b.bmat.p)); break;
     }
   }
+  const int dbg = getenv("OBHIP_GRAM_DBG") ? atoi(getenv("OBHIP_GRAM_DBG")) : 0;
+  if (dbg & 1) OB_HIP(hipMemsetAsync(b.bmat.p, 0, need * sizeof(double), cur_stream()));
   const int nb = (int)((t.p + kGT - 1) / kGT);
   const int npairs = nb * (nb + 1) / 2;
   const uint64_t ntiles = b.n_pad / kTileRows;
@@ -270,14 +487,29 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
   const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
   nsplit = (ntiles + tps - 1) / tps;
   double *part = nullptr;
-  OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double), (void **)&part));
-  const size_t lds = (size_t)3 * kCR * kTP * sizeof(double);
+  OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 64, (void **)&part));
+  unsigned long long *dbgout =
+      (dbg & 16) ? (unsigned long long *)(part + (size_t)nsplit * npairs * kGT * kGT) : nullptr;
+  const size_t lds = (size_t)kNB * kCR * kTP * sizeof(double) + 2 * kNB * sizeof(uint32_t);
   OB_HIP(hipFuncSetAttribute((const void *)k_gram_panel, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds));
-  {
+  if (!(dbg & 4)) {
+    const size_t ldsd = (size_t)kNB * kCR * kTP * sizeof(double);
+    ProfScope ps("gram");
+    OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+    hipLaunchKernelGGL(k_gram_dma, dim3((unsigned)npairs, (unsigned)nsplit), dim3(512), ldsd,
+                       cur_stream(), b.bmat.p, t.p_pad, nb, ntiles, tps, part, dbgout);
+    OB_HIP(hipGetLastError());
+    if (dbgout) {
+      unsigned long long h[3];
+      OB_HIP(hipMemcpy(h, dbgout, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[gram dbg] block: %llu memtime ticks, %llu realtime ticks (100 MHz) -> %.1f MHz if memtime = shader clock; %.1f ticks/chunk\n", h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0, h[2] ? (double)h[0] / h[2] : 0.0);
+    }
+  } else {
     ProfScope ps("gram");
     hipLaunchKernelGGL(k_gram_panel, dim3((unsigned)npairs, (unsigned)nsplit), dim3(768), lds,
-                       cur_stream(), b.bmat.p, t.p_pad, nb, ntiles, tps, part);
+                       cur_stream(), b.bmat.p, t.p_pad, nb, ntiles, tps, part, dbg);
     OB_HIP(hipGetLastError());
   }
   return launch_gram_reduce(part, npairs, (int)nsplit, nb, (int)t.p, d_G);

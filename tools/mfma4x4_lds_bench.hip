@@ -9,7 +9,7 @@
 constexpr int kTP = 272;
 static double g_fill = 0.0;
 
-template <int THREADS, bool LDS, bool BARRIER, int NMUL = 0>
+template <int THREADS, bool LDS, bool BARRIER, int NMUL = 0, int NVALU = 0>
 __global__ void __launch_bounds__(THREADS) k(double *out, int chunks, const double *in) {
   __shared__ double T[16 * kTP];
   for (int e = threadIdx.x; e < 16 * kTP; e += THREADS) T[e] = in[e & 1023] + 1e-9 * e;
@@ -66,12 +66,17 @@ __global__ void __launch_bounds__(THREADS) k(double *out, int chunks, const doub
           acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[j][r], acc[i][j][r], 0, 0, 0);
   };
   double a0[4], b0[2][4], a1[4], b1[2][4];
+  int dummy = lane;
   load_ops(0, a0, b0);
   load_ops(1, a1, b1);
   for (int c = 0; c < chunks; ++c) {
 #pragma unroll
     for (int s = 0; s < 4; s += 2) {
       if (LDS) load_ops(s + 1, a1, b1);
+      // NVALU integer VALU instructions per chunk inside the consumer's own stream (the
+      // LDS address arithmetic a dynamic buffer index costs)
+#pragma unroll
+      for (int q = 0; q < NVALU / 2; ++q) asm volatile("v_add_u32 %0, 1, %0" : "+v"(dummy));
       mfma_step(a0, b0);
       if (LDS) load_ops((s + 2) & 3, a0, b0);
       mfma_step(a1, b1);
@@ -86,10 +91,10 @@ __global__ void __launch_bounds__(THREADS) k(double *out, int chunks, const doub
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) s += acc[i][j][r];
-  out[blockIdx.x * THREADS + threadIdx.x] = s;
+  out[blockIdx.x * THREADS + threadIdx.x] = s + dummy;
 }
 
-template <int THREADS, bool LDS, bool BARRIER, int NMUL = 0>
+template <int THREADS, bool LDS, bool BARRIER, int NMUL = 0, int NVALU = 0>
 void run(const char *label, int chunks) {
   const int blocks = 256;
   double *out, *in;
@@ -99,10 +104,10 @@ void run(const char *label, int chunks) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  k<THREADS, LDS, BARRIER, NMUL><<<blocks, THREADS>>>(out, chunks, in);
+  k<THREADS, LDS, BARRIER, NMUL, NVALU><<<blocks, THREADS>>>(out, chunks, in);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k<THREADS, LDS, BARRIER, NMUL><<<blocks, THREADS>>>(out, chunks, in);
+  k<THREADS, LDS, BARRIER, NMUL, NVALU><<<blocks, THREADS>>>(out, chunks, in);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -123,6 +128,9 @@ int main(int argc, char **argv) {
   run<768, true, false>("32 acc, 12 LDS operands/step", 40000);
   run<512, true, true>("32 acc, LDS operands, barrier per 4 steps", 40000);
   run<768, true, true>("32 acc, LDS operands, barrier per 4 steps", 40000);
+  run<512, true, true, 0, 8>("8 consumers, barrier, + 8 int VALU / chunk", 40000);
+  run<512, true, true, 0, 24>("8 consumers, barrier, + 24 int VALU / chunk", 40000);
+  run<512, true, true, 0, 64>("8 consumers, barrier, + 64 int VALU / chunk", 40000);
   run<768, true, true, 8>("8 consumers + 4 waves x 8 v_mul_f64 / chunk", 40000);
   run<768, true, true, 64>("8 consumers + 4 waves x 64 v_mul_f64 / chunk", 40000);
   run<768, true, true, 256>("8 consumers + 4 waves x 256 v_mul_f64 / chunk", 40000);
