@@ -436,6 +436,168 @@ k_gram_dma(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntiles
   }
 }
 
+// ---- two desynchronised blocks per CU --------------------------------------------------------
+// Same data flow as k_gram_dma, but 4 waves per block with 64 x 64 wave tiles (64
+// accumulators) and two blocks resident per CU: while the waves of one block sit at their
+// barrier (or wait for their LDS-direct loads), the other block's wave on the same SIMD owns
+// the matrix pipe.  Two panel buffers per block (2 x 34 KB x 2 blocks = 139 KB of LDS).
+// lgkmcnt holds 4 bits, so a K step's 20 operand reads go out in two halves (12 + 8) with at
+// most 15 newer reads behind any wait.
+__device__ __forceinline__ void lds_wait12(int keep8, double (&a)[4], double (&b)[4][4]) {
+  // a[0..3], b[0..1][0..3] usable; 8 newer reads may stay in flight
+  asm volatile("s_waitcnt lgkmcnt(8)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0][0]), "+v"(b[0][1]),
+                 "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]),
+                 "+v"(b[1][3]));
+}
+template <int KEEP>
+__device__ __forceinline__ void lds_wait8(double (&b)[4][4]) {
+  // b[2..3][0..3] usable; KEEP newer reads may stay in flight
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[2][2]), "+v"(b[2][3]), "+v"(b[3][0]),
+                 "+v"(b[3][1]), "+v"(b[3][2]), "+v"(b[3][3])
+               : "n"(KEEP));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_rd_h0(uint32_t aaddr, const uint32_t (&baddr)[4],
+                                          double (&a)[4], double (&b)[4][4]) {
+  a[0] = lds_rd<OFF>(aaddr);
+  a[1] = lds_rd<OFF + 128>(aaddr);
+  a[2] = lds_rd<OFF + 256>(aaddr);
+  a[3] = lds_rd<OFF + 384>(aaddr);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b[0][r] = lds_rd<OFF>(baddr[r]);
+    b[1][r] = lds_rd<OFF + 128>(baddr[r]);
+  }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_rd_h1(const uint32_t (&baddr)[4], double (&b)[4][4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b[2][r] = lds_rd<OFF + 256>(baddr[r]);
+    b[3][r] = lds_rd<OFF + 384>(baddr[r]);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntiles,
+            uint64_t tiles_per_split, double *__restrict__ part, unsigned long long *dbgout) {
+  extern __shared__ double T[];  // [2][16][272]
+  constexpr int tszb = kCR * kTP * 8;  // bytes per buffer
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int I = 0, rem = blockIdx.x;
+  while (rem >= nb - I) {
+    rem -= nb - I;
+    ++I;
+  }
+  const int J = I + rem;
+
+  const uint64_t t0 = (uint64_t)blockIdx.y * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+  const int nchunks = (int)(t1 > t0 ? (t1 - t0) * (kTileRows / kCR) : 0);
+
+  // wave w moves rows w, w + 4, w + 8, w + 12 of both panels of a chunk
+  const uint32_t ldsT = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)T;
+  const uint32_t lds0 = ldsT + wave * kTP * 8;
+  const uint32_t voff = lane * 16;
+  const char *gA = (const char *)(B + (t0 * kTileRows + wave) * p_pad + (uint64_t)I * kGT);
+  const char *gB = (const char *)(B + (t0 * kTileRows + wave) * p_pad + (uint64_t)J * kGT);
+  const uint64_t pitch4 = 4 * p_pad * sizeof(double), pitch16 = 4 * pitch4;
+  auto issue = [&](int ch, int buf) {
+    const uint32_t l = lds0 + buf * tszb;
+    const char *a = gA + (uint64_t)ch * pitch16, *b = gB + (uint64_t)ch * pitch16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      lds_dma_1k(a + q * pitch4, voff, l + q * 4 * kTP * 8);
+      lds_dma_1k(b + q * pitch4, voff, l + q * 4 * kTP * 8 + kGT * 8);
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mk = lane >> 4, mblk = (lane >> 2) & 3, me = lane & 3;
+  double acc[4][4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+  const uint32_t aaddr = ldsT + (mk * kTP + wm * 64 + mblk * 4 + me) * 8;
+  uint32_t baddr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    baddr[r] = ldsT + (mk * kTP + kGT + wn * 64 + ((mblk + r) & 3) * 4 + me) * 8;
+  auto mfma_half = [&](const double (&a)[4], const double (&b)[4][4], int j0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = j0; j < j0 + 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[j][r], acc[i][j][r], 0, 0, 0);
+  };
+
+  if (nchunks > 0) issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  double a0[4], b0[4][4], a1[4], b1[4][4];
+  constexpr int stp = 4 * kTP * 8;  // bytes per K step (4 rows)
+
+  // one K step on the operand set `cur`; the next step's reads go out in two halves
+#define OB_STEP(cur_a, cur_b, nxt_a, nxt_b, NEXT_OFF, HAS_NEXT)                              \
+  lds_wait12(0, cur_a, cur_b);                                                               \
+  if (HAS_NEXT) lds_rd_h0<NEXT_OFF>(aaddr, baddr, nxt_a, nxt_b);                             \
+  mfma_half(cur_a, cur_b, 0);                                                                \
+  lds_wait8<(HAS_NEXT) ? 12 : 0>(cur_b);                                                     \
+  if (HAS_NEXT) lds_rd_h1<NEXT_OFF>(baddr, nxt_b);                                           \
+  mfma_half(cur_a, cur_b, 2);
+
+#define OB_CHUNK_BODY2(BUF)                                                                  \
+  {                                                                                          \
+    constexpr int ob = (BUF) * tszb;                                                         \
+    if (c + 1 < nchunks) issue(c + 1, (BUF) ^ 1); /* free since the barrier */               \
+    lds_rd_h0<ob>(aaddr, baddr, a0, b0);                                                     \
+    lds_rd_h1<ob>(baddr, b0);                                                                \
+    OB_STEP(a0, b0, a1, b1, ob + stp, true)                                                  \
+    OB_STEP(a1, b1, a0, b0, ob + 2 * stp, true)                                              \
+    OB_STEP(a0, b0, a1, b1, ob + 3 * stp, true)                                              \
+    OB_STEP(a1, b1, a0, b0, 0, false)                                                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* own part of chunk c + 1 landed */    \
+    __builtin_amdgcn_s_barrier();                                                            \
+    ++c;                                                                                     \
+  }
+
+  for (int c = 0; c < nchunks;) {
+    OB_CHUNK_BODY2(0)
+    if (c >= nchunks) break;
+    OB_CHUNK_BODY2(1)
+  }
+#undef OB_CHUNK_BODY2
+#undef OB_STEP
+
+  double *out = part + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kGT * kGT);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + i * 16 + mblk * 4 + mk;
+        const int col = wn * 64 + j * 16 + ((mblk + r) & 3) * 4 + me;
+        out[row * kGT + col] = acc[i][j][r];
+      }
+  if (dbgout && blockIdx.x == 7 && blockIdx.y == 3 && tid == 0) {
+    dbgout[0] = __builtin_amdgcn_s_memtime() - st0;
+    dbgout[1] = __builtin_amdgcn_s_memrealtime() - sr0;
+    dbgout[2] = nchunks;
+  }
+}
+
 template <int W2>
 int run_materialize(const obhip_basis &b, obhip_terms &t, double *d_B) {
   const size_t lds = (t.Mu * kTileRows + 4 * 32 * kTB) * sizeof(double);
@@ -482,10 +644,30 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
   const int nb = (int)((t.p + kGT - 1) / kGT);
   const int npairs = nb * (nb + 1) / 2;
   const uint64_t ntiles = b.n_pad / kTileRows;
-  uint64_t nsplit = std::max<uint64_t>(1, (4096 + npairs - 1) / npairs);
-  nsplit = std::min(nsplit, std::max<uint64_t>(1, ntiles / 8));
+  // Row split: one block per CU at a time and all blocks equally long, so the launch takes
+  // ceil(blocks / CUs) rounds of tiles-per-split each; pick the split that minimises that
+  // product (528 pairs x 16 splits = 33 x 256 exactly on MI355X), 2 tiles per block charged
+  // for its prologue and partial-tile write.
+  static int ncu = 0;
+  if (!ncu) {
+    OB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b.device));
+    if (ncu <= 0) ncu = 256;
+  }
+  const bool two_blocks = !(dbg & 8) && !(dbg & 4);  // k_gram_dma2: two resident blocks per CU
+  const uint64_t slots = (uint64_t)ncu * (two_blocks ? 2 : 1);
+  uint64_t nsplit = 1, best = ~0ull;
+  const uint64_t max_split =
+      std::max<uint64_t>(1, std::min<uint64_t>({64, ntiles / 8, (4ull << 30) / ((uint64_t)npairs * kGT * kGT * 8)}));
+  for (uint64_t ns = 1; ns <= max_split; ++ns) {
+    const uint64_t tp = (ntiles + ns - 1) / ns, nse = (ntiles + tp - 1) / tp;
+    const uint64_t rounds = (nse * npairs + slots - 1) / slots, cost = rounds * (tp + 2);
+    if (cost < best) {
+      best = cost;
+      nsplit = nse;
+    }
+  }
+  if (getenv("OBHIP_GRAM_NSPLIT")) nsplit = std::max(1, atoi(getenv("OBHIP_GRAM_NSPLIT")));
   const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
-  nsplit = (ntiles + tps - 1) / tps;
   double *part = nullptr;
   OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 64, (void **)&part));
   unsigned long long *dbgout =
@@ -494,12 +676,20 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
   OB_HIP(hipFuncSetAttribute((const void *)k_gram_panel, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds));
   if (!(dbg & 4)) {
-    const size_t ldsd = (size_t)kNB * kCR * kTP * sizeof(double);
     ProfScope ps("gram");
-    OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
-    hipLaunchKernelGGL(k_gram_dma, dim3((unsigned)npairs, (unsigned)nsplit), dim3(512), ldsd,
-                       cur_stream(), b.bmat.p, t.p_pad, nb, ntiles, tps, part, dbgout);
+    if (two_blocks) {
+      const size_t ldsd = (size_t)2 * kCR * kTP * sizeof(double);
+      OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma2,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+      hipLaunchKernelGGL(k_gram_dma2, dim3((unsigned)npairs, (unsigned)nsplit), dim3(256), ldsd,
+                         cur_stream(), b.bmat.p, t.p_pad, nb, ntiles, tps, part, dbgout);
+    } else {
+      const size_t ldsd = (size_t)kNB * kCR * kTP * sizeof(double);
+      OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+      hipLaunchKernelGGL(k_gram_dma, dim3((unsigned)npairs, (unsigned)nsplit), dim3(512), ldsd,
+                         cur_stream(), b.bmat.p, t.p_pad, nb, ntiles, tps, part, dbgout);
+    }
     OB_HIP(hipGetLastError());
     if (dbgout) {
       unsigned long long h[3];
