@@ -482,7 +482,8 @@ __device__ __forceinline__ void lds_rd_h1(const uint32_t (&baddr)[4], double (&b
 
 __global__ void __launch_bounds__(256, 2)
 k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntiles,
-            uint64_t tiles_per_split, double *__restrict__ part, unsigned long long *dbgout) {
+            uint64_t tiles_per_split, const uint32_t *__restrict__ pairs,
+            double *__restrict__ part, unsigned long long *dbgout) {
   extern __shared__ double T[];  // [2][16][272]
   constexpr int tszb = kCR * kTP * 8;  // bytes per buffer
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
@@ -490,12 +491,11 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntile
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  int I = 0, rem = blockIdx.x;
-  while (rem >= nb - I) {
-    rem -= nb - I;
-    ++I;
-  }
-  const int J = I + rem;
+  // XCD-aware order: pairs[] deals compact squares of the (I, J) triangle to the blocks
+  // that share an XCD (and with it an L2), see build_pair_order
+  const uint32_t ij = pairs[blockIdx.x];
+  const int I = ij & 0xffff, J = ij >> 16;
+  const int slot = I * nb - I * (I - 1) / 2 + (J - I);  // row-major index in the upper triangle
 
   const uint64_t t0 = (uint64_t)blockIdx.y * tiles_per_split;
   const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
@@ -510,6 +510,7 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntile
   const uint64_t pitch4 = 4 * p_pad * sizeof(double), pitch16 = 4 * pitch4;
   auto issue = [&](int ch, int buf) {
     const uint32_t l = lds0 + buf * tszb;
+    if (dbgout && dbgout[7]) ch = 0;  // debug: L2-resident source
     const char *a = gA + (uint64_t)ch * pitch16, *b = gB + (uint64_t)ch * pitch16;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -580,7 +581,7 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntile
 #undef OB_CHUNK_BODY2
 #undef OB_STEP
 
-  double *out = part + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kGT * kGT);
+  double *out = part + ((uint64_t)blockIdx.y * gridDim.x + slot) * (kGT * kGT);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -596,6 +597,37 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntile
     dbgout[1] = __builtin_amdgcn_s_memrealtime() - sr0;
     dbgout[2] = nchunks;
   }
+}
+
+// Workgroups go to the 8 XCDs round-robin by linear id, so blocks x, x + 8, x + 16, ... of
+// a row split share one 4-MB L2.  Give each XCD a contiguous run of the tile pairs sorted
+// square-major (8 x 8 squares of the (I, J) triangle): its ~66 resident blocks then touch
+// ~16-24 of the 32 column blocks instead of all of them, and panel rows fetched by one
+// block are L2 hits for the others.
+constexpr int kXcd = 8;
+void build_pair_order(int nb, std::vector<uint32_t> &tab) {
+  const int npairs = nb * (nb + 1) / 2;
+  const int group = (npairs + kXcd - 1) / kXcd;
+  int sq = 1;
+  while ((sq + 1) * (sq + 1) <= group) ++sq;
+  std::vector<uint32_t> sorted;
+  sorted.reserve(npairs);
+  for (int bi = 0; bi * sq < nb; ++bi)
+    for (int bj = bi; bj * sq < nb; ++bj)
+      for (int i = bi * sq; i < std::min(nb, (bi + 1) * sq); ++i)
+        for (int j = std::max(i, bj * sq); j < std::min(nb, (bj + 1) * sq); ++j)
+          sorted.push_back((uint32_t)i | ((uint32_t)j << 16));
+  tab.assign(npairs, 0);
+  if (getenv("OBHIP_GRAM_ORDER") && atoi(getenv("OBHIP_GRAM_ORDER")) == 0) {  // tuning aid
+    int x = 0;
+    for (int i = 0; i < nb; ++i)
+      for (int j = i; j < nb; ++j) tab[x++] = (uint32_t)i | ((uint32_t)j << 16);
+    return;
+  }
+  // block x = kXcd * m + k runs on XCD k: hand it element m of XCD k's run
+  int next = 0;
+  for (int k = 0; k < kXcd; ++k)
+    for (int x = k; x < npairs; x += kXcd) tab[x] = sorted[next++];
 }
 
 template <int W2>
@@ -672,6 +704,10 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
   OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 64, (void **)&part));
   unsigned long long *dbgout =
       (dbg & 16) ? (unsigned long long *)(part + (size_t)nsplit * npairs * kGT * kGT) : nullptr;
+  if (dbgout) {
+    unsigned long long flag = (dbg & 2) ? 1 : 0;
+    OB_HIP(hipMemcpy(dbgout + 7, &flag, 8, hipMemcpyHostToDevice));
+  }
   const size_t lds = (size_t)kNB * kCR * kTP * sizeof(double) + 2 * kNB * sizeof(uint32_t);
   OB_HIP(hipFuncSetAttribute((const void *)k_gram_panel, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds));
@@ -681,8 +717,15 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
       const size_t ldsd = (size_t)2 * kCR * kTP * sizeof(double);
       OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma2,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+      if (b.gram_pairs_nb != nb) {
+        std::vector<uint32_t> tab;
+        build_pair_order(nb, tab);
+        OB_TRY(b.gram_pairs.upload(tab.data(), tab.size()));
+        b.gram_pairs_nb = nb;
+      }
       hipLaunchKernelGGL(k_gram_dma2, dim3((unsigned)npairs, (unsigned)nsplit), dim3(256), ldsd,
-                         cur_stream(), b.bmat.p, t.p_pad, nb, ntiles, tps, part, dbgout);
+                         cur_stream(), b.bmat.p, t.p_pad, nb, ntiles, tps, b.gram_pairs.p, part,
+                         dbgout);
     } else {
       const size_t ldsd = (size_t)kNB * kCR * kTP * sizeof(double);
       OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma,

@@ -172,6 +172,8 @@ struct obhip_basis {
   obhip::DevBuf<char> work;     // scratch for split-reduction partials (grown on demand)
   obhip::DevBuf<double> bmat;   // row-major design matrix [n_pad][p_pad], staging of the
                                 // materialised-B Gram kernel (allocated on first use)
+  obhip::DevBuf<uint32_t> gram_pairs;  // XCD-aware tile-pair order of that kernel
+  int gram_pairs_nb = -1;
   int device = 0;
   int workspace(size_t bytes, void **out) {
     if (work.n < bytes) {
