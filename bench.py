@@ -229,7 +229,7 @@ def main():
         hp.step()
     torch.cuda.synchronize()
     prof = {}
-    for name in ["build_basis", "gram", "gram_reduce", "tmm", "mm", "sqtmm", "form_hessian",
+    for name in ["build_basis", "materialize_B", "gram", "gram_reduce", "tmm", "mm", "sqtmm", "form_hessian",
                  "cholesky", "backsolve", "predict"]:
         cnt, ms = C.c_uint64(0), C.c_double(0)
         _lib.call("obhip_profile_get", name.encode(), C.byref(cnt), C.byref(ms))
@@ -303,13 +303,16 @@ def main():
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE,
         # WRITE_SIZE) on this exact workload; see the file for the command and caveats
         traffic = None
+        kernel = {0: "k_gram_dma2", 1: "k_gram", 2: "k_gram_valu", 3: "k_gram_mfma4",
+                  4: "k_gram_dma2"}[args.gram_backend]
         tf = os.path.join(ROOT, "profiles", "r01_gram_traffic.json")
-        if os.path.exists(tf) and args.gram_backend in (0, 3):
+        if os.path.exists(tf):
             tj = json.load(open(tf))
             c = tj["config"]
-            if (c["d"], c["rows"], c["p"], c["knots"]) == (args.d, n, p, args.knots):
+            if tj["kernel"] == kernel and \
+                    (c["d"], c["rows"], c["p"], c["knots"]) == (args.d, n, p, args.knots):
                 traffic = tj["traffic_bytes_per_launch"]
-        out["roofline"] = {"bound": "mfma", "kernel": "k_gram_mfma4", "achieved": ach,
+        out["roofline"] = {"bound": "mfma", "kernel": kernel, "achieved": ach,
                            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                            "traffic_unit": "bytes per launch (PMC, separate pass)",
