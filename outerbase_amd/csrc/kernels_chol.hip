@@ -18,6 +18,8 @@
 //                  matching update of z.
 // Backward: k_chol_back per block from the last to the first: theta_j =
 // L_jj^-T z_j, then z[0:j) -= L[j, 0:j)^T theta_j.
+#include <utility>
+
 #include "obhip_internal.h"
 
 namespace obhip {
@@ -134,6 +136,213 @@ k_chol_panel(double *__restrict__ H, double *__restrict__ z, int p, int j0, int 
       else
         H[(size_t)(r0 + r) * p + j0 + lane] = v;
     }
+}
+
+// ---- panel step ---------------------------------------------------------------------------------
+// One workgroup (4 waves) per 64 panel rows; block 0 handles the diagonal block only, the
+// last block the rhs row z (which makes the forward substitution L z = rhs part of the panel
+// solve).  Every workgroup re-factorises the 64 x 64 diagonal block itself (cheaper than a
+// launch boundary):
+//   1. wave 0: unblocked right-looking Cholesky, lane = row, 64 columns of the row in
+//      registers.  The next pivot's only dependence on the current column goes through a
+//      v_readlane (register path); the rest of the rank-1 update reads the finished column
+//      back from LDS as broadcast ds_read_b128 and overlaps the next column's rsqrt chain.
+//      Waves 1-3 meanwhile stage the workgroup's panel rows in LDS.
+//   2. wave w inverts the 16 x 16 diagonal sub-block L_ww (lane = column of the inverse).
+//   3. blocked triangular solve X L_jj^T = A on v_mfma_f64_16x16x4_f64, wave w owns 16
+//      rows: X_b = (A_b - sum_{c<b} X_c L_bc^T) inv(L_bb)^T for the four 16-column blocks,
+//      results passed from the MFMA output layout to the operand layout through LDS.
+typedef double d2v __attribute__((ext_vector_type(2)));
+constexpr int LT = NB + 2;   // column-buffer pitch (even: 16-byte aligned pairs)
+constexpr int SP = 17;       // pitch of the 16 x 16 scratch blocks
+
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+// column C of the in-register factorisation (lane = row); a template so that every index
+// below is a compile-time constant (a[] must stay in registers)
+template <int C>
+__device__ __forceinline__ void potrf_col(double (&a)[NB], double &piv, bool &bad, double *Lt,
+                                          double *dinv, int lane) {
+  if (!(piv > 0.0)) bad = true;
+  const double rs = rsqrt_nr(piv);
+  double sq = piv * rs;
+  sq = fma(fma(-sq, sq, piv), 0.5 * rs, sq);
+  const double lc = lane < C ? 0.0 : (lane == C ? sq : a[C] * rs);
+  if (lane == C) dinv[C] = rs;
+  if constexpr (C + 1 < NB) {
+    // the next pivot depends on this column only through L[C+1][C]: register path
+    a[C + 1] = fma(-lc, readlane_d(lc, C + 1), a[C + 1]);
+    piv = readlane_d(a[C + 1], C + 1);
+  }
+  Lt[C * LT + lane] = lc;
+  // rest of the rank-1 update; L[k][C] comes back from LDS as broadcast reads, in groups
+  // of 8 values one group ahead of the FMAs (sched_barrier: left alone, the scheduler
+  // hoists every read of the column and spills ~2000 registers)
+  constexpr int K0 = C + 2, G0 = K0 / 8;
+  if constexpr (K0 < NB) {
+    d2v cur[4], nxt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (8 * G0 + 2 * u + 1 >= K0) cur[u] = *(const d2v *)&Lt[C * LT + 8 * G0 + 2 * u];
+#pragma unroll
+    for (int g = G0; g < NB / 8; ++g) {
+      if (g + 1 < NB / 8) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nxt[u] = *(const d2v *)&Lt[C * LT + 8 * (g + 1) + 2 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 8 * g + 2 * u;
+        if (k >= K0) a[k] = fma(-lc, cur[u].x, a[k]);
+        if (k + 1 >= K0) a[k + 1] = fma(-lc, cur[u].y, a[k + 1]);
+      }
+      // pin the group: the "+v" operands order the FMAs, the memory clobber the reads
+      asm volatile(""
+                   : "+v"(a[8 * g]), "+v"(a[8 * g + 1]), "+v"(a[8 * g + 2]), "+v"(a[8 * g + 3]),
+                     "+v"(a[8 * g + 4]), "+v"(a[8 * g + 5]), "+v"(a[8 * g + 6]), "+v"(a[8 * g + 7])
+                   :
+                   : "memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+    }
+  }
+}
+template <int... Cs>
+__device__ __forceinline__ void potrf_cols(std::integer_sequence<int, Cs...>, double (&a)[NB],
+                                           double &piv, bool &bad, double *Lt, double *dinv,
+                                           int lane) {
+  (potrf_col<Cs>(a, piv, bad, Lt, dinv, lane), ...);
+}
+
+__global__ void __launch_bounds__(256)
+k_chol_panel2(double *__restrict__ H, double *__restrict__ z, int p, int j0, int *__restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double Lt[NB * LT];  // Lt[c][k] = L[k][c], 0 for k < c
+  __shared__ double P[NB * LDP];    // diagonal block; later X (solved rows), per wave 16 rows
+  __shared__ double Ap[NB * LDP];   // panel rows
+  __shared__ double Iw[4 * 16 * SP];  // inverses of the four 16 x 16 diagonal sub-blocks
+  __shared__ double Ts[4 * 16 * SP];  // per-wave transpose scratch
+  __shared__ double dinv[NB];         // 1 / L[i][i]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jb = min(NB, p - j0);
+
+  // diagonal block -> LDS (identity padding beyond jb), 16 rows per wave, coalesced
+  {
+    const double *src = H + (size_t)j0 * p + j0 + min(lane, jb - 1);
+    double t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = src[(size_t)min(wave * 16 + i, jb - 1) * p];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = wave * 16 + i;
+      P[r * LDP + lane] = (r < jb && lane < jb) ? t[i] : ((r == lane) ? 1.0 : 0.0);
+    }
+  }
+  __syncthreads();
+
+  const bool is_z = blockIdx.x == gridDim.x - 1;
+  const int r0 = j0 + NB * (int)blockIdx.x;
+  const int nrows = is_z ? 1 : min(NB, p - r0);
+
+  if (wave == 0) {
+    double a[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) a[k] = P[lane * LDP + k];
+    bool bad = false;
+    double piv = readlane_d(a[0], 0);
+    potrf_cols(std::make_integer_sequence<int, NB>{}, a, piv, bad, Lt, dinv, lane);
+    if (bad && blockIdx.x == 0 && lane == 0) atomicMax(info, j0 + 1);
+  } else if (blockIdx.x != 0) {
+    // panel rows of this workgroup -> Ap (coalesced rows, zero padding), waves 1-3
+    const int lc = min(lane, jb - 1);
+    const double *src = is_z ? z + j0 + lc : H + (size_t)min(r0, p - 1) * p + j0 + lc;
+    const size_t pitch = is_z ? 0 : (size_t)p;
+    const int rmax = max(nrows - 1, 0);
+    for (int rb = (wave - 1) * 8; rb < NB; rb += 24) {
+      double t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = src[(size_t)min(rb + i, rmax) * pitch];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = rb + i;
+        if (r < NB) Ap[r * LDP + lane] = (r < nrows && lane < jb) ? t[i] : 0.0;
+      }
+    }
+  }
+  __syncthreads();  // Lt, dinv, Ap complete; P (diagonal block) is free
+
+  if (blockIdx.x == 0) {
+    // write L_jj (lower triangle) back
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      if (r < jb && c <= r) H[(size_t)(j0 + r) * p + j0 + c] = Lt[c * LT + r];
+    }
+    return;
+  }
+
+  // inverse of the 16 x 16 diagonal sub-block `wave`: lane j < 16 solves L_ww x = e_j
+  {
+    const int j = lane & 15, o = 16 * wave;
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const double xi = x[i] * dinv[o + i];
+      x[i] = xi;
+#pragma unroll
+      for (int m = i + 1; m < 16; ++m) x[m] = fma(-Lt[(o + i) * LT + o + m], xi, x[m]);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Iw[wave * 16 * SP + i * SP + j] = x[i];
+    }
+  }
+  __syncthreads();
+
+  // blocked solve, wave w owns rows 16 w .. 16 w + 15; everything below is wave-local
+  const int t16 = lane & 15, q = lane >> 4;
+  double *X = P + wave * 16 * LDP;    // solved blocks, operand layout source [m][64]
+  double *T = Ts + wave * 16 * SP;    // [m][n] scratch
+  const double *A = Ap + wave * 16 * LDP;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < b; ++c)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double av = X[t16 * LDP + 16 * c + 4 * s + q];               // X_c[m][k]
+        const double bv = Lt[(16 * c + 4 * s + q) * LT + 16 * b + t16];    // L[16b+n][16c+k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[(q + 4 * r) * SP + t16] = A[(q + 4 * r) * LDP + 16 * b + t16] - acc[r];
+    d4 xb = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double av = T[t16 * SP + 4 * s + q];                           // T[m][k]
+      const double bv = Iw[b * 16 * SP + t16 * SP + 4 * s + q];            // inv(L_bb)[n][k]
+      xb = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xb, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + q + 4 * r, col = 16 * b + t16;
+      X[(q + 4 * r) * LDP + col] = xb[r];
+      if (row < nrows && col < jb) {
+        if (is_z)
+          z[j0 + col] = xb[r];
+        else
+          H[(size_t)(r0 + row) * p + j0 + col] = xb[r];
+      }
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -281,8 +490,8 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
     ProfScope ps("cholesky");
     for (int j0 = 0; j0 < p; j0 += NB) {
       const int nrowblk = (p - j0 + NB - 1) / NB;  // block 0 = diagonal block
-      hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)(nrowblk + 1)), dim3(64), 0, st, d_H, z, p, j0,
-                         info);
+      hipLaunchKernelGGL(k_chol_panel2, dim3((unsigned)(nrowblk + 1)), dim3(256), 0, st, d_H, z, p,
+                         j0, info);
       const int m = p - (j0 + NB);
       if (m > 0) {
         const int nt = (m + 127) / 128;
