@@ -7,15 +7,15 @@
 // triangle holds L (H = L L^T), the strict upper triangle is scratch.
 //
 // Per 64-column block step j:
-//   k_chol_panel : every workgroup (one wave) re-factorises the 64 x 64
-//                  diagonal block in registers (lane = row, v_readlane
-//                  broadcasts; ~2k dependent FMAs, cheaper than a launch
-//                  boundary), then solves its 64 panel rows against L_jj^T.
-//                  One extra "row" is the right-hand side z, which turns the
-//                  forward substitution L z = rhs into part of the panel solve.
+//   k_chol_panel2: every workgroup re-factorises the 64 x 64 diagonal block itself
+//                  (cheaper than a launch boundary) and solves its 64 panel rows against
+//                  L_jj^T on the matrix cores (details at the kernel).  One extra "row" is
+//                  the right-hand side z, which turns the forward substitution L z = rhs
+//                  into part of the panel solve.  The solved rows also go to a k-major
+//                  scratch copy Wt[k][row] for the update.
 //   k_chol_update: trailing update A22 -= L21 L21^T (lower tiles only) on
-//                  v_mfma_f64_16x16x4_f64, 128 x 128 tiles, K = 64; plus the
-//                  matching update of z.
+//                  v_mfma_f64_16x16x4_f64, 128 x 128 tiles, K = 64, operands straight from
+//                  Wt in 128-byte segments; plus the matching update of z.
 // Backward: k_chol_back per block from the last to the first: theta_j =
 // L_jj^-T z_j, then z[0:j) -= L[j, 0:j)^T theta_j.
 #include <utility>
@@ -35,107 +35,6 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
   lo = __builtin_amdgcn_readlane(lo, l);
   hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
-}
-
-__global__ void __launch_bounds__(64)
-k_chol_panel(double *__restrict__ H, double *__restrict__ z, int p, int j0, int *__restrict__ info) {
-  __shared__ double Ld[NB * LDP];
-  __shared__ double P[NB * LDP];
-  const int lane = threadIdx.x;
-  const int jb = min(NB, p - j0);
-
-  // diagonal block -> LDS (identity padding beyond jb)
-  // (branch-free clamped addresses, 16 row loads in flight per batch: a load /
-  // wait / store per row would cost one L2 round trip per row)
-  {
-    const double *src = H + (size_t)j0 * p + j0 + min(lane, jb - 1);
-#pragma unroll
-    for (int rb = 0; rb < NB; rb += 16) {
-      double t[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t[i] = src[(size_t)min(rb + i, jb - 1) * p];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = rb + i;
-        Ld[r * LDP + lane] = (r < jb && lane < jb) ? t[i] : ((r == lane) ? 1.0 : 0.0);
-      }
-    }
-  }
-  __syncthreads();
-  double a[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) a[k] = Ld[lane * LDP + k];
-
-  // unblocked right-looking Cholesky, lane i owns row i
-  bool bad = false;
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    const double piv = readlane_d(a[c], c);
-    if (!(piv > 0.0)) bad = true;
-    const double dinv = 1.0 / sqrt(piv);
-    const double lc = (lane == c) ? sqrt(piv) : a[c] * dinv;
-    a[c] = lc;
-#pragma unroll
-    for (int k = c + 1; k < NB; ++k) {
-      const double lk = readlane_d(lc, k);
-      a[k] = fma(-lc, lk, a[k]);
-    }
-  }
-  if (bad && blockIdx.x == 0 && lane == 0) atomicMax(info, j0 + 1);
-#pragma unroll
-  for (int k = 0; k < NB; ++k) Ld[lane * LDP + k] = a[k];
-  __syncthreads();
-
-  if (blockIdx.x == 0) {
-    // write L_jj (lower triangle) back
-    for (int r = 0; r < jb; ++r)
-      if (lane <= r) H[(size_t)(j0 + r) * p + j0 + lane] = Ld[r * LDP + lane];
-    return;
-  }
-
-  // panel rows of this workgroup; the last workgroup carries the rhs row z
-  const bool is_z = blockIdx.x == gridDim.x - 1;
-  const int r0 = j0 + NB * (int)blockIdx.x;
-  const int nrows = is_z ? 1 : min(NB, p - r0);
-  {
-    const int lc = min(lane, jb - 1);
-    const double *src = is_z ? z + j0 + lc : H + (size_t)min(r0, p - 1) * p + j0 + lc;
-    const int rmax = is_z ? 0 : min(NB, p - r0) - 1;  // clamp row offsets into the matrix
-#pragma unroll
-    for (int rb = 0; rb < NB; rb += 16) {
-      double t[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t[i] = src[(size_t)min(rb + i, max(rmax, 0)) * p];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = rb + i;
-        P[r * LDP + lane] = (r < nrows && lane < jb) ? t[i] : 0.0;
-      }
-    }
-  }
-  __syncthreads();
-  double x[NB];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) x[c] = P[lane * LDP + c];
-  // x L_jj^T = h  (row-wise forward substitution)
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    double s = x[c];
-#pragma unroll
-    for (int k = 0; k < c; ++k) s = fma(-x[k], Ld[c * LDP + k], s);
-    x[c] = s / Ld[c * LDP + c];
-  }
-#pragma unroll
-  for (int c = 0; c < NB; ++c) P[lane * LDP + c] = x[c];
-  __syncthreads();
-  for (int r = 0; r < nrows; ++r)
-    if (lane < jb) {
-      const double v = P[r * LDP + lane];
-      if (is_z)
-        z[j0 + lane] = v;
-      else
-        H[(size_t)(r0 + r) * p + j0 + lane] = v;
-    }
 }
 
 // ---- panel step ---------------------------------------------------------------------------------
@@ -221,7 +120,8 @@ __device__ __forceinline__ void potrf_cols(std::integer_sequence<int, Cs...>, do
 }
 
 __global__ void __launch_bounds__(256)
-k_chol_panel2(double *__restrict__ H, double *__restrict__ z, int p, int j0, int *__restrict__ info) {
+k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict__ Wt, int pw, int p,
+              int j0, int *__restrict__ info) {
   __shared__ __attribute__((aligned(16))) double Lt[NB * LT];  // Lt[c][k] = L[k][c], 0 for k < c
   __shared__ double P[NB * LDP];    // diagonal block; later X (solved rows), per wave 16 rows
   __shared__ double Ap[NB * LDP];   // panel rows
@@ -343,18 +243,43 @@ k_chol_panel2(double *__restrict__ H, double *__restrict__ z, int p, int j0, int
       }
     }
   }
+  // k-major copy of the solved rows for the trailing update: Wt[k][row], 128-byte segments
+  if (!is_z) {
+    const int m = lane & 15, kq = lane >> 4;
+    if (wave * 16 + m < nrows) {
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = 4 * kk + kq;
+        Wt[(size_t)k * pw + r0 + wave * 16 + m] = X[m * LDP + k];
+      }
+    }
+  }
 }
 
+// Trailing update of one 128 x 128 lower tile: D = H - L21_i L21_j^T.  Latency-shaped: the
+// panel was written by the previous kernel (other XCDs' L2s), so every dependent global
+// access is a trip to Infinity Cache / HBM.  Everything the block needs is therefore
+// requested up front -- both 128 x 64 operand panels (16-byte pieces of the k-major copy,
+// staged in LDS) and the H tile itself, straight into the accumulators -- so the block pays
+// one memory round trip, 256 MFMAs per wave from LDS, and a store.
+constexpr int UP = 128 + 16;  // LDS pitch of a staged panel row (doubles)
+
 __global__ void __launch_bounds__(256)
-k_chol_update(double *__restrict__ H, double *__restrict__ z, int p, int j0, int nt, int npairs) {
+k_chol_update(double *__restrict__ H, double *__restrict__ z, const double *__restrict__ Wt, int pw,
+              int p, int j0, int nt, int npairs) {
+  __shared__ __attribute__((aligned(16))) double Sa[NB * UP];
+  __shared__ __attribute__((aligned(16))) double Sb[NB * UP];
   const int t0 = j0 + NB;
   if ((int)blockIdx.x >= npairs) {
-    // z[c] -= sum_k z[j0 + k] * L[c][j0 + k]
+    // z[c] -= sum_k z[j0 + k] * L[c][j0 + k], all 64 loads in flight at once
     const int c = t0 + ((int)blockIdx.x - npairs) * 256 + (int)threadIdx.x;
     if (c < p) {
+      double w[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) w[k] = Wt[(size_t)k * pw + c];
       double s = z[c];
-      const double *lrow = H + (size_t)c * p + j0;
-      for (int k = 0; k < NB; ++k) s = fma(-z[j0 + k], lrow[k], s);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) s = fma(-z[j0 + k], w[k], s);
       z[c] = s;
     }
     return;
@@ -366,29 +291,52 @@ k_chol_update(double *__restrict__ H, double *__restrict__ z, int p, int j0, int
     ++bi;
   }
   const int bj = rem;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  if (bi == bj && wn > wm) return;  // strictly upper 64 x 64 quadrant
+  const bool active = !(bi == bj && wn > wm);  // strictly upper 64 x 64 quadrant: no work
   const int t16 = lane & 15, q = lane >> 4;
   const int rbase = t0 + bi * 128 + wm * 64, cbase = t0 + bj * 128 + wn * 64;
-  const double *pa[4], *pb[4];
+
+  // panels: 64 k x 128 rows each = 4096 16-byte pieces per panel, 16 per thread
+  d2v ga[16], gb[16];
+  {
+    const double *srca = Wt + t0 + bi * 128, *srcb = Wt + t0 + bj * 128;
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    pa[f] = H + (size_t)min(p - 1, rbase + f * 16 + t16) * p + j0 + q;
-    pb[f] = H + (size_t)min(p - 1, cbase + f * 16 + t16) * p + j0 + q;
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u, k = e >> 6, c2 = e & 63;
+      ga[u] = *(const d2v *)(srca + (size_t)k * pw + 2 * c2);
+      gb[u] = *(const d2v *)(srcb + (size_t)k * pw + 2 * c2);
+    }
   }
+  // H tile into the accumulators (rows / columns beyond p or above the diagonal: zero)
   d4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rbase + i * 16 + q + 4 * r, col = cbase + j * 16 + t16;
+        acc[i][j][r] = (active && row < p && col <= row) ? H[(size_t)row * p + col] : 0.0;
+      }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = tid + 256 * u, k = e >> 6, c2 = e & 63;
+    *(d2v *)&Sa[k * UP + 2 * c2] = ga[u];
+    *(d2v *)&Sb[k * UP + 2 * c2] = gb[u];
+  }
+  __syncthreads();
+  if (!active) return;
+  const double *pa = Sa + q * UP + wm * 64 + t16;
+  const double *pb = Sb + q * UP + wn * 64 + t16;
 #pragma unroll 4
   for (int s = 0; s < 16; ++s) {
     double a[4], b[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      a[f] = pa[f][4 * s];
-      b[f] = pb[f][4 * s];
+      a[f] = -pa[4 * s * UP + 16 * f];
+      b[f] = pb[4 * s * UP + 16 * f];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -404,7 +352,7 @@ k_chol_update(double *__restrict__ H, double *__restrict__ z, int p, int j0, int
       for (int r = 0; r < 4; ++r) {
         const int row = rbase + i * 16 + q + 4 * r;
         const int col = cbase + j * 16 + t16;
-        if (row < p && col < p && col <= row) H[(size_t)row * p + col] -= acc[i][j][r];
+        if (row < p && col <= row) H[(size_t)row * p + col] = acc[i][j][r];
       }
 }
 
@@ -465,7 +413,9 @@ __global__ void k_form_hessian(double *__restrict__ G, const double *__restrict_
 
 }  // namespace
 
-uint64_t newton_workspace_bytes(uint64_t p) { return (p + 64) * sizeof(double); }
+// z (p), info (64 doubles reserved), k-major panel copy Wt (64 rows of chol_pitch(p) doubles)
+static uint64_t chol_pitch(uint64_t p) { return (p + 127) / 128 * 128 + 128; }
+uint64_t newton_workspace_bytes(uint64_t p) { return (p + 64 + NB * chol_pitch(p)) * sizeof(double); }
 
 int launch_form_hessian(uint64_t p, double *d_G, const double *d_prec, double e2, double *d_diagH) {
   ProfScope ps("form_hessian");
@@ -483,22 +433,25 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
   const int p = (int)p64;
   double *z = (double *)d_ws;
   int *info = (int *)(z + p);
+  double *Wt = z + p + 64;
+  const int pw = (int)chol_pitch(p64);
   hipStream_t st = cur_stream();
+  OB_HIP(hipMemsetAsync(Wt, 0, sizeof(double) * NB * pw, st));  // rows beyond p stay zero
   OB_HIP(hipMemcpyAsync(z, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, st));
   OB_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
   {
     ProfScope ps("cholesky");
     for (int j0 = 0; j0 < p; j0 += NB) {
       const int nrowblk = (p - j0 + NB - 1) / NB;  // block 0 = diagonal block
-      hipLaunchKernelGGL(k_chol_panel2, dim3((unsigned)(nrowblk + 1)), dim3(256), 0, st, d_H, z, p,
-                         j0, info);
+      hipLaunchKernelGGL(k_chol_panel2, dim3((unsigned)(nrowblk + 1)), dim3(256), 0, st, d_H, z, Wt,
+                         pw, p, j0, info);
       const int m = p - (j0 + NB);
       if (m > 0) {
         const int nt = (m + 127) / 128;
         const int npairs = nt * (nt + 1) / 2;
         const int nz = (m + 255) / 256;
-        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(npairs + nz)), dim3(256), 0, st, d_H, z, p,
-                           j0, nt, npairs);
+        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(npairs + nz)), dim3(256), 0, st, d_H, z, Wt,
+                           pw, p, j0, nt, npairs);
       }
     }
     OB_HIP(hipGetLastError());
