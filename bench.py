@@ -238,6 +238,22 @@ def main():
                               ms_per_step=ms.value / nprof)
     _lib.call("obhip_profile_enable", 0)
 
+    # fit-only and predict-only wall times, outside the timed region
+    split = {}
+    for name, fn in (("fit", hp.fit), ("predict", hp.predict)):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            fn()
+        sync()
+        dt = (time.perf_counter() - t0) / 2
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        split[name + "_ms"] = dt * 1e3
+        split[name + "_only_points_per_s"] = float(n_rows_all(hp)) / dt
+
     # parity of this very run against the oracle on a row sample (cheap, untimed)
     check = check_against_oracle(hp) if rank == 0 else None
 
@@ -293,6 +309,7 @@ def main():
             "terms_nnz": hp.terms_info["nnz_total"], "basis_columns": hp.ncols,
             "parallelism": "rows sharded over %d rank(s); all-reduce of G and g" % world,
         },
+        "fit_predict_split": split,
         "kernels_ms": prof,
         "parity_check": check,
         "alt_backend": alt,

@@ -105,6 +105,22 @@ int obhip_model_get_rotation(const obhip_model *m, double *rotmat,
  * parity tests inject the oracle's so that both sides share one rotation). */
 int obhip_model_set_rotation(obhip_model *m, const double *rotmat,
                              const double *basisvar, const int64_t *maxlevel);
+/* Hyper-parameter gradient layout (outermod::hyp_set, modandbase.cpp:183-197): nhyp
+ * hyper-parameters in all; hyper-parameter h belongs to dimension hypmatch[h] and owns
+ * the column block [gest[h], gest[h+1]) (m_l columns) of the *_gradhyp arrays.
+ * hypmatch: nhyp entries, gest: nhyp + 1; any pointer may be NULL. */
+int obhip_model_grad_layout(const obhip_model *m, uint64_t *nhyp, uint64_t *hypmatch,
+                            uint64_t *gest);
+/* gradient part of outermod::build (modandbase.cpp:257-274): rotmat_gradhyp is
+ * mmax x gest[nhyp] column-major (modandbase.h:45), logbasisvar_gradhyp gest[nhyp] */
+int obhip_model_get_rotation_grad(const obhip_model *m, double *rotmat_gradhyp,
+                                  double *logbasisvar_gradhyp);
+/* counterpart of obhip_model_set_rotation for the gradient arrays */
+int obhip_model_set_rotation_grad(obhip_model *m, const double *rotmat_gradhyp,
+                                  const double *logbasisvar_gradhyp);
+/* om$getlvar_gradhyp(terms): modandbase.cpp:364-379; out p x nhyp column-major */
+int obhip_model_term_lvar_gradhyp(const obhip_model *m, const uint64_t *terms, uint64_t p,
+                                  double *out);
 /* om$selectterms(numele): modandbase.cpp:387-440.  seed==0: the reference's
  * RNG shuffle (modandbase.cpp:408) is replaced by the identity permutation;
  * seed!=0: SplitMix64-driven pick among the near-best candidates.
@@ -176,6 +192,23 @@ int obhip_basis_mm_dev(const obhip_basis *b, const obhip_terms *t,
                        const double *d_a, double *d_out, int squared);
 int obhip_basis_tmm_dev(const obhip_basis *b, const obhip_terms *t,
                         const double *d_a, double *d_out, int squared);
+
+/* ---- hyper-parameter gradients ------------------------- */
+/* The gradient basis (outerbase::build with dograd, modandbase.cpp:547-626) is built on
+ * the first call and kept until the basis is rebuilt.  nhyp and the block layout come
+ * from obhip_model_grad_layout.  The basis must have been built after the last change of
+ * the model (OBHIP_ERR_STATE otherwise).
+ * ob$getmat_gradhyp(terms): modandbase.cpp:663-669 (getmge_, linalg.cpp:778-822);
+ * out: n x p x nhyp, column-major slices. */
+int obhip_basis_getmat_gradhyp(const obhip_basis *b, const obhip_terms *t, double *out);
+/* ob$matmul_gradhyp(terms, a): modandbase.cpp:725-744 (prodmmge_, linalg.cpp:219-276);
+ * out (n, may be NULL) = B a, out_gradhyp n x nhyp column-major. */
+int obhip_basis_mm_gradhyp(const obhip_basis *b, const obhip_terms *t, const double *a,
+                           double *out, double *out_gradhyp);
+/* ob$tmatmul_gradhyp(terms, a): modandbase.cpp:755-776 (tprodmmge_, linalg.cpp:395-471);
+ * out (p, may be NULL) = B^T a, out_gradhyp p x nhyp column-major. */
+int obhip_basis_tmm_gradhyp(const obhip_basis *b, const obhip_terms *t, const double *a,
+                            double *out, double *out_gradhyp);
 
 /* ---- Gram / Newton ("back end A") -------------------------------------- */
 /* G = B^T B (loglik_std::hess without its e^{-2 sigma}, loglik_std.cpp:

@@ -96,7 +96,7 @@ def cov_gradhyp(kind, x1, x2, hyp):
     """covf_*::cov_gradhyp -- n x m x numhyp cube.
 
     covfuncs.cpp:134-150 (mat25), :220-243 (mat25pow), :318-347 (mat25ang).
-    Used here only for the finite-difference identity of test-covf.R.
+    Checked against finite differences as tests/testthat/test-covf.R does.
     """
     x1 = np.asarray(x1, dtype=np.float64)
     x2 = np.asarray(x2, dtype=np.float64)
@@ -230,6 +230,24 @@ class OuterMod:
         self.rotmat = np.zeros((mmax, M))
         self.basisvar = np.zeros(M)
         self.maxlevel = np.zeros(d, dtype=np.int64)
+        # gradient bookkeeping, hyp_set modandbase.cpp:183-197: per dimension one block
+        # of m_l columns per hyper-parameter; gest[h] = first column of hyper-parameter
+        # h, hypmatch[h] = its dimension
+        nh = int(self.hypst[d])
+        self.hypmatch = np.zeros(nh, dtype=np.int64)
+        self.gest = np.zeros(nh + 1, dtype=np.int64)
+        self.knotptstge = np.zeros(d + 1, dtype=np.int64)
+        cur = 0
+        for l in range(d):
+            self.knotptstge[l] = cur
+            for h in range(self.hypst[l], self.hypst[l + 1]):
+                self.hypmatch[h] = l
+                self.gest[h] = cur
+                cur += self.knotptst[l + 1] - self.knotptst[l]
+        self.knotptstge[d] = cur
+        self.gest[nh] = cur
+        self.rotmat_gradhyp = np.zeros((mmax, cur))
+        self.logbasisvar_gradhyp = np.zeros(cur)
         for k in range(d):
             xsh = self.knots_of(k)
             lenh = len(xsh)
@@ -247,6 +265,20 @@ class OuterMod:
             self.rotmat[:lenh, o:o + lenh] = \
                 U / (sr / math.sqrt(lenh))[None, :]                 # :252-254
             self.basisvar[o:o + lenh] = np.log(sr / lenh)           # :255
+            # gradient matrices, :257-274 (sr and U are the jittered / sign-fixed ones)
+            Rge = cov_gradhyp(self.kinds[k], xsh, xsh, self.hyp_of(k))  # :258
+            Fm = np.tile(sr[None, :], (lenh, 1))                    # :260
+            np.fill_diagonal(Fm, 0.0)                               # :261
+            Fm = Fm - sr[:, None]                                   # :262
+            Fm = 1.0 / Fm                                           # :263
+            og = self.knotptstge[k]
+            for l in range(self.hypst[k + 1] - self.hypst[k]):
+                UtdRV = U.T @ Rge[:, :, l] @ U                      # :267
+                self.logbasisvar_gradhyp[og + l * lenh:og + (l + 1) * lenh] = \
+                    np.diag(UtdRV) / sr                             # :268-269
+                Ah = U @ (UtdRV * Fm)                               # :270
+                Ah = Ah / (sr / math.sqrt(lenh))[None, :]           # :271
+                self.rotmat_gradhyp[:lenh, og + l * lenh:og + (l + 1) * lenh] = Ah
 
     # modandbase.cpp:285-298 (buildob, value form)
     def buildob(self, xcol, k):
@@ -256,6 +288,32 @@ class OuterMod:
         R = R @ self.rotmat[:lenh, o:o + lenh]
         R[:, 1:] = R[:, 1:] / R[:, 0:1]
         return R
+
+    # modandbase.cpp:306-327 (buildob, gradient form): R as above and Rt[:, :, h] =
+    # (d cov/d hyp_h . rotmat + cov . rotmat_gradhyp_h) / R[:, 0] for EVERY column
+    # (column 0 included; it is not the derivative of the normalised ratio)
+    def buildob_grad(self, xcol, k):
+        lenh = self.knotptst[k + 1] - self.knotptst[k]
+        o = self.knotptst[k]
+        rot = self.rotmat[:lenh, o:o + lenh]
+        R = cov(self.kinds[k], xcol, self.knots_of(k), self.hyp_of(k))      # :310
+        Rt = cov_gradhyp(self.kinds[k], xcol, self.knots_of(k), self.hyp_of(k))  # :312
+        for h in range(self.hypst[k], self.hypst[k + 1]):
+            j = h - self.hypst[k]
+            Rt[:, :, j] = Rt[:, :, j] @ rot + \
+                R @ self.rotmat_gradhyp[:lenh, self.gest[h]:self.gest[h + 1]]  # :316-319
+        R = R @ rot                                                           # :321
+        Rt = Rt / R[:, 0:1, None]                                             # :324-325
+        R[:, 1:] = R[:, 1:] / R[:, 0:1]                                       # :326
+        return R, Rt
+
+    # modandbase.cpp:364-379 (getlvar_gradhyp)
+    def getlvar_gradhyp(self, terms):
+        terms = np.asarray(terms, dtype=np.int64)
+        out = np.zeros((terms.shape[0], len(self.hypmatch)))
+        for h in range(len(self.hypmatch)):
+            out[:, h] = self.logbasisvar_gradhyp[self.gest[h] + terms[:, self.hypmatch[h]]]
+        return out
 
     # modandbase.cpp:336-342 (totvar)
     def totvar(self, x):
@@ -327,9 +385,10 @@ class OuterBase:
     """Restatement of class outerbase (src/modandbase.h:57-125), value
     (non-gradient) parts."""
 
-    def __init__(self, om, x):
+    def __init__(self, om, x, dograd=False):
         self.om = om
         self.xp = np.array(x, dtype=np.float64, order="F")
+        self.dograd = dograd
         self.build()
 
     # modandbase.cpp:547-626 (build); the tall/short OpenMP branches compute
@@ -341,8 +400,16 @@ class OuterBase:
         self.basemat = np.zeros((n, M), order="F")
         self.basescalemat = np.zeros((n, om.d), order="F")
         self.basescale = np.ones(n)
+        if self.dograd:
+            self.basemat_gradhyp = np.zeros((n, om.knotptstge[om.d]), order="F")
         for k in range(om.d):
-            R = om.buildob(self.xp[:, k], k)
+            if self.dograd:
+                R, Rt = om.buildob_grad(self.xp[:, k], k)           # :568
+                for h in range(om.hypst[k], om.hypst[k + 1]):
+                    self.basemat_gradhyp[:, om.gest[h]:om.gest[h + 1]] = \
+                        Rt[:, :, h - om.hypst[k]]                   # :585-587
+            else:
+                R = om.buildob(self.xp[:, k], k)
             self.basescalemat[:, k] = R[:, 0]                       # :572
             self.basescale *= R[:, 0]                               # :573
             R[:, 0] = 1.0                                           # :574
@@ -409,6 +476,87 @@ def tprodmm(terms, a, basemat, basescale, knotptst):
     for k in range(terms.shape[0]):
         out[k] = _colprod(terms, knotptst, basemat, k) @ b
     return out
+
+
+def _colprod_ge(terms, knotptst, basemat, basematge, gest, hypmatch, k, h):
+    """One term's column of dB/d hyp_h without basescale: the product of
+    _colprod with dimension hypmatch[h]'s factor replaced by the gradient column
+    gest[h] + level -- level 0 included (dotmultgesub_, linalg.cpp:375-384; in
+    domultgesub_ :150-161 the level-0 case is spread over `- temp % ge[0]` per term and
+    `+ ge[0] % out` at the end, prodmmge_ :271-272, which sums to the same)."""
+    lm = hypmatch[h]
+    temp = np.ones(basemat.shape[0])
+    for m in range(terms.shape[1]):
+        t = terms[k, m]
+        if t > 0 and m != lm:
+            temp = temp * basemat[:, knotptst[m] + t]
+    return temp * basematge[:, gest[h] + terms[k, lm]]
+
+
+def getmge(terms, basemat, basescale, knotptst, basematge, gest, hypmatch):
+    """getmge_ (linalg.cpp:778-822, the non-chunked branch :812-817; its chunked
+    branch :788-810 assigns a zero buffer and cannot be what is meant): the cube
+    dB/d hyp, n x p x nhyp."""
+    terms = np.asarray(terms, dtype=np.int64)
+    nh = len(hypmatch)
+    out = np.empty((basemat.shape[0], terms.shape[0], nh))
+    for h in range(nh):
+        for k in range(terms.shape[0]):
+            out[:, k, h] = _colprod_ge(terms, knotptst, basemat, basematge, gest, hypmatch, k, h)
+    return out * basescale[:, None, None]
+
+
+def prodmmge(terms, a, basemat, basescale, knotptst, basematge, gest, hypmatch):
+    """prodmmge_ (linalg.cpp:219-276): B.a and its gradient, n x nhyp."""
+    terms = np.asarray(terms, dtype=np.int64)
+    a = np.asarray(a, dtype=np.float64)
+    nh = len(hypmatch)
+    out = np.zeros(basemat.shape[0])
+    outge = np.zeros((basemat.shape[0], nh))
+    for k in range(terms.shape[0]):
+        temp = a[k] * _colprod(terms, knotptst, basemat, k)          # :148-152
+        out += temp                                                  # :153
+        for h in range(nh):                                          # :154-163
+            if terms[k, hypmatch[h]] > 0:
+                tempalt = a[k] * _colprod_ge(terms, knotptst, basemat, basematge, gest,
+                                             hypmatch, k, h)
+                outge[:, h] += tempalt - temp * basematge[:, gest[h]]
+    for h in range(nh):
+        outge[:, h] += basematge[:, gest[h]] * out                   # :271-272
+    return out * basescale, outge * basescale[:, None]               # :273-274
+
+
+def tprodmmge(terms, a, basemat, basescale, knotptst, basematge, gest, hypmatch):
+    """tprodmmge_ (linalg.cpp:395-471): B^T.a and its gradient, p x nhyp."""
+    terms = np.asarray(terms, dtype=np.int64)
+    b = basescale * np.asarray(a, dtype=np.float64)                  # :410
+    nh = len(hypmatch)
+    out = np.zeros(terms.shape[0])
+    outge = np.zeros((terms.shape[0], nh))
+    for k in range(terms.shape[0]):
+        out[k] = np.sum(b * _colprod(terms, knotptst, basemat, k))   # :371-375
+        for h in range(nh):                                          # :377-385
+            outge[k, h] = np.dot(b, _colprod_ge(terms, knotptst, basemat, basematge, gest,
+                                                hypmatch, k, h))
+    return out, outge
+
+
+def ob_getmat_gradhyp(ob, terms):          # modandbase.cpp:663-669
+    om = ob.om
+    return getmge(terms, ob.basemat, ob.basescale, om.knotptst, ob.basemat_gradhyp,
+                  om.gest, om.hypmatch)
+
+
+def ob_mm_gradhyp(ob, terms, a):           # modandbase.cpp:725-744
+    om = ob.om
+    return prodmmge(terms, a, ob.basemat, ob.basescale, om.knotptst, ob.basemat_gradhyp,
+                    om.gest, om.hypmatch)
+
+
+def ob_tmm_gradhyp(ob, terms, a):          # modandbase.cpp:755-776
+    om = ob.om
+    return tprodmmge(terms, a, ob.basemat, ob.basescale, om.knotptst, ob.basemat_gradhyp,
+                     om.gest, om.hypmatch)
 
 
 def ob_getmat(ob, terms):      # modandbase.cpp:649-654

@@ -48,6 +48,7 @@ int basis_setup(obhip_basis *b, const obhip_model *m, const int64_t *levelcap) {
   std::vector<int64_t> cap;
   if (levelcap) cap.assign(levelcap, levelcap + m->d);
   OB_TRY(b->md.build(*m, cap));
+  b->grad.reset();  // the gradient basis follows the value basis
   const uint64_t tiles = b->n_pad / kTileRows;
   OB_TRY(b->bm.alloc(tiles * b->md.Mc * kTileRows));
   OB_TRY(b->scale.alloc(b->n_pad));

@@ -1,0 +1,340 @@
+// Hyper-parameter gradients of the outer-product basis for gfx950:
+//   basemat_gradhyp        outermod::buildob, gradient form   src/modandbase.cpp:306-327
+//                          outerbase::build with dograd       src/modandbase.cpp:547-626
+//   getmat_gradhyp         getmge_                            src/linalg.cpp:778-822
+//   matmul_gradhyp         prodmmge_ / domultgesub_           src/linalg.cpp:139-276
+//   tmatmul_gradhyp        tprodmmge_ / dotmultgesub_         src/linalg.cpp:362-471
+//
+// For hyper-parameter h of dimension l = hypmatch[h] the reference stores, per row,
+//   basemat_gradhyp[:, gest[h] + t] = (d cov/d hyp_h . rotmat_l + cov . rotmat_gradhyp_h)[:, t] / c_l
+// for EVERY level t (0 included), and its products amount to
+//   d B[i,k] / d hyp_h = basescale_i . prod_{m != l} basemat[i, col(m, t_km)] . basemat_gradhyp[i, gest[h] + t_kl]
+// i.e. the ordinary term product with dimension l's factor (the constant 1 at level 0)
+// replaced by the gradient column.  So this file builds ONE combined tile-blocked array
+// (basemat columns, then per hyper-parameter the gradient columns of levels 0..cap) and
+// per hyper-parameter a *view* of the terms in which dimension l is dropped and a pseudo-
+// dimension pointing at the gradient block carries level t_kl + 1; the value kernels
+// k_mm / k_tmm (kernels_prod.hip) then compute the gradient products unchanged, one pass
+// per hyper-parameter.
+#include "obhip_internal.h"
+#include "device_common.h"
+
+namespace obhip {
+
+namespace {
+
+// kernel value and its hyper-parameter derivatives at one knot (covfuncs.cpp:134-150,
+// 220-243, 318-347); a0, a1 as in kernel_pre, lx = log(x) (mat25pow only)
+template <int KIND>
+__device__ __forceinline__ void kernel_value_grad(const DimDesc &D, double ka, double kb, double kd,
+                                                  double a0, double a1, double lx, double &kv,
+                                                  double &g0, double &g1) {
+  constexpr double a = 2.0, b = 0.25;
+  if (KIND == OBHIP_COV_MAT25ANG) {
+    const double hs = a0 - ka, hc = a1 - kb;
+    const double h = sqrt(hs * hs + hc * hc);
+    const double e = exp(-h), w = e * (h + 1.0);
+    kv = (1.0 + h + h * h * (1.0 / 3.0)) * e;
+    g0 = a / 3 * hs * hs * w;
+    g1 = a / 3 * hc * hc * w;
+  } else {
+    const double h = a0 - ka, ah = fabs(h);
+    const double e = exp(-ah);
+    kv = (1.0 + ah + ah * ah * (1.0 / 3.0)) * e;
+    const double h2 = h * (1.0 + ah) * e;
+    g0 = a / 3 * (h * h2);
+    g1 = 0.0;
+    if (KIND == OBHIP_COV_MAT25POW)
+      g1 = (lx * a0 - kd) * (-(b * D.p0 / 3) * h2) + b / 3 * (h * h2);  // D.p0 = powv
+  }
+}
+
+// one dimension, one row: R = cov . rot, Rt_h = dcov_h . rot + cov . rotg_h, everything
+// divided by R[0]; basemat columns and gradient columns go to the combined tile
+template <int KIND>
+__device__ __forceinline__ double build_dim_grad(const DimDesc &D, const GradHyp *__restrict__ hy,
+                                                 int nh, const double *__restrict__ ka,
+                                                 const double *__restrict__ kb,
+                                                 const double *__restrict__ kd,
+                                                 const double *__restrict__ rot,
+                                                 const double *__restrict__ rotg, double xv,
+                                                 double *__restrict__ tile_out) {
+  double a0, a1, a2;
+  kernel_pre<KIND>(D, xv, a0, a1, a2);
+  const double lx = KIND == OBHIP_COV_MAT25POW ? log(xv) : 0.0;
+  double cl = 1.0;
+  for (int c0 = 0; c0 < D.ncolp; c0 += 8) {
+    double r[8], t0[8], t1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = t0[c] = t1[c] = 0.0;
+    const double *rp = rot + D.rotoff + c0;
+    const double *g0p = rotg + hy[0].rotgoff + c0;
+    const double *g1p = rotg + hy[nh - 1].rotgoff + c0;
+    for (int j = 0; j < D.m; ++j) {
+      double kv, d0, d1;
+      kernel_value_grad<KIND>(D, ka[D.koff + j], kb[D.koff + j], kd[D.koff + j], a0, a1, lx, kv, d0,
+                              d1);
+      const size_t o = (size_t)j * D.ncolp;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const double rc = rp[o + c];
+        r[c] = fma(kv, rc, r[c]);
+        t0[c] = fma(d0, rc, fma(kv, g0p[o + c], t0[c]));
+        if (KIND != OBHIP_COV_MAT25) t1[c] = fma(d1, rc, fma(kv, g1p[o + c], t1[c]));
+      }
+    }
+    if (c0 == 0) cl = r[0];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int col = c0 + c;
+      if (col < D.ncol) {
+        if (col >= 1) tile_out[(size_t)(D.ccol0 + col - 1) * kTileRows] = r[c] / cl;
+        tile_out[(size_t)(hy[0].gecol + col) * kTileRows] = t0[c] / cl;
+        if (KIND != OBHIP_COV_MAT25) tile_out[(size_t)(hy[1].gecol + col) * kTileRows] = t1[c] / cl;
+      }
+    }
+  }
+  return cl;
+}
+
+__global__ void __launch_bounds__(256)
+k_build_basis_grad(const DimDesc *__restrict__ dims, const GradHyp *__restrict__ hyps,
+                   const int *__restrict__ hypst, const double *__restrict__ ka,
+                   const double *__restrict__ kb, const double *__restrict__ kd,
+                   const double *__restrict__ rot, const double *__restrict__ rotg,
+                   const double *__restrict__ x, uint64_t n, int d, uint64_t Mtot,
+                   double *__restrict__ bm, double *__restrict__ scale) {
+  __shared__ double part[4][kTileRows];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t tile = blockIdx.x;
+  const uint64_t row = tile * kTileRows + lane;
+  const bool valid = row < n;
+  double *tile_out = bm + tile * Mtot * kTileRows + lane;
+  double sc = 1.0;
+  for (int l = wave; l < d; l += 4) {
+    const DimDesc D = dims[l];
+    const GradHyp *hy = hyps + hypst[l];
+    const int nh = hypst[l + 1] - hypst[l];
+    const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
+    double cl;
+    if (D.kind == OBHIP_COV_MAT25)
+      cl = build_dim_grad<OBHIP_COV_MAT25>(D, hy, nh, ka, kb, kd, rot, rotg, xv, tile_out);
+    else if (D.kind == OBHIP_COV_MAT25POW)
+      cl = build_dim_grad<OBHIP_COV_MAT25POW>(D, hy, nh, ka, kb, kd, rot, rotg, xv, tile_out);
+    else
+      cl = build_dim_grad<OBHIP_COV_MAT25ANG>(D, hy, nh, ka, kb, kd, rot, rotg, xv, tile_out);
+    sc *= cl;
+  }
+  part[wave][lane] = sc;
+  if (wave == 0) tile_out[0] = 1.0;
+  __syncthreads();
+  if (wave == 0) {
+    const double s = part[0][lane] * part[1][lane] * part[2][lane] * part[3][lane];
+    scale[row] = valid ? s : 0.0;
+  }
+}
+
+}  // namespace
+
+// (Re)build the gradient basis of b for the current model state.
+int ensure_gradbasis(obhip_basis &b) {
+  const obhip_model &m = *b.model;
+  // like the reference's outerbase, b does not follow later changes of the model
+  // (vignettes/learning.Rmd:48-54); mixing its tables with newer gradient tables would be
+  // silently wrong, so ask for the rebuild instead
+  if (b.md.model_version != m.version)
+    return fail(OBHIP_ERR_STATE, "the model changed after this basis was built: call build() first");
+  if (b.grad && b.grad->model_version == m.version) return 0;
+  auto g = std::make_unique<obhip_gradbasis>();
+  const uint64_t d = m.d, nh = m.nhyp();
+  // tables: per hyper-parameter the rotmat_gradhyp block capped like ModelDev::rot
+  std::vector<double> hrotg, hkd(m.M(), 0.0);
+  std::vector<int> hhypst(d + 1);
+  g->hyps_h.resize(nh);
+  uint64_t gecol = b.md.Mc;
+  for (uint64_t l = 0; l < d; ++l) {
+    const DimDesc &D = b.md.dims_h[l];
+    const uint64_t ml = m.m_of(l), o = m.knotptst[l];
+    hhypst[l] = (int)m.hypst[l];
+    for (uint64_t h = m.hypst[l]; h < m.hypst[l + 1]; ++h) {
+      GradHyp &G = g->hyps_h[h];
+      G.dim = (int)l;
+      G.which = (int)(h - m.hypst[l]);
+      G.rotgoff = (int)hrotg.size();
+      G.gecol = (int)gecol;
+      gecol += (uint64_t)D.ncol;
+      hrotg.resize(hrotg.size() + ml * D.ncolp, 0.0);
+      for (uint64_t j = 0; j < ml; ++j)
+        for (int cc = 0; cc < D.ncol; ++cc)
+          hrotg[G.rotgoff + j * D.ncolp + cc] = m.rotmat_gradhyp[(m.gest[h] + cc) * m.mmax + j];
+    }
+    if (D.kind == OBHIP_COV_MAT25POW)
+      for (uint64_t j = 0; j < ml; ++j) {
+        const double t = std::pow(m.knotpt[o + j], D.p0) / D.p1;
+        hkd[o + j] = std::log(m.knotpt[o + j]) * t;  // covfuncs.cpp:234
+      }
+  }
+  hhypst[d] = (int)m.hypst[d];
+  OB_TRY(g->hyps.upload(g->hyps_h.data(), nh));
+  OB_TRY(g->rotg.upload(hrotg.data(), hrotg.size()));
+  OB_TRY(g->kd.upload(hkd.data(), hkd.size()));
+  DevBuf<int> dhypst;
+  OB_TRY(dhypst.upload(hhypst.data(), hhypst.size()));
+
+  // the combined array as an obhip_basis whose dimension table is extended by one
+  // pseudo-dimension per hyper-parameter: its level j >= 1 is gradient level j - 1
+  g->gb = std::make_unique<obhip_basis>();
+  obhip_basis &gb = *g->gb;
+  gb.model = b.model;
+  gb.n = b.n;
+  gb.n_pad = b.n_pad;
+  gb.d = d + nh;
+  gb.device = b.device;
+  gb.md.cap = b.md.cap;
+  gb.md.dims_h = b.md.dims_h;
+  for (uint64_t h = 0; h < nh; ++h) {
+    const DimDesc &D = b.md.dims_h[m.hypmatch[h]];
+    DimDesc P = D;
+    P.ccol0 = g->hyps_h[h].gecol;  // level j -> column gecol + j - 1
+    P.ncol = D.ncol + 1;
+    gb.md.cap.push_back((int64_t)D.ncol);
+    gb.md.dims_h.push_back(P);
+  }
+  gb.md.Mc = gecol;
+  gb.md.model_version = m.version;
+  const uint64_t tiles = b.n_pad / kTileRows;
+  OB_TRY(gb.bm.alloc(tiles * gecol * kTileRows));
+  OB_TRY(gb.scale.alloc(b.n_pad));
+  {
+    ProfScope ps("build_basis_grad");
+    hipLaunchKernelGGL(k_build_basis_grad, dim3((unsigned)tiles), dim3(256), 0, cur_stream(),
+                       b.md.dims.p, g->hyps.p, dhypst.p, b.md.ka.p, b.md.kb.p, g->kd.p, b.md.rot.p,
+                       g->rotg.p, b.x.p, b.n, (int)d, gecol, gb.bm.p, gb.scale.p);
+    OB_HIP(hipGetLastError());
+    OB_HIP(hipStreamSynchronize(cur_stream()));  // dhypst is a local
+  }
+  g->model_version = m.version;
+  b.grad = std::move(g);
+  return 0;
+}
+
+// View of the terms for hyper-parameter h: dimension hypmatch[h] dropped, pseudo-dimension
+// d + h at level t + 1 (so even level 0 picks up its gradient column).
+obhip_terms *grad_view(obhip_terms &t, const obhip_basis &b, uint64_t h) {
+  const obhip_model &m = *b.model;
+  const uint64_t nh = m.nhyp(), d = t.d, de = d + nh;
+  if (t.ge_views.size() != nh) {
+    t.ge_views.clear();
+    t.ge_views.resize(nh);
+  }
+  if (!t.ge_views[h]) {
+    auto v = std::make_unique<obhip_terms>();
+    v->p = t.p;
+    v->d = de;
+    v->lev.assign(t.p * de, 0);
+    v->maxlev.assign(de, 0);
+    const uint64_t l = m.hypmatch[h];
+    for (uint64_t k = 0; k < t.p; ++k) {
+      uint64_t nnz = 0;
+      for (uint64_t q = 0; q < d; ++q) {
+        const uint32_t lv = q == l ? 0u : t.lev[k * d + q];
+        v->lev[k * de + q] = lv;
+        v->maxlev[q] = std::max<int64_t>(v->maxlev[q], lv);
+        nnz += lv > 0;
+      }
+      const uint32_t gl = t.lev[k * d + l] + 1;
+      v->lev[k * de + d + h] = gl;
+      v->maxlev[d + h] = std::max<int64_t>(v->maxlev[d + h], gl);
+      ++nnz;
+      v->nnz_total += nnz;
+      v->max_nnz = std::max(v->max_nnz, nnz);
+    }
+    t.ge_views[h] = std::move(v);
+  }
+  return t.ge_views[h].get();
+}
+
+}  // namespace obhip
+
+using namespace obhip;
+
+namespace {
+
+int d2h(void *dst, const void *src, size_t bytes) {
+  OB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cur_stream()));
+  OB_HIP(hipStreamSynchronize(cur_stream()));
+  return 0;
+}
+
+int check_grad_args(const obhip_basis *b, const obhip_terms *t) {
+  if (!b || !t) return fail(OBHIP_ERR_INVALID, "gradhyp: null argument");
+  if (t->d != b->model->d) return fail(OBHIP_ERR_INVALID, "terms and model disagree on d");
+  for (uint64_t l = 0; l < t->d; ++l)
+    if (t->maxlev[l] > b->md.cap[l])
+      return fail(OBHIP_ERR_INVALID, "terms use a level above the basis' level cap");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int obhip_basis_getmat_gradhyp(const obhip_basis *bc, const obhip_terms *tc, double *out) {
+  OB_TRY(check_grad_args(bc, tc));
+  if (!out) return fail(OBHIP_ERR_INVALID, "getmat_gradhyp: null argument");
+  obhip_basis &b = *const_cast<obhip_basis *>(bc);
+  obhip_terms &t = *const_cast<obhip_terms *>(tc);
+  OB_TRY(ensure_gradbasis(b));
+  DevBuf<double> tmp;
+  OB_TRY(tmp.alloc(b.n * t.p));
+  for (uint64_t h = 0; h < b.model->nhyp(); ++h) {
+    OB_TRY(launch_getmat(*b.grad->gb, *grad_view(t, b, h), tmp.p));
+    OB_TRY(d2h(out + h * b.n * t.p, tmp.p, b.n * t.p * sizeof(double)));
+  }
+  return 0;
+}
+
+int obhip_basis_mm_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const double *a,
+                           double *out, double *out_gradhyp) {
+  OB_TRY(check_grad_args(bc, tc));
+  if (!a || !out_gradhyp) return fail(OBHIP_ERR_INVALID, "mm_gradhyp: null argument");
+  obhip_basis &b = *const_cast<obhip_basis *>(bc);
+  obhip_terms &t = *const_cast<obhip_terms *>(tc);
+  OB_TRY(ensure_gradbasis(b));
+  DevBuf<double> da, dout;
+  OB_TRY(da.upload(a, t.p));
+  OB_TRY(dout.alloc(b.n));
+  if (out) {
+    OB_TRY(launch_mm(b, t, da.p, dout.p, false));
+    OB_TRY(d2h(out, dout.p, b.n * sizeof(double)));
+  }
+  for (uint64_t h = 0; h < b.model->nhyp(); ++h) {
+    OB_TRY(launch_mm(*b.grad->gb, *grad_view(t, b, h), da.p, dout.p, false));
+    OB_TRY(d2h(out_gradhyp + h * b.n, dout.p, b.n * sizeof(double)));
+  }
+  return 0;
+}
+
+int obhip_basis_tmm_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const double *a,
+                            double *out, double *out_gradhyp) {
+  OB_TRY(check_grad_args(bc, tc));
+  if (!a || !out_gradhyp) return fail(OBHIP_ERR_INVALID, "tmm_gradhyp: null argument");
+  obhip_basis &b = *const_cast<obhip_basis *>(bc);
+  obhip_terms &t = *const_cast<obhip_terms *>(tc);
+  OB_TRY(ensure_gradbasis(b));
+  DevBuf<double> da, dout;
+  OB_TRY(da.upload(a, b.n));
+  OB_TRY(dout.alloc(t.p));
+  if (out) {
+    OB_TRY(launch_tmm(b, t, da.p, dout.p, false));
+    OB_TRY(d2h(out, dout.p, t.p * sizeof(double)));
+  }
+  for (uint64_t h = 0; h < b.model->nhyp(); ++h) {
+    OB_TRY(launch_tmm(*b.grad->gb, *grad_view(t, b, h), da.p, dout.p, false));
+    OB_TRY(d2h(out_gradhyp + h * t.p, dout.p, t.p * sizeof(double)));
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -74,6 +74,42 @@ void cov_host(int kind, const double *hyp, const double *x1, uint64_t n1,
     }
 }
 
+// covf_*::cov_gradhyp (covfuncs.cpp:134-150, 220-243, 318-347)
+void cov_gradhyp_host(int kind, const double *hyp, const double *x1, uint64_t n1, const double *x2,
+                      uint64_t n2, double *out) {
+  const double a = 2.0, b = 0.25;
+  const uint64_t sl = n1 * n2;
+  if (kind == OBHIP_COV_MAT25ANG) {
+    const double lss = std::exp(a * hyp[0]), lsc = std::exp(a * hyp[1]);
+    for (uint64_t j = 0; j < n2; ++j)
+      for (uint64_t i = 0; i < n1; ++i) {
+        const double hs = std::sin(x1[i]) / lss - std::sin(x2[j]) / lss;
+        const double hc = std::cos(x1[i]) / lsc - std::cos(x2[j]) / lsc;
+        const double h = std::sqrt(hs * hs + hc * hc);
+        const double w = std::exp(-h) * (h + 1.0);
+        out[j * n1 + i] = a / 3 * hs * hs * w;
+        out[sl + j * n1 + i] = a / 3 * hc * hc * w;
+      }
+    return;
+  }
+  const bool pw = kind == OBHIP_COV_MAT25POW;
+  const double powv = pw ? std::exp(b * hyp[1]) : 1.0;
+  const double ls = pw ? std::exp(a * hyp[0] + b * hyp[1]) : std::exp(a * hyp[0]);
+  for (uint64_t j = 0; j < n2; ++j) {
+    const double t2 = (pw ? std::pow(x2[j], powv) : x2[j]) / ls;
+    for (uint64_t i = 0; i < n1; ++i) {
+      const double t1 = (pw ? std::pow(x1[i], powv) : x1[i]) / ls;
+      const double h = t1 - t2;
+      const double h2 = h * (1.0 + std::fabs(h)) * std::exp(-std::fabs(h));
+      out[j * n1 + i] = a / 3 * (h * h2);
+      if (pw) {
+        const double g = std::log(x1[i]) * t1 - std::log(x2[j]) * t2;
+        out[sl + j * n1 + i] = g * (-(b * powv / 3) * h2) + b / 3 * (h * h2);
+      }
+    }
+  }
+}
+
 double cov_hyplpdf_host(int kind, const double *hyp) {
   const CovInfo &ci = kCovInfo[kind];
   double out = 0;
@@ -169,6 +205,21 @@ int obhip_model::build() {
   rotmat.assign(mmax * Mtot, 0.0);
   basisvar.assign(Mtot, 0.0);
   maxlevel.assign(d, 0);
+  // gradient bookkeeping (modandbase.cpp:183-197)
+  hypmatch.assign(hypst[d], 0);
+  gest.assign(hypst[d] + 1, 0);
+  {
+    uint64_t cur = 0;
+    for (uint64_t l = 0; l < d; ++l)
+      for (uint64_t h = hypst[l]; h < hypst[l + 1]; ++h) {
+        hypmatch[h] = l;
+        gest[h] = cur;
+        cur += m_of(l);
+      }
+    gest[hypst[d]] = cur;
+    rotmat_gradhyp.assign(mmax * cur, 0.0);
+    logbasisvar_gradhyp.assign(cur, 0.0);
+  }
   for (uint64_t k = 0; k < d; ++k) {
     const uint64_t lenh = m_of(k), o = knotptst[k];
     const double *xs = &knotpt[o];
@@ -211,6 +262,40 @@ int obhip_model::build() {
       for (uint64_t i = 0; i < lenh; ++i)
         rotmat[(o + j) * mmax + i] = Ud[j * lenh + i] / dv;
       basisvar[o + j] = std::log(sr[j] / (double)lenh);
+    }
+    // gradient matrices (modandbase.cpp:257-274) from the jittered sr and sign-fixed U:
+    // UtdRV = U^T dR U; dlog(var) = diag(UtdRV) / sr; Ah = U (UtdRV % Fm) / (sr / sqrt(m)),
+    // Fm[i][j] = 1 / (sr[j] - sr[i]) off the diagonal and -1 / sr[i] on it
+    const uint64_t nh = hypst[k + 1] - hypst[k];
+    std::vector<double> Rge(lenh * lenh * nh), T1(lenh * lenh), T2(lenh * lenh);
+    cov_gradhyp_host(kinds[k], &hyp[hypst[k]], xs, lenh, xs, lenh, Rge.data());
+    for (uint64_t l = 0; l < nh; ++l) {
+      const double *dR = &Rge[l * lenh * lenh];  // symmetric
+      // T1 = dR U (column j of U is Ud[j*lenh ..])
+      for (uint64_t j = 0; j < lenh; ++j)
+        for (uint64_t i = 0; i < lenh; ++i) {
+          double acc = 0;
+          for (uint64_t q = 0; q < lenh; ++q) acc += dR[q * lenh + i] * Ud[j * lenh + q];
+          T1[j * lenh + i] = acc;
+        }
+      // T2 = (U^T T1) % Fm
+      const uint64_t go = gest[hypst[k] + l];
+      for (uint64_t j = 0; j < lenh; ++j)
+        for (uint64_t i = 0; i < lenh; ++i) {
+          double acc = 0;
+          for (uint64_t q = 0; q < lenh; ++q) acc += Ud[i * lenh + q] * T1[j * lenh + q];
+          if (i == j) logbasisvar_gradhyp[go + j] = acc / sr[j];
+          T2[j * lenh + i] = acc * (i == j ? -1.0 / sr[i] : 1.0 / (sr[j] - sr[i]));
+        }
+      // Ah = U T2, columns scaled by sqrt(m) / sr[j]
+      for (uint64_t j = 0; j < lenh; ++j) {
+        const double dv = sr[j] / sq;
+        for (uint64_t i = 0; i < lenh; ++i) {
+          double acc = 0;
+          for (uint64_t q = 0; q < lenh; ++q) acc += Ud[q * lenh + i] * T2[j * lenh + q];
+          rotmat_gradhyp[(go + j) * mmax + i] = acc / dv;
+        }
+      }
     }
   }
   ++version;
@@ -350,6 +435,54 @@ int obhip_model_set_rotation(obhip_model *m, const double *rotmat,
   }
   m->maxlevel.assign(maxlevel, maxlevel + m->d);
   ++m->version;
+  return 0;
+}
+
+int obhip_model_grad_layout(const obhip_model *m, uint64_t *nhyp, uint64_t *hypmatch,
+                            uint64_t *gest) {
+  if (!m) return fail(OBHIP_ERR_INVALID, "null model");
+  if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  if (nhyp) *nhyp = m->nhyp();
+  if (hypmatch) std::copy(m->hypmatch.begin(), m->hypmatch.end(), hypmatch);
+  if (gest) std::copy(m->gest.begin(), m->gest.end(), gest);
+  return 0;
+}
+
+int obhip_model_get_rotation_grad(const obhip_model *m, double *rotmat_gradhyp,
+                                  double *logbasisvar_gradhyp) {
+  if (!m) return fail(OBHIP_ERR_INVALID, "null model");
+  if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  if (rotmat_gradhyp)
+    std::copy(m->rotmat_gradhyp.begin(), m->rotmat_gradhyp.end(), rotmat_gradhyp);
+  if (logbasisvar_gradhyp)
+    std::copy(m->logbasisvar_gradhyp.begin(), m->logbasisvar_gradhyp.end(), logbasisvar_gradhyp);
+  return 0;
+}
+
+int obhip_model_set_rotation_grad(obhip_model *m, const double *rotmat_gradhyp,
+                                  const double *logbasisvar_gradhyp) {
+  if (!m || !rotmat_gradhyp || !logbasisvar_gradhyp)
+    return fail(OBHIP_ERR_INVALID, "null argument");
+  if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  const uint64_t ng = m->gest.back();
+  m->rotmat_gradhyp.assign(rotmat_gradhyp, rotmat_gradhyp + m->mmax * ng);
+  m->logbasisvar_gradhyp.assign(logbasisvar_gradhyp, logbasisvar_gradhyp + ng);
+  ++m->version;
+  return 0;
+}
+
+int obhip_model_term_lvar_gradhyp(const obhip_model *m, const uint64_t *terms, uint64_t p,
+                                  double *out) {
+  if (!m || !terms || !out) return fail(OBHIP_ERR_INVALID, "term_lvar_gradhyp: null argument");
+  if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  for (uint64_t h = 0; h < m->nhyp(); ++h) {
+    const uint64_t l = m->hypmatch[h];
+    for (uint64_t k = 0; k < p; ++k) {
+      const uint64_t t = terms[l * p + k];
+      if (t >= m->m_of(l)) return fail(OBHIP_ERR_INVALID, "term level out of range");
+      out[h * p + k] = m->logbasisvar_gradhyp[m->gest[h] + t];
+    }
+  }
   return 0;
 }
 

@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -84,6 +85,8 @@ struct CovInfo {
 const CovInfo &cov_info(int kind);
 void cov_host(int kind, const double *hyp, const double *x1, uint64_t n1,
               const double *x2, uint64_t n2, double *out /* n1 x n2 col-major */);
+void cov_gradhyp_host(int kind, const double *hyp, const double *x1, uint64_t n1, const double *x2,
+                      uint64_t n2, double *out /* n1 x n2 x numhyp, col-major slices */);
 double cov_hyplpdf_host(int kind, const double *hyp);
 
 // symmetric eigen-decomposition (cyclic Jacobi), eigenvalues ascending like
@@ -107,6 +110,12 @@ struct obhip_model {
   std::vector<double> basisvar;    // M
   std::vector<int64_t> maxlevel;   // d
   uint64_t version = 0;            // bumped whenever build() runs
+  // hyper-parameter gradients (modandbase.cpp:183-197,257-274): one block of m_l columns
+  // per hyper-parameter; gest[h] = first column of hyper-parameter h, hypmatch[h] = its dim
+  std::vector<uint64_t> hypmatch, gest;     // nhyp, nhyp + 1
+  std::vector<double> rotmat_gradhyp;       // mmax x gest[nhyp] col-major
+  std::vector<double> logbasisvar_gradhyp;  // gest[nhyp]
+  uint64_t nhyp() const { return hypmatch.size(); }
 
   uint64_t M() const { return knotpt.size(); }
   uint64_t m_of(uint64_t l) const { return knotptst[l + 1] - knotptst[l]; }
@@ -155,10 +164,36 @@ struct obhip_terms {
   obhip::DevBuf<uint32_t> ucol;       // Mu compact column ids (used list)
   obhip::DevBuf<int32_t> cpos;        // compact column -> used index or -1 (Mc)
   uint64_t p_pad = 0;
+  // per hyper-parameter views for the gradient products (kernels_grad.hip)
+  std::vector<std::unique_ptr<obhip_terms>> ge_views;
   // device view of the model capped at maxlev, for the fused predictor
   obhip::ModelDev pred_md;
   const obhip_model *pred_model = nullptr;
   int prepare(const std::vector<int64_t> &cap, const std::vector<obhip::DimDesc> &dims);
+};
+
+// ---- hyper-parameter gradient tables (device) -------------------------------------
+namespace obhip {
+struct GradHyp {
+  int dim;      // dimension of this hyper-parameter
+  int which;    // its index within the dimension (0 or 1)
+  int rotgoff;  // offset into rotg (doubles), block [m][ncolp] like ModelDev::rot
+  int gecol;    // first gradient column of this hyper-parameter in the combined tile
+};
+}  // namespace obhip
+
+struct obhip_basis;
+// gradient basis of an outerbase (outerbase::build with dograd, modandbase.cpp:547-626):
+// a second tile-blocked array holding the basemat columns AND, behind them, for every
+// hyper-parameter h the columns basemat_gradhyp[:, gest[h] + t], t = 0..cap -- laid out
+// so that the ordinary product kernels can run on it with per-hyper-parameter term views.
+struct obhip_gradbasis {
+  uint64_t model_version = ~0ull;
+  std::vector<obhip::GradHyp> hyps_h;
+  obhip::DevBuf<obhip::GradHyp> hyps;
+  obhip::DevBuf<double> rotg;  // per hyper-parameter [m][ncolp]
+  obhip::DevBuf<double> kd;    // per knot: log(knot) * t(knot) (mat25pow), else 0
+  std::unique_ptr<obhip_basis> gb;  // combined array + extended dimension table
 };
 
 // ---- outerbase ------------------------------------------------------------------
@@ -174,6 +209,7 @@ struct obhip_basis {
                                 // materialised-B Gram kernel (allocated on first use)
   obhip::DevBuf<uint32_t> gram_pairs;  // XCD-aware tile-pair order of that kernel
   int gram_pairs_nb = -1;
+  std::unique_ptr<obhip_gradbasis> grad;  // built on first *_gradhyp call, dropped on rebuild
   int device = 0;
   int workspace(size_t bytes, void **out) {
     if (work.n < bytes) {
@@ -205,6 +241,9 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a,
 int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G);
 void set_gram_backend(int b);
 int get_gram_backend();
+// kernels_grad.hip
+int ensure_gradbasis(obhip_basis &b);
+obhip_terms *grad_view(obhip_terms &t, const obhip_basis &b, uint64_t h);
 // kernels_chol.hip
 uint64_t newton_workspace_bytes(uint64_t p);
 int launch_newton_solve(uint64_t p, double *d_H, const double *d_rhs,

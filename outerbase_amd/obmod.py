@@ -103,7 +103,7 @@ class outermod:
         self.d = 0
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None:
+        if getattr(self, "_h", None) and _lib is not None and _lib.lib is not None:
             _lib.lib.obhip_model_destroy(self._h)
             self._h = None
 
@@ -131,6 +131,30 @@ class outermod:
         ml = np.ascontiguousarray(maxlevel, dtype=np.int64)
         call("obhip_model_set_rotation", self._h, ptr(rot), ptr(bv), ptr(ml))
 
+    def grad_layout(self):
+        """(hypmatch, gest): dimension and first gradient column of every hyper-parameter
+        (modandbase.cpp:183-197)."""
+        nh = C.c_uint64(0)
+        call("obhip_model_grad_layout", self._h, C.byref(nh), None, None)
+        hm = np.empty(nh.value, dtype=np.uint64)
+        ge = np.empty(nh.value + 1, dtype=np.uint64)
+        call("obhip_model_grad_layout", self._h, None, ptr(hm), ptr(ge))
+        return hm.astype(np.int64), ge.astype(np.int64)
+
+    def rotation_grad(self):
+        """(rotmat_gradhyp, logbasisvar_gradhyp) of outermod::build (modandbase.cpp:257-274)."""
+        _, _, mmax, _ = self.dims()
+        ng = int(self.grad_layout()[1][-1])
+        rg = np.empty((mmax, ng), order="F")
+        lv = np.empty(ng)
+        call("obhip_model_get_rotation_grad", self._h, ptr(rg), ptr(lv))
+        return rg, lv
+
+    def set_rotation_grad(self, rotmat_gradhyp, logbasisvar_gradhyp):
+        rg = _fmat(rotmat_gradhyp)
+        lv = _f64(logbasisvar_gradhyp)
+        call("obhip_model_set_rotation_grad", self._h, ptr(rg), ptr(lv))
+
     @property
     def maxlevel(self):
         return self.rotation()[2]
@@ -156,6 +180,14 @@ class outermod:
         t = _umat(terms)
         out = np.empty(t.shape[0])
         call("obhip_model_term_var", self._h, ptr(t), t.shape[0], ptr(out))
+        return out
+
+    def getlvar_gradhyp(self, terms):
+        """modandbase.cpp:364-379"""
+        t = _umat(terms)
+        nh = len(self.grad_layout()[0])
+        out = np.empty((t.shape[0], nh), order="F")
+        call("obhip_model_term_lvar_gradhyp", self._h, ptr(t), t.shape[0], ptr(out))
         return out
 
     def hyplpdf(self, hyp):
@@ -242,7 +274,7 @@ class _Terms:
         return dict(p=p.value, d=d.value, nnz_total=nnz.value, max_nnz=mx.value)
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None:
+        if getattr(self, "_h", None) and _lib is not None and _lib.lib is not None:
             _lib.lib.obhip_terms_destroy(self._h)
             self._h = None
 
@@ -273,7 +305,7 @@ class outerbase:
         self.vertpl = False
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None:
+        if getattr(self, "_h", None) and _lib is not None and _lib.lib is not None:
             _lib.lib.obhip_basis_destroy(self._h)
             self._h = None
 
@@ -305,6 +337,37 @@ class outerbase:
         out = np.empty((rows, a2.shape[1]), order="F")
         call(fn, self._h, t._h, ptr(a2), a2.shape[1], ptr(out))
         return out[:, 0].copy() if vec else out
+
+    # -- hyper-parameter gradients (interfaceR.cpp:689-692) ------------------------------
+    def getmat_gradhyp(self, terms):
+        """n x p x nhyp cube (modandbase.cpp:663-669)."""
+        t = _terms_of(self.om, terms)
+        nh = len(self.om.grad_layout()[0])
+        out = np.empty((self.n_row, t.p, nh), order="F")
+        call("obhip_basis_getmat_gradhyp", self._h, t._h, ptr(out))
+        return out
+
+    def matmul_gradhyp(self, terms, a):
+        """n x nhyp (mm_gradhyp_out, modandbase.cpp:739-744)."""
+        t = _terms_of(self.om, terms)
+        a = _f64(a)
+        if a.shape[0] != t.p:
+            raise ValueError("non-conformable arguments")
+        nh = len(self.om.grad_layout()[0])
+        out = np.empty((self.n_row, nh), order="F")
+        call("obhip_basis_mm_gradhyp", self._h, t._h, ptr(a), None, ptr(out))
+        return out
+
+    def tmatmul_gradhyp(self, terms, a):
+        """p x nhyp (tmm_gradhyp_out, modandbase.cpp:771-776)."""
+        t = _terms_of(self.om, terms)
+        a = _f64(a)
+        if a.shape[0] != self.n_row:
+            raise ValueError("non-conformable arguments")
+        nh = len(self.om.grad_layout()[0])
+        out = np.empty((t.p, nh), order="F")
+        call("obhip_basis_tmm_gradhyp", self._h, t._h, ptr(a), None, ptr(out))
+        return out
 
     def matmul(self, terms, a):
         return self._mm("obhip_basis_mm", terms, a, "p", "n")

@@ -52,6 +52,7 @@ def make_pair(kinds, knotlist, hyp=None, share_rotation=True):
     ob.setknot(om_d, knotlist)
     if share_rotation:
         om_d.set_rotation(om_o.rotmat, om_o.basisvar, om_o.maxlevel)
+        om_d.set_rotation_grad(om_o.rotmat_gradhyp, om_o.logbasisvar_gradhyp)
     return om_o, om_d
 
 

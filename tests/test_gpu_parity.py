@@ -400,3 +400,67 @@ def test_synthetic_generator_matches_oracle():
     xo, yo = O.synth_xy(42, 5000, n, kinds)
     assert np.array_equal(x.cpu().numpy().T, xo)
     assert relerr(y.cpu().numpy(), yo) < 1e-13
+
+
+# ---- hyper-parameter gradients (tests/testthat/test-obomgrad.R) ------------
+@pytest.mark.parametrize("kinds,n,p", [
+    (["mat25pow"] + ["mat25"] * 7, 200, 100),          # test-obomgrad.R "short, skinny"
+    (["mat25", "mat25pow", "mat25ang"], 333, 150),     # every covariance, ragged n
+    (["mat25"] * 5, 1000, 700),                        # wide
+])
+def test_gradhyp_products_match_oracle(kinds, n, p):
+    """getmat_gradhyp / matmul_gradhyp / tmatmul_gradhyp (getmge_, prodmmge_, tprodmmge_:
+    linalg.cpp:778-822, 219-276, 395-471) against the oracle on the same rotation."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    rng = np.random.default_rng(n + p)
+    hyp = None
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 24), hyp=hyp)
+    x = sample_x(rng, n, kinds)
+    terms = om_o.selectterms(p)
+    bo = O.OuterBase(om_o, x, dograd=True)
+    bd = ob.outerbase(om_d, x)
+    a = rng.standard_normal(p)
+    v = rng.standard_normal(n)
+    mean_o, mge_o = O.ob_mm_gradhyp(bo, terms, a)
+    g_o, gge_o = O.ob_tmm_gradhyp(bo, terms, v)
+    # levels of ~8 and more (eigenvalue ratio ~1e-8 at 24 knots) lose digits in the knot
+    # sums on both sides (see test_gram_backends); low-level cases agree to ~1e-12
+    tol = 1e-7 if terms.max() >= 8 else 1e-9
+    assert relerr(bd.matmul_gradhyp(terms, a), mge_o) < tol
+    assert relerr(bd.tmatmul_gradhyp(terms, v), gge_o) < tol
+    if n * p <= 60000:
+        assert relerr(bd.getmat_gradhyp(terms), O.ob_getmat_gradhyp(bo, terms)) < tol
+
+
+def test_gradhyp_follows_the_reference_finite_difference_test():
+    """test-obomgrad.R:21-67 on the device: the gradient along a random direction equals the
+    difference quotient of two rebuilt bases (updatehyp + build)."""
+    import outerbase_amd as ob
+    from conftest import KNOTS_REF
+    d, ss, nterms = 8, 400, 100
+    kinds = ["mat25pow"] + ["mat25"] * (d - 1)
+    rng = np.random.default_rng(42)
+    x = rng.random((ss, d))
+    om = ob.outermod()
+    ob.setcovfs(om, kinds)
+    ob.setknot(om, [KNOTS_REF] * d)
+    hyp0 = ob.gethyp(om)
+    terms = om.selectterms(nterms)
+    obp = ob.outerbase(om, x)
+    theta = 0.01 * rng.standard_normal(nterms)
+    y = rng.standard_normal(ss)
+    mge = obp.matmul_gradhyp(terms, theta)
+    gge = obp.tmatmul_gradhyp(terms, y)
+    eps, hypp = 1e-6, rng.random(len(hyp0)) - 0.5
+    vals = []
+    for sgn in (1.0, -1.0):
+        om.updatehyp(hyp0 + sgn * eps * hypp)
+        with pytest.raises(ob.ObhipError):
+            obp.matmul_gradhyp(terms, theta)      # stale basis: must be rebuilt first
+        obp.build()
+        vals.append((obp.matmul(terms, theta), obp.tmatmul(terms, y)))
+    fd_m = (vals[0][0] - vals[1][0]) / (2 * eps)
+    fd_t = (vals[0][1] - vals[1][1]) / (2 * eps)
+    assert np.max(np.abs(fd_m - mge @ hypp)) < 1e-3 * np.max(np.abs(fd_m))
+    assert np.max(np.abs(fd_t - gge @ hypp)) < 1e-3 * np.max(np.abs(fd_t))

@@ -79,6 +79,33 @@ def test_eigenmodel_matches_lapack_on_leading_levels():
     assert np.all(ml >= 8)
 
 
+def test_eigenmodel_gradient_matches_oracle():
+    """gradient part of outermod::build (modandbase.cpp:257-274) and getlvar_gradhyp
+    (:364-379): library (Jacobi) vs oracle (LAPACK) on the leading levels; the layout
+    (hypmatch, gest) exactly."""
+    kinds = ["mat25pow", "mat25", "mat25ang", "mat25"]
+    hyp = np.array([0.1, -0.05, 0.08, -0.1, 0.05, 0.02])
+    om_o, om_d = make_pair(kinds, O.bench_knots(kinds, 24), hyp=hyp, share_rotation=False)
+    hm, ge = om_d.grad_layout()
+    assert np.array_equal(hm, om_o.hypmatch) and np.array_equal(ge, om_o.gest)
+    rg, lv = om_d.rotation_grad()
+    assert rg.shape == om_o.rotmat_gradhyp.shape
+    lead = 6
+    for h in range(len(hm)):
+        sl = slice(ge[h], ge[h] + lead)
+        assert np.allclose(lv[sl], om_o.logbasisvar_gradhyp[sl], atol=1e-7)
+        if kinds[hm[h]] == "mat25ang":
+            continue  # degenerate sin/cos eigen-pairs, see above
+        ref = om_o.rotmat_gradhyp[:, sl]
+        assert np.max(np.abs(rg[:, sl] - ref)) < 1e-6 * np.max(np.abs(ref))
+    terms = om_o.selectterms(60)
+    assert np.allclose(om_d.getlvar_gradhyp(terms), om_o.getlvar_gradhyp(terms), atol=1e-6)
+    # injected gradient tables come back unchanged
+    om_d.set_rotation_grad(om_o.rotmat_gradhyp, om_o.logbasisvar_gradhyp)
+    rg2, lv2 = om_d.rotation_grad()
+    assert np.array_equal(rg2, om_o.rotmat_gradhyp) and np.array_equal(lv2, om_o.logbasisvar_gradhyp)
+
+
 @pytest.mark.parametrize("kinds,m,p", [
     (["mat25pow"] + ["mat25"] * 7, None, 20),          # test-obombasic.R
     (["mat25"] * 10, 40, 1024),                        # BASELINE config 2
