@@ -134,6 +134,10 @@ int obhip_model_term_var(const obhip_model *m, const uint64_t *terms,
 int obhip_model_hyplpdf(const obhip_model *m, const double *hyp, uint64_t nhyp,
                         double *out);
 
+/* om$hyplpdf_grad(hyp): modandbase.cpp:106-118 (covf::lpdf_gradhyp, covfuncs.cpp:53-70) */
+int obhip_model_hyplpdf_grad(const obhip_model *m, const double *hyp, uint64_t nhyp,
+                             double *out);
+
 /* ---- terms ------------------------------------------------------------- */
 /* Upload a umat `terms` (p x d, column-major, 0-based levels) once; the
  * reference passes it by value on every call (modandbase.cpp:649,677,700). */

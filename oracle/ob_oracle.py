@@ -148,6 +148,21 @@ def cov_hyp_lpdf(kind, hypp):
     return out
 
 
+def cov_hyp_lpdf_grad(kind, hypp):
+    """covf::lpdf_gradhyp (covfuncs.cpp:53-70): zeros outside the box."""
+    info = COV_INFO[kind]
+    hypp = np.asarray(hypp, dtype=np.float64)
+    out = np.zeros(info["numhyp"])
+    if len(hypp) != info["numhyp"]:
+        return out
+    for l in range(len(hypp)):
+        if info["hypub"][l] < hypp[l] or info["hyplb"][l] > hypp[l]:
+            return np.zeros(info["numhyp"])
+        out[l] -= 5 / (info["hypub"][l] - hypp[l])
+        out[l] += 5 / (hypp[l] - info["hyplb"][l])
+    return out - (hypp - np.asarray(info["hyp0"])) / np.asarray(info["hypvar"])
+
+
 # ----------------------------------------------------------------------------
 # outermod                                     src/modandbase.cpp:67-440
 # ----------------------------------------------------------------------------
@@ -221,6 +236,16 @@ class OuterMod:
         return sum(cov_hyp_lpdf(self.kinds[l],
                                 hypp[self.hypst[l]:self.hypst[l + 1]])
                    for l in range(self.d))
+
+    # modandbase.cpp:106-118 (hyplpdf_grad)
+    def hyplpdf_grad(self, hypp):
+        hypp = np.asarray(hypp, dtype=np.float64)
+        out = np.zeros(len(self.hyp))
+        if len(hypp) == len(self.hyp):
+            for l in range(self.d):
+                sl = slice(self.hypst[l], self.hypst[l + 1])
+                out[sl] = cov_hyp_lpdf_grad(self.kinds[l], hypp[sl])
+        return out
 
     # modandbase.cpp:210-276 (build), value part :219-255
     def build(self):
@@ -670,6 +695,33 @@ def lpdf_val(ob, terms, y, sigma, rho, coeff):
     v += -0.5 * np.sum(np.square(coeff / (coeffsd * sca))) \
         - np.sum(np.log(coeffsd * sca))
     return float(v)
+
+
+def loglik_update(ob, terms, y, sigma, coeff):
+    """loglik_gauss::update / loglik_std::update with compute_gradhyp and
+    compute_gradpara (loglik_gauss.cpp:110-130, loglik_std.cpp:100-120): val, grad,
+    gradhyp, gradpara.  ob must have been built with dograd."""
+    yhat, yhatge = ob_mm_gradhyp(ob, terms, coeff)
+    resid = math.exp(-sigma) * (yhat - y)
+    val = float(-0.5 * np.sum(np.square(resid)) - len(y) * sigma)
+    r2 = -math.exp(-sigma) * resid
+    grad = ob_tmm(ob, terms, r2)
+    gradhyp = r2 @ yhatge
+    gradpara = np.array([np.sum(np.square(resid)) - len(y)])
+    return val, grad, gradhyp, gradpara
+
+
+def logpr_update(om, terms, rho, coeff):
+    """logpr_gauss::update with compute_gradhyp / compute_gradpara
+    (logpr_gauss.cpp:98-108; coefflvarge = getlvar_gradhyp, :80)."""
+    coeffsd = np.sqrt(om.getvar(terms))
+    sca = math.exp(rho)
+    stdresid = coeff / (coeffsd * sca)
+    val = float(-0.5 * np.sum(np.square(stdresid)) - np.sum(np.log(coeffsd * sca)))
+    gradhyp = (0.5 * om.getlvar_gradhyp(terms)).T @ (np.square(stdresid) - 1)
+    gradpara = np.array([np.sum(np.square(stdresid)) - len(coeffsd)])
+    grad = -stdresid / (coeffsd * sca)
+    return val, grad, gradhyp, gradpara
 
 
 def fit_cg(ob, terms, y, sigma=None, rho=DEFAULT_RHO, tol=1e-10, maxit=100,

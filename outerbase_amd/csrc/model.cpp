@@ -515,6 +515,26 @@ int obhip_model_hyplpdf(const obhip_model *m, const double *hyp, uint64_t nhyp,
   return 0;
 }
 
+int obhip_model_hyplpdf_grad(const obhip_model *m, const double *hyp, uint64_t nhyp, double *out) {
+  if (!m || !hyp || !out) return fail(OBHIP_ERR_INVALID, "hyplpdf_grad: null argument");
+  for (uint64_t h = 0; h < m->hyp.size(); ++h) out[h] = 0.0;
+  if (nhyp != m->hyp.size()) return 0;  // modandbase.cpp:111: zeros on a size mismatch
+  for (uint64_t l = 0; l < m->d; ++l) {
+    // covf::lpdf_gradhyp, covfuncs.cpp:53-70 (zeros outside the box)
+    const CovInfo &ci = kCovInfo[m->kinds[l]];
+    const double *hp = hyp + m->hypst[l];
+    double *o = out + m->hypst[l];
+    bool inside = true;
+    for (int q = 0; q < ci.numhyp; ++q)
+      if (ci.hypub[q] < hp[q] || ci.hyplb[q] > hp[q]) inside = false;
+    if (!inside) continue;
+    for (int q = 0; q < ci.numhyp; ++q)
+      o[q] = -5.0 / (ci.hypub[q] - hp[q]) + 5.0 / (hp[q] - ci.hyplb[q]) -
+             (hp[q] - ci.hyp0[q]) / ci.hypvar[q];
+  }
+  return 0;
+}
+
 }  // extern "C"
 
 // ---- term selection -------------------------------------------------------------

@@ -196,6 +196,13 @@ class outermod:
         call("obhip_model_hyplpdf", self._h, ptr(hyp), len(hyp), C.byref(out))
         return out.value
 
+    def hyplpdf_grad(self, hyp):
+        """modandbase.cpp:106-118"""
+        hyp = _f64(hyp)
+        out = np.zeros(self.dims()[3])
+        call("obhip_model_hyplpdf_grad", self._h, ptr(hyp), len(hyp), ptr(out))
+        return out
+
 
 def setcovfs(om, covnames):
     """interfaceR.cpp:53-73"""
@@ -412,6 +419,10 @@ class lpdf:
         self.fullhess = False
         self.compute_val = True
         self.compute_grad = True
+        self.compute_gradhyp = False   # fit.h:36-38
+        self.compute_gradpara = False
+        self.gradhyp = np.zeros(0)
+        self.gradpara = np.zeros(0)
         self.paranames = []
 
     def setnthreads(self, k):  # fit.h:57 (no-op on the device)
@@ -440,6 +451,7 @@ class logpr_gauss(lpdf):
 
     def updateom(self):
         self.coeffsd = np.sqrt(self.om.getvar(self.terms))
+        self.coefflvarge = self.om.getlvar_gradhyp(self.terms)   # logpr_gauss.cpp:80
 
     def updatepara(self, para):
         self.para = np.array(para, dtype=np.float64).reshape(-1)
@@ -454,6 +466,10 @@ class logpr_gauss(lpdf):
         sca = math.exp(self.para[0])
         stdresid = self.coeff / (self.coeffsd * sca)
         self.val = float(-0.5 * np.sum(stdresid ** 2) - np.sum(np.log(self.coeffsd * sca)))
+        if self.compute_gradhyp:      # logpr_gauss.cpp:102
+            self.gradhyp = (0.5 * self.coefflvarge).T @ (stdresid ** 2 - 1)
+        if self.compute_gradpara:     # :103
+            self.gradpara = np.array([np.sum(stdresid ** 2) - len(self.coeffsd)])
         self.grad = -1.0 * stdresid / (self.coeffsd * sca)
 
     def diaghess(self):
@@ -499,7 +515,12 @@ class _loglik(lpdf):
         self.yhat = self.ob.matmul(self._t, self.coeff)
         resid = math.exp(-s) * (self.yhat - self.y)
         self.val = float(-0.5 * np.sum(resid ** 2) - len(self.y) * s)
-        self.grad = self.ob.tmatmul(self._t, -math.exp(-s) * resid)
+        r2 = -math.exp(-s) * resid
+        self.grad = self.ob.tmatmul(self._t, r2)
+        if self.compute_gradhyp:      # loglik_gauss.cpp:114-117,127
+            self.gradhyp = r2 @ self.ob.matmul_gradhyp(self._t, self.coeff)
+        if self.compute_gradpara:     # :128
+            self.gradpara = np.array([np.sum(resid ** 2) - len(self.y)])
 
     def hessmult(self, g):
         v = self.ob.matmul(self._t, np.asarray(g, dtype=np.float64))
@@ -576,10 +597,16 @@ class lpdfvec(lpdf):
 
     def update(self, coeff):
         self.coeff = np.array(coeff, dtype=np.float64)
-        for o in self.lpdflist:
+        for o in self.lpdflist:       # fit.cpp:323-328: the flags are pushed down
+            o.compute_gradhyp = self.compute_gradhyp
+            o.compute_gradpara = self.compute_gradpara
             o.update(self.coeff)
         self.val = sum(o.val for o in self.lpdflist)
         self.grad = self.lpdflist[0].grad + self.lpdflist[1].grad
+        if self.compute_gradhyp:      # fit.cpp:339-342,347-352: summed over the list
+            self.gradhyp = self.lpdflist[0].gradhyp + self.lpdflist[1].gradhyp
+        if self.compute_gradpara:     # concatenated like para
+            self.gradpara = np.concatenate([self.lpdflist[0].gradpara, self.lpdflist[1].gradpara])
 
     def hessmult(self, g):
         return self.lpdflist[0].hessmult(g) + self.lpdflist[1].hessmult(g)

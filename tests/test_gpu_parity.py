@@ -464,3 +464,32 @@ def test_gradhyp_follows_the_reference_finite_difference_test():
     fd_t = (vals[0][1] - vals[1][1]) / (2 * eps)
     assert np.max(np.abs(fd_m - mge @ hypp)) < 1e-3 * np.max(np.abs(fd_m))
     assert np.max(np.abs(fd_t - gge @ hypp)) < 1e-3 * np.max(np.abs(fd_t))
+
+
+def test_lpdf_gradhyp_matches_oracle():
+    """lpdfvec(loglik_gauss, logpr_gauss)$update with compute_gradhyp / compute_gradpara
+    (fit.cpp:319-352, loglik_gauss.cpp:110-130, logpr_gauss.cpp:98-108) and om$hyplpdf_grad."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25pow", "mat25", "mat25ang", "mat25"]
+    rng = np.random.default_rng(17)
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 24))
+    x, y = O.synth_xy(42, 0, 500, kinds)
+    y = (y - y.mean()) / y.std(ddof=1)
+    terms = om_o.selectterms(120)
+    coeff = 0.05 * rng.standard_normal(120)
+    lik = ob.loglik_gauss(om_d, terms, y, x)
+    pr = ob.logpr_gauss(om_d, terms)
+    lp = ob.lpdfvec(lik, pr)
+    lp.compute_gradhyp = lp.compute_gradpara = True
+    lp.updatepara([-1.3, 5.0])
+    lp.update(coeff)
+    bo = O.OuterBase(om_o, x, dograd=True)
+    v, g, gh, gp = O.loglik_update(bo, terms, y, -1.3, coeff)
+    pv, pg, pgh, pgp = O.logpr_update(om_o, terms, 5.0, coeff)
+    assert abs(lp.val - (v + pv)) < 1e-10 * abs(v + pv)
+    assert relerr(lp.grad, g + pg) < 1e-10
+    assert relerr(lp.gradhyp, gh + pgh) < 1e-8
+    assert relerr(lp.gradpara, np.concatenate([gp, pgp])) < 1e-11
+    hyp = ob.gethyp(om_d) + 0.1
+    assert np.allclose(om_d.hyplpdf_grad(hyp), om_o.hyplpdf_grad(hyp), rtol=1e-14)
