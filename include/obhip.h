@@ -214,6 +214,19 @@ int obhip_basis_mm_gradhyp(const obhip_basis *b, const obhip_terms *t, const dou
 int obhip_basis_tmm_gradhyp(const obhip_basis *b, const obhip_terms *t, const double *a,
                             double *out, double *out_gradhyp);
 
+/* ob$sqmm_gradhyp(terms, a) / ob$sqtmm_gradhyp(terms, a): the same on the squared stores
+ * basematsq / basescalesq / basematsq_gradhyp (modandbase.cpp:798-809, 845-856);
+ * out_gradhyp n x nhyp resp. p x nhyp, column-major */
+int obhip_basis_sqmm_gradhyp(const obhip_basis *b, const obhip_terms *t, const double *a,
+                             double *out_gradhyp);
+int obhip_basis_sqtmm_gradhyp(const obhip_basis *b, const obhip_terms *t, const double *a,
+                              double *out_gradhyp);
+/* ob$sqcolsums_gradhyp(terms): modandbase.cpp:875-879; p x nhyp */
+int obhip_basis_sqcolsums_gradhyp(const obhip_basis *b, const obhip_terms *t, double *out_gradhyp);
+/* ob$residvar_gradhyp(terms): modandbase.cpp:904-925; n x nhyp */
+int obhip_basis_residvar_gradhyp(const obhip_basis *b, const obhip_terms *t, const obhip_model *m,
+                                 double *out_gradhyp);
+
 /* ---- Gram / Newton ("back end A") -------------------------------------- */
 /* G = B^T B (loglik_std::hess without its e^{-2 sigma}, loglik_std.cpp:
  * 170-173) and g = B^T y (loglik_std::update at coeff = 0, :100-120).

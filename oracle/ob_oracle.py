@@ -427,6 +427,7 @@ class OuterBase:
         self.basescale = np.ones(n)
         if self.dograd:
             self.basemat_gradhyp = np.zeros((n, om.knotptstge[om.d]), order="F")
+            self.basematsq_gradhyp = np.zeros((n, om.knotptstge[om.d]), order="F")
         for k in range(om.d):
             if self.dograd:
                 R, Rt = om.buildob_grad(self.xp[:, k], k)           # :568
@@ -438,6 +439,10 @@ class OuterBase:
             self.basescalemat[:, k] = R[:, 0]                       # :572
             self.basescale *= R[:, 0]                               # :573
             R[:, 0] = 1.0                                           # :574
+            if self.dograd:
+                for h in range(om.hypst[k], om.hypst[k + 1]):       # :588-590, R[:, 0] is 1 here
+                    self.basematsq_gradhyp[:, om.gest[h]:om.gest[h + 1]] = \
+                        2 * (Rt[:, :, h - om.hypst[k]] * R)
             self.basemat[:, om.knotptst[k]:om.knotptst[k + 1]] = R  # :578
         self.basematsq = np.square(self.basemat)                    # :581
         self.basescalesq = np.square(self.basescale)                # :597
@@ -582,6 +587,29 @@ def ob_tmm_gradhyp(ob, terms, a):          # modandbase.cpp:755-776
     om = ob.om
     return tprodmmge(terms, a, ob.basemat, ob.basescale, om.knotptst, ob.basemat_gradhyp,
                      om.gest, om.hypmatch)
+
+
+def ob_sqmm_gradhyp(ob, terms, a):         # modandbase.cpp:798-809
+    om = ob.om
+    return prodmmge(terms, a, ob.basematsq, ob.basescalesq, om.knotptst,
+                    ob.basematsq_gradhyp, om.gest, om.hypmatch)[1]
+
+
+def ob_sqtmm_gradhyp(ob, terms, a):        # modandbase.cpp:845-856
+    om = ob.om
+    return tprodmmge(terms, a, ob.basematsq, ob.basescalesq, om.knotptst,
+                     ob.basematsq_gradhyp, om.gest, om.hypmatch)[1]
+
+
+def ob_sqcolsums_gradhyp(ob, terms):       # modandbase.cpp:875-879
+    return ob_sqtmm_gradhyp(ob, terms, np.ones(ob.xp.shape[0]))
+
+
+def ob_residvar_gradhyp(ob, terms):        # modandbase.cpp:904-925
+    varc = ob.om.getvar(terms)
+    outge = -ob_sqmm_gradhyp(ob, terms, varc)
+    lv2 = ob.om.getlvar_gradhyp(terms) * varc[:, None]
+    return outge - prodmm(terms, lv2, ob.basematsq, ob.basescalesq, ob.om.knotptst)
 
 
 def ob_getmat(ob, terms):      # modandbase.cpp:649-654

@@ -219,6 +219,65 @@ int ensure_gradbasis(obhip_basis &b) {
   return 0;
 }
 
+namespace {
+
+// squared store of the gradient basis (basematsq / basematsq_gradhyp, modandbase.cpp:581,
+// 588-590): basemat columns squared, gradient column t of a hyper-parameter -> 2 * it *
+// basemat level t of its dimension (the ones column at level 0); scale squared
+__global__ void __launch_bounds__(256)
+k_square_gradbasis(const double *__restrict__ src, const double *__restrict__ scale,
+                   const uint32_t *__restrict__ pair, uint64_t Mc, uint64_t Mtot,
+                   double *__restrict__ dst, double *__restrict__ scale_sq) {
+  const uint64_t tile = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double *s = src + tile * Mtot * kTileRows + lane;
+  double *o = dst + tile * Mtot * kTileRows + lane;
+  for (uint64_t c = wave; c < Mtot; c += 4) {
+    const double v = s[c * kTileRows];
+    o[c * kTileRows] = c < Mc ? v * v : 2.0 * v * s[(uint64_t)pair[c - Mc] * kTileRows];
+  }
+  if (wave == 0) {
+    const double sc = scale[tile * kTileRows + lane];
+    scale_sq[tile * kTileRows + lane] = sc * sc;
+  }
+}
+
+}  // namespace
+
+int ensure_gradbasis_sq(obhip_basis &b) {
+  OB_TRY(ensure_gradbasis(b));
+  obhip_gradbasis &g = *b.grad;
+  if (g.gbsq) return 0;
+  const obhip_basis &gb = *g.gb;
+  const uint64_t Mc = b.md.Mc, Mtot = gb.md.Mc;
+  std::vector<uint32_t> pair(Mtot - Mc, 0u);
+  for (size_t h = 0; h < g.hyps_h.size(); ++h) {
+    const DimDesc &D = b.md.dims_h[g.hyps_h[h].dim];
+    for (int t = 1; t < D.ncol; ++t) pair[g.hyps_h[h].gecol - Mc + t] = (uint32_t)(D.ccol0 + t - 1);
+  }
+  DevBuf<uint32_t> dpair;
+  OB_TRY(dpair.upload(pair.data(), pair.size()));
+  auto sq = std::make_unique<obhip_basis>();
+  sq->model = gb.model;
+  sq->n = gb.n;
+  sq->n_pad = gb.n_pad;
+  sq->d = gb.d;
+  sq->device = gb.device;
+  sq->md.cap = gb.md.cap;
+  sq->md.dims_h = gb.md.dims_h;
+  sq->md.Mc = Mtot;
+  sq->md.model_version = gb.md.model_version;
+  const uint64_t tiles = gb.n_pad / kTileRows;
+  OB_TRY(sq->bm.alloc(tiles * Mtot * kTileRows));
+  OB_TRY(sq->scale.alloc(gb.n_pad));
+  hipLaunchKernelGGL(k_square_gradbasis, dim3((unsigned)tiles), dim3(256), 0, cur_stream(), gb.bm.p,
+                     gb.scale.p, dpair.p, Mc, Mtot, sq->bm.p, sq->scale.p);
+  OB_HIP(hipGetLastError());
+  OB_HIP(hipStreamSynchronize(cur_stream()));  // dpair is a local
+  g.gbsq = std::move(sq);
+  return 0;
+}
+
 // View of the terms for hyper-parameter h: dimension hypmatch[h] dropped, pseudo-dimension
 // d + h at level t + 1 (so even level 0 picks up its gradient column).
 obhip_terms *grad_view(obhip_terms &t, const obhip_basis &b, uint64_t h) {
@@ -312,6 +371,69 @@ int obhip_basis_mm_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const d
   for (uint64_t h = 0; h < b.model->nhyp(); ++h) {
     OB_TRY(launch_mm(*b.grad->gb, *grad_view(t, b, h), da.p, dout.p, false));
     OB_TRY(d2h(out_gradhyp + h * b.n, dout.p, b.n * sizeof(double)));
+  }
+  return 0;
+}
+
+// products on the squared stores: ob$sqmm_gradhyp / ob$sqtmm_gradhyp
+// (modandbase.cpp:798-809, 845-856)
+static int sq_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const double *a,
+                      double *out_gradhyp, bool transposed) {
+  OB_TRY(check_grad_args(bc, tc));
+  if (!a || !out_gradhyp) return fail(OBHIP_ERR_INVALID, "sq*_gradhyp: null argument");
+  obhip_basis &b = *const_cast<obhip_basis *>(bc);
+  obhip_terms &t = *const_cast<obhip_terms *>(tc);
+  OB_TRY(ensure_gradbasis_sq(b));
+  const uint64_t nin = transposed ? b.n : t.p, nout = transposed ? t.p : b.n;
+  DevBuf<double> da, dout;
+  OB_TRY(da.upload(a, nin));
+  OB_TRY(dout.alloc(nout));
+  for (uint64_t h = 0; h < b.model->nhyp(); ++h) {
+    if (transposed)
+      OB_TRY(launch_tmm(*b.grad->gbsq, *grad_view(t, b, h), da.p, dout.p, false));
+    else
+      OB_TRY(launch_mm(*b.grad->gbsq, *grad_view(t, b, h), da.p, dout.p, false));
+    OB_TRY(d2h(out_gradhyp + h * nout, dout.p, nout * sizeof(double)));
+  }
+  return 0;
+}
+
+int obhip_basis_sqmm_gradhyp(const obhip_basis *b, const obhip_terms *t, const double *a,
+                             double *out_gradhyp) {
+  return sq_gradhyp(b, t, a, out_gradhyp, false);
+}
+
+int obhip_basis_sqtmm_gradhyp(const obhip_basis *b, const obhip_terms *t, const double *a,
+                              double *out_gradhyp) {
+  return sq_gradhyp(b, t, a, out_gradhyp, true);
+}
+
+int obhip_basis_sqcolsums_gradhyp(const obhip_basis *b, const obhip_terms *t, double *out_gradhyp) {
+  if (!b) return fail(OBHIP_ERR_INVALID, "sqcolsums_gradhyp: null argument");
+  std::vector<double> ones(b->n, 1.0);  // modandbase.cpp:875-879
+  return sq_gradhyp(b, t, ones.data(), out_gradhyp, true);
+}
+
+int obhip_basis_residvar_gradhyp(const obhip_basis *b, const obhip_terms *t, const obhip_model *m,
+                                 double *out_gradhyp) {
+  if (!b || !t || !m || !out_gradhyp) return fail(OBHIP_ERR_INVALID, "residvar_gradhyp: null argument");
+  if (m != b->model) return fail(OBHIP_ERR_INVALID, "residvar_gradhyp: basis belongs to another model");
+  const uint64_t p = t->p, n = b->n, nh = m->nhyp(), d = m->d;
+  // varc = getvar(terms), lvarge = getlvar_gradhyp(terms) (modandbase.cpp:350-356, 364-379)
+  std::vector<double> varc(p), col(p), tmp(n);
+  for (uint64_t k = 0; k < p; ++k) {
+    double sv = 0;
+    for (uint64_t l = 0; l < d; ++l) sv += m->basisvar[m->knotptst[l] + t->lev[k * d + l]];
+    varc[k] = std::exp(sv);
+  }
+  OB_TRY(sq_gradhyp(b, t, varc.data(), out_gradhyp, false));  // :909
+  for (uint64_t i = 0; i < n * nh; ++i) out_gradhyp[i] = -out_gradhyp[i];
+  for (uint64_t h = 0; h < nh; ++h) {  // :912-919: minus B^2 (lvarge % varc), column by column
+    const uint64_t l = m->hypmatch[h];
+    for (uint64_t k = 0; k < p; ++k)
+      col[k] = varc[k] * m->logbasisvar_gradhyp[m->gest[h] + t->lev[k * d + l]];
+    OB_TRY(obhip_basis_sqmm(b, t, col.data(), 1, tmp.data()));
+    for (uint64_t i = 0; i < n; ++i) out_gradhyp[h * n + i] -= tmp[i];
   }
   return 0;
 }

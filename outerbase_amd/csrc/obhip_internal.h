@@ -193,7 +193,8 @@ struct obhip_gradbasis {
   obhip::DevBuf<obhip::GradHyp> hyps;
   obhip::DevBuf<double> rotg;  // per hyper-parameter [m][ncolp]
   obhip::DevBuf<double> kd;    // per knot: log(knot) * t(knot) (mat25pow), else 0
-  std::unique_ptr<obhip_basis> gb;  // combined array + extended dimension table
+  std::unique_ptr<obhip_basis> gb;    // combined array + extended dimension table
+  std::unique_ptr<obhip_basis> gbsq;  // its squared store (basematsq / basematsq_gradhyp)
 };
 
 // ---- outerbase ------------------------------------------------------------------
@@ -243,6 +244,7 @@ void set_gram_backend(int b);
 int get_gram_backend();
 // kernels_grad.hip
 int ensure_gradbasis(obhip_basis &b);
+int ensure_gradbasis_sq(obhip_basis &b);
 obhip_terms *grad_view(obhip_terms &t, const obhip_basis &b, uint64_t h);
 // kernels_chol.hip
 uint64_t newton_workspace_bytes(uint64_t p);

@@ -376,6 +376,34 @@ class outerbase:
         call("obhip_basis_tmm_gradhyp", self._h, t._h, ptr(a), None, ptr(out))
         return out
 
+    def _sq_gradhyp(self, fn, terms, a, nin, nout):
+        t = _terms_of(self.om, terms)
+        a = _f64(a)
+        if a.shape[0] != (t.p if nin == "p" else self.n_row):
+            raise ValueError("non-conformable arguments")
+        nh = len(self.om.grad_layout()[0])
+        out = np.empty((self.n_row if nout == "n" else t.p, nh), order="F")
+        call(fn, self._h, t._h, ptr(a), ptr(out))
+        return out
+
+    def sqmm_gradhyp(self, terms, a):       # modandbase.cpp:798-809
+        return self._sq_gradhyp("obhip_basis_sqmm_gradhyp", terms, a, "p", "n")
+
+    def sqtmm_gradhyp(self, terms, a):      # modandbase.cpp:845-856
+        return self._sq_gradhyp("obhip_basis_sqtmm_gradhyp", terms, a, "n", "p")
+
+    def sqcolsums_gradhyp(self, terms):     # modandbase.cpp:875-879
+        t = _terms_of(self.om, terms)
+        out = np.empty((t.p, len(self.om.grad_layout()[0])), order="F")
+        call("obhip_basis_sqcolsums_gradhyp", self._h, t._h, ptr(out))
+        return out
+
+    def residvar_gradhyp(self, terms):      # modandbase.cpp:904-925
+        t = _terms_of(self.om, terms)
+        out = np.empty((self.n_row, len(self.om.grad_layout()[0])), order="F")
+        call("obhip_basis_residvar_gradhyp", self._h, t._h, self.om._h, ptr(out))
+        return out
+
     def matmul(self, terms, a):
         return self._mm("obhip_basis_mm", terms, a, "p", "n")
 
@@ -475,6 +503,9 @@ class logpr_gauss(lpdf):
     def diaghess(self):
         return 1.0 / np.square(self.coeffsd * math.exp(self.para[0]))
 
+    def diaghessgradhyp(self):        # logpr_gauss.cpp:131-135
+        return -self.coefflvarge / np.square(self.coeffsd * math.exp(self.para[0]))[:, None]
+
     def hessmult(self, g):
         return np.asarray(g) / np.square(self.coeffsd * math.exp(self.para[0]))
 
@@ -528,6 +559,12 @@ class _loglik(lpdf):
 
     def diaghess(self):
         return math.exp(-2 * self.para[0]) * self.ob.sqcolsums(self._t)
+
+    def diaghessgradhyp(self):        # loglik_gauss.cpp:158-161
+        return math.exp(-2 * self.para[0]) * self.ob.sqcolsums_gradhyp(self._t)
+
+    def diaghessgradpara(self):       # loglik_gauss.cpp:169-172
+        return (-2 * math.exp(-2 * self.para[0]) * self.ob.sqcolsums(self._t))[:, None]
 
 
 class loglik_gauss(_loglik):

@@ -493,3 +493,30 @@ def test_lpdf_gradhyp_matches_oracle():
     assert relerr(lp.gradpara, np.concatenate([gp, pgp])) < 1e-11
     hyp = ob.gethyp(om_d) + 0.1
     assert np.allclose(om_d.hyplpdf_grad(hyp), om_o.hyplpdf_grad(hyp), rtol=1e-14)
+
+
+def test_squared_store_gradients_match_oracle():
+    """ob$sqmm_gradhyp, sqtmm_gradhyp, sqcolsums_gradhyp, residvar_gradhyp
+    (modandbase.cpp:798-809, 845-856, 875-879, 904-925) and the lpdfs' diaghessgradhyp."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25", "mat25pow", "mat25ang", "mat25"]
+    rng = np.random.default_rng(23)
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 24))
+    n, p = 260, 90
+    x = sample_x(rng, n, kinds)
+    terms = om_o.selectterms(p)
+    a, v = np.abs(rng.standard_normal(p)), rng.standard_normal(n)
+    bo = O.OuterBase(om_o, x, dograd=True)
+    bd = ob.outerbase(om_d, x)
+    assert relerr(bd.sqmm_gradhyp(terms, a), O.ob_sqmm_gradhyp(bo, terms, a)) < 1e-9
+    assert relerr(bd.sqtmm_gradhyp(terms, v), O.ob_sqtmm_gradhyp(bo, terms, v)) < 1e-9
+    assert relerr(bd.sqcolsums_gradhyp(terms), O.ob_sqcolsums_gradhyp(bo, terms)) < 1e-9
+    assert relerr(bd.residvar_gradhyp(terms), O.ob_residvar_gradhyp(bo, terms)) < 1e-9
+    y = rng.standard_normal(n)
+    lik = ob.loglik_gauss(om_d, terms, y, x)
+    s = float(lik.para[0])
+    assert relerr(lik.diaghessgradhyp(), math.exp(-2 * s) * O.ob_sqcolsums_gradhyp(bo, terms)) < 1e-9
+    pr = ob.logpr_gauss(om_d, terms)
+    want = -om_o.getlvar_gradhyp(terms) / (om_o.getvar(terms) * math.exp(2 * 6.0))[:, None]
+    assert relerr(pr.diaghessgradhyp(), want) < 1e-12
