@@ -752,6 +752,23 @@ def logpr_update(om, terms, rho, coeff):
     return val, grad, gradhyp, gradpara
 
 
+def margadj_diag(ob, terms, sigma, rho):
+    """Marginal adjustment of lpdfvec in its diagonal form (lpdfvec::buildhess,
+    fit.cpp:252-268, added by margadj :371-380): with the total Hessian diagonal
+    D = e^{-2 sigma} sqcolsums + 1/(sd e^rho)^2,
+      val += -1/2 sum log D,  gradhyp += -1/2 sum_k dD_k/dhyp / D_k,  same for para.
+    Returns (val, gradhyp, gradpara_loglik, gradpara_logpr); ob needs dograd."""
+    om = ob.om
+    prec = prior_prec(om, terms, rho)
+    D = math.exp(-2 * sigma) * ob_sqcolsums(ob, terms) + prec
+    dgh = math.exp(-2 * sigma) * ob_sqcolsums_gradhyp(ob, terms) \
+        - om.getlvar_gradhyp(terms) * prec[:, None]         # loglik_gauss.cpp:158-161, logpr :131-135
+    dgp_lik = -2 * math.exp(-2 * sigma) * ob_sqcolsums(ob, terms)   # loglik_gauss.cpp:169-172
+    dgp_pr = -2 * prec                                              # logpr_gauss.cpp:143-145
+    return (float(-0.5 * np.sum(np.log(D))), -0.5 * np.sum(dgh / D[:, None], axis=0),
+            float(-0.5 * np.sum(dgp_lik / D)), float(-0.5 * np.sum(dgp_pr / D)))
+
+
 def fit_cg(ob, terms, y, sigma=None, rho=DEFAULT_RHO, tol=1e-10, maxit=100,
            coeff0=None):
     """lpdf::optcg on lpdfvec(logpr_gauss, loglik_gauss) (fit.cpp:37-96) with

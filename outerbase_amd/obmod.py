@@ -506,6 +506,9 @@ class logpr_gauss(lpdf):
     def diaghessgradhyp(self):        # logpr_gauss.cpp:131-135
         return -self.coefflvarge / np.square(self.coeffsd * math.exp(self.para[0]))[:, None]
 
+    def diaghessgradpara(self):       # logpr_gauss.cpp:143-145
+        return (-2.0 / np.square(self.coeffsd * math.exp(self.para[0])))[:, None]
+
     def hessmult(self, g):
         return np.asarray(g) / np.square(self.coeffsd * math.exp(self.para[0]))
 
@@ -592,7 +595,8 @@ def _gram_host(ob, t):
 
 
 class lpdfvec(lpdf):
-    """src/fit.cpp:174-363 for a (likelihood, prior) pair, domarg = False."""
+    """src/fit.cpp:174-380 for a (likelihood, prior) pair; domarg switches the marginal
+    adjustment on in its diagonal form (what obfit uses, R/fitting.R:110)."""
 
     def __init__(self, a, b):
         super().__init__()
@@ -644,6 +648,22 @@ class lpdfvec(lpdf):
             self.gradhyp = self.lpdflist[0].gradhyp + self.lpdflist[1].gradhyp
         if self.compute_gradpara:     # concatenated like para
             self.gradpara = np.concatenate([self.lpdflist[0].gradpara, self.lpdflist[1].gradpara])
+        if self.domarg:
+            self._margadj()
+
+    def _margadj(self):
+        """Marginal adjustment, diagonal form (lpdfvec::buildhess fit.cpp:252-268 and
+        margadj :371-380): -1/2 sum log diag(H) and its hyp / para gradients."""
+        D = self.diaghess()
+        self.totdiaghess = D
+        self.val += float(-0.5 * np.sum(np.log(D)))
+        if self.compute_gradhyp:
+            dgh = self.lpdflist[0].diaghessgradhyp() + self.lpdflist[1].diaghessgradhyp()
+            self.gradhyp = self.gradhyp - 0.5 * np.sum(dgh / D[:, None], axis=0)
+        if self.compute_gradpara:
+            dgp = np.concatenate([self.lpdflist[0].diaghessgradpara(),
+                                  self.lpdflist[1].diaghessgradpara()], axis=1)
+            self.gradpara = self.gradpara - 0.5 * np.sum(dgp / D[:, None], axis=0)
 
     def hessmult(self, g):
         return self.lpdflist[0].hessmult(g) + self.lpdflist[1].hessmult(g)

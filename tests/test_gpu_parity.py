@@ -520,3 +520,57 @@ def test_squared_store_gradients_match_oracle():
     pr = ob.logpr_gauss(om_d, terms)
     want = -om_o.getlvar_gradhyp(terms) / (om_o.getvar(terms) * math.exp(2 * 6.0))[:, None]
     assert relerr(pr.diaghessgradhyp(), want) < 1e-12
+
+
+def test_lpdfvec_marginal_adjustment_diagonal_form():
+    """logpdf$domarg = TRUE as in obfit (R/fitting.R:108-110): val / gradhyp / gradpara of
+    lpdfvec(logpr_gauss, loglik_gauss) with the diagonal marginal adjustment
+    (fit.cpp:252-268, 371-380) against the oracle, and the hyp gradient against a
+    difference quotient of val through updatehyp + updateom."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25pow", "mat25", "mat25"]
+    rng = np.random.default_rng(31)
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 20))
+    x, y = O.synth_xy(42, 0, 400, kinds)
+    y = (y - y.mean()) / y.std(ddof=1)
+    terms = om_o.selectterms(40)          # levels <= 7: val stays smooth enough in hyp
+    coeff = 0.05 * rng.standard_normal(40)
+    pr = ob.logpr_gauss(om_d, terms)
+    lik = ob.loglik_gauss(om_d, terms, y, x)
+    lp = ob.lpdfvec(pr, lik)                      # obfit's order: prior first
+    lp.domarg = True
+    lp.compute_gradhyp = lp.compute_gradpara = True
+    rho, sigma = 4.5, -1.1
+    lp.updatepara([rho, sigma])
+    lp.update(coeff)
+    bo = O.OuterBase(om_o, x, dograd=True)
+    v, g, gh, gp = O.loglik_update(bo, terms, y, sigma, coeff)
+    pv, pg, pgh, pgp = O.logpr_update(om_o, terms, rho, coeff)
+    mv, mgh, mgp_lik, mgp_pr = O.margadj_diag(bo, terms, sigma, rho)
+    assert abs(lp.val - (v + pv + mv)) < 1e-10 * abs(v + pv + mv)
+    assert relerr(lp.gradhyp, gh + pgh + mgh) < 1e-8
+    assert relerr(lp.gradpara, np.array([pgp[0] + mgp_pr, gp[0] + mgp_lik])) < 1e-10
+    # difference quotient on the device (no shared rotation: own eigen-model throughout)
+    om = ob.outermod()
+    ob.setcovfs(om, kinds)
+    ob.setknot(om, knots_for(kinds, 20))
+    hyp0 = ob.gethyp(om)
+    pr2, lik2 = ob.logpr_gauss(om, terms), ob.loglik_gauss(om, terms, y, x)
+    lp2 = ob.lpdfvec(pr2, lik2)
+    lp2.domarg = True
+    lp2.compute_gradhyp = True
+    lp2.updatepara([rho, sigma])
+    lp2.update(coeff)
+    gh0 = lp2.gradhyp.copy()
+    # val carries ~1e-9 relative rounding noise from the high-level basis columns, so the
+    # quotient needs a step of 1e-4 (CPU oracle: 2e-5 agreement at 1e-4, 1e-3 at 1e-5)
+    eps, hd = 1e-4, rng.random(len(hyp0)) - 0.5
+    vals = []
+    for sgn in (1.0, -1.0):
+        om.updatehyp(hyp0 + sgn * eps * hd)
+        lp2.updateom()
+        lp2.update(coeff)
+        vals.append(lp2.val)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - gh0 @ hd) < 1e-3 * abs(fd)
