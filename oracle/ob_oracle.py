@@ -752,6 +752,38 @@ def logpr_update(om, terms, rho, coeff):
     return val, grad, gradhyp, gradpara
 
 
+def loglik_gda_update(ob, terms, y, para, coeff, dodiag=True):
+    """loglik_gda::buildstd + update + diaghess family (loglik_gda.cpp:117-235): returns a
+    dict with val, grad, gradhyp, gradpara, obssd, diaghess, diaghessgradhyp,
+    diaghessgradpara.  ob needs dograd."""
+    e0, e1 = math.exp(2 * para[0]), math.exp(2 * para[1])
+    rterms = ob_residvar(ob, terms)                                   # :221
+    obsvar = np.full(len(y), e0) + (e1 * rterms if dodiag else 0.0)   # :219-222
+    obssd = np.sqrt(obsvar)
+    n, nh = len(y), len(ob.om.hypmatch)
+    ge = ob_residvar_gradhyp(ob, terms) * ((e1 * 0.5) / obssd)[:, None] if dodiag \
+        else np.zeros((n, nh))                                        # :224-227
+    gp = np.zeros((n, 2))
+    gp[:, 0] = e0 / obssd                                             # :229
+    if dodiag:
+        gp[:, 1] = e1 * rterms / obssd                                # :230
+    yhat, yhatge = ob_mm_gradhyp(ob, terms, coeff)                    # :122-125
+    r = (yhat - y) / obssd
+    r2 = np.square(r)
+    out = {"val": float(-0.5 * np.sum(r2) - np.sum(np.log(obssd))), "obssd": obssd}
+    r = -r / obssd
+    r2 = r2 / obssd
+    out["grad"] = ob_tmm(ob, terms, r)
+    out["gradhyp"] = r @ yhatge + (r2 @ ge - (1 / obssd) @ ge if dodiag else 0.0)   # :139-145
+    out["gradpara"] = r2 @ gp - (1 / obssd) @ gp                                     # :147-150
+    w = 1 / np.square(obssd)
+    out["diaghess"] = ob_sqtmm(ob, terms, w)                                         # :177-180
+    out["diaghessgradhyp"] = ob_sqtmm_gradhyp(ob, terms, w) + \
+        (ob_sqtmm(ob, terms, ge * (w * (-2 / obssd))[:, None]) if dodiag else 0.0)  # :187-200
+    out["diaghessgradpara"] = ob_sqtmm(ob, terms, gp * (w * (-2 / obssd))[:, None])  # :207-214
+    return out
+
+
 def margadj_diag(ob, terms, sigma, rho):
     """Marginal adjustment of lpdfvec in its diagonal form (lpdfvec::buildhess,
     fit.cpp:252-268, added by margadj :371-380): with the total Hessian diagonal

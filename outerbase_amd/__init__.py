@@ -9,11 +9,13 @@ obfit/obpred harness (R/fitting.R).  There is no CPU fallback.
 from . import _lib
 from ._lib import ObhipError, device_count
 from .obmod import (covf, covf_mat25, covf_mat25ang, covf_mat25pow, gethyp, getpara, hypnames,
-                    listcov, loglik_gauss, loglik_std, logpr_gauss, lpdf, lpdfvec, outerbase,
-                    outermod, predictor, setcovfs, setknot)
+                    listcov, loglik_gauss, loglik_gda, loglik_std, logpr_gauss, lpdf, lpdfvec,
+                    outerbase, outermod, predictor, setcovfs, setknot)
+from .fitting import BFGS_lpdf, BFGS_std, obfit, obpred
 
 __all__ = [
     "ObhipError", "device_count", "covf", "covf_mat25", "covf_mat25ang", "covf_mat25pow", "gethyp",
-    "getpara", "hypnames", "listcov", "loglik_gauss", "loglik_std", "logpr_gauss", "lpdf",
-    "lpdfvec", "outerbase", "outermod", "predictor", "setcovfs", "setknot",
+    "getpara", "hypnames", "listcov", "loglik_gauss", "loglik_gda", "loglik_std", "logpr_gauss",
+    "lpdf", "lpdfvec", "outerbase", "outermod", "predictor", "setcovfs", "setknot",
+    "BFGS_lpdf", "BFGS_std", "obfit", "obpred",
 ]

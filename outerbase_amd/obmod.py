@@ -462,6 +462,50 @@ class lpdf:
             return -np.inf
         return float(-0.5 * np.sum((parap - self.para0) ** 2 / self.paravar))  # fit.cpp:133-139
 
+    def paralpdf_grad(self, parap):
+        parap = np.asarray(parap, dtype=np.float64)
+        if len(parap) != len(self.para0):
+            return np.zeros(len(self.para))
+        return -(parap - self.para0) / self.paravar                            # fit.cpp:146-157
+
+    def optcg(self, tol, maxepch):
+        """lpdf::optcg (fit.cpp:37-96), generic form: diagonally preconditioned CG on
+        update / hessmult / diaghess of this object (the n-passes run on the device through
+        those methods, the p-vector algebra here).  lpdfvec overrides it with the
+        device-resident loop when the likelihood has one noise level."""
+        self.fullhess = False
+        self.compute_gradhyp = self.compute_gradpara = False
+        if len(self.coeff) != self.nterms:
+            self.coeff = np.zeros(self.nterms)
+        coeff = np.array(self.coeff, dtype=np.float64)
+        self.update(coeff)
+        m = self.diaghess()
+        if not np.all(np.isfinite(m)) and not np.all(np.isfinite(self.grad)):
+            self.val = -np.inf
+            return
+        rm = self.grad / m
+        pv = rm.copy()
+        q = self.hessmult(pv)
+        valdiff = 10.0
+        self.cgiters = 0
+        for _ in range(int(maxepch)):
+            num = float(np.sum(self.grad * rm))
+            if num < tol and valdiff < tol:
+                break
+            alpha = num / float(np.sum(q * pv))
+            coeff = coeff + alpha * pv
+            valo = self.val
+            self.update(coeff)
+            valdiff = self.val - valo
+            rm = self.grad / m
+            beta = -float(np.sum((alpha * q) * rm)) / num
+            pv = rm + beta * pv
+            q = self.hessmult(pv)
+            self.cgiters += 1
+        self.compute_gradhyp = self.compute_gradpara = True    # fit.cpp:87-93
+        self.update(coeff)
+        self.compute_gradhyp = self.compute_gradpara = False
+
 
 class logpr_gauss(lpdf):
     """src/lpdfs/logpr_gauss.cpp:41-158"""
@@ -583,6 +627,90 @@ class loglik_std(_loglik):
         return math.exp(-2 * self.para[0]) * G
 
 
+class loglik_gda(_loglik):
+    """src/lpdfs/loglik_gda.cpp:48-235: Gaussian likelihood whose per-observation variance
+    adds the residual variance of the truncated expansion (the diagonal adjustment,
+    field `dodiag`), composed from the device products (residvar, sqtmm, the *_gradhyp
+    family); the n-vectors live on the host as in the Rcpp module."""
+
+    def __init__(self, om, terms, y, x):
+        super().__init__(om, terms, y, x)
+        self.para0 = np.array([0.5 * math.log(0.01 * rvar(self.y)), 0.0])   # :58-60
+        self.paravar = np.array([4.0, 4.0])
+        self.paranames = ["noisescale", "lik.coeffscale"]
+        self.para = self.para0.copy()
+        self.dodiag = True
+        self._redostd = True
+
+    def updateom(self):
+        super().updateom()
+        self._redostd = True
+
+    def updatepara(self, para):
+        super().updatepara(para)
+        self._redostd = True
+
+    def updateterms(self, terms):
+        super().updateterms(terms)
+        self._redostd = True
+
+    def _buildstd(self):              # :215-235
+        if not self._redostd:
+            return
+        e0, e1 = math.exp(2 * self.para[0]), math.exp(2 * self.para[1])
+        rterms = self.ob.residvar(self._t)
+        obsvar = np.full(len(self.y), e0)
+        if self.dodiag:
+            obsvar = obsvar + e1 * rterms
+        self.obssd = np.sqrt(obsvar)
+        if self.dodiag:
+            self.obssd_gradhyp = self.ob.residvar_gradhyp(self._t) * ((e1 * 0.5) / self.obssd)[:, None]
+        self.obssd_gradpara = np.zeros((len(self.y), 2))
+        self.obssd_gradpara[:, 0] = e0 / self.obssd
+        if self.dodiag:
+            self.obssd_gradpara[:, 1] = e1 * rterms / self.obssd
+        self._redostd = False
+
+    def update(self, coeff):          # :117-153
+        self.coeff = np.array(coeff, dtype=np.float64)
+        self.yhat = self.ob.matmul(self._t, self.coeff)
+        self._buildstd()
+        r = (self.yhat - self.y) / self.obssd
+        r2 = np.square(r)
+        self.val = float(-0.5 * np.sum(r2) - np.sum(np.log(self.obssd)))
+        r = -r / self.obssd
+        r2 = r2 / self.obssd
+        self.grad = self.ob.tmatmul(self._t, r)
+        if self.compute_gradhyp:
+            self.gradhyp = r @ self.ob.matmul_gradhyp(self._t, self.coeff)
+            if self.dodiag:
+                self.gradhyp = self.gradhyp + r2 @ self.obssd_gradhyp \
+                    - (1.0 / self.obssd) @ self.obssd_gradhyp
+        if self.compute_gradpara:
+            self.gradpara = r2 @ self.obssd_gradpara - (1.0 / self.obssd) @ self.obssd_gradpara
+
+    def hessmult(self, g):            # :160-169
+        v = self.ob.matmul(self._t, np.asarray(g, dtype=np.float64))
+        return self.ob.tmatmul(self._t, v / np.square(self.obssd))
+
+    def diaghess(self):               # :177-180
+        self._buildstd()
+        return self.ob.sqtmm(self._t, 1.0 / np.square(self.obssd))
+
+    def diaghessgradhyp(self):        # :187-200
+        self._buildstd()
+        temp = 1.0 / np.square(self.obssd)
+        lh = self.ob.sqtmm_gradhyp(self._t, temp)
+        if self.dodiag:
+            lh = lh + self.ob.sqtmm(self._t, self.obssd_gradhyp * (temp * (-2.0 / self.obssd))[:, None])
+        return lh
+
+    def diaghessgradpara(self):       # :207-214
+        self._buildstd()
+        temp = (1.0 / np.square(self.obssd)) * (-2.0 / self.obssd)
+        return self.ob.sqtmm(self._t, self.obssd_gradpara * temp[:, None])
+
+
 def _gram_host(ob, t):
     """B^T B through the device Gram kernel, returned to the host."""
     import torch
@@ -609,8 +737,10 @@ class lpdfvec(lpdf):
         self.terms = self.loglik.terms
         self.nterms = self.loglik.nterms
         self.para = np.concatenate([a.para, b.para])
+        self.para0 = np.concatenate([a.para0, b.para0])
+        self.paravar = np.concatenate([a.paravar, b.paravar])
         self.paranames = a.paranames + b.paranames
-        self.domarg = False
+        self.domarg = True            # fit.h:98 (field domargadj)
         self.coeff = np.zeros(self.nterms)
         self.totdiaghess = None
         self.tothess = None
@@ -651,11 +781,24 @@ class lpdfvec(lpdf):
         if self.domarg:
             self._margadj()
 
-    def _margadj(self):
-        """Marginal adjustment, diagonal form (lpdfvec::buildhess fit.cpp:252-268 and
-        margadj :371-380): -1/2 sum log diag(H) and its hyp / para gradients."""
-        D = self.diaghess()
+    def _settotdiaghess(self, D):     # lpdfvec::settotdiaghess: the members see it too
         self.totdiaghess = D
+        for o in self.lpdflist:
+            o.totdiaghess = D
+
+    def _margadj(self):
+        """Marginal adjustment (lpdfvec::buildhess fit.cpp:252-299, margadj :371-380):
+        -1/2 sum log diag(H) and its hyp / para gradients in the diagonal form; with the
+        full Hessian (after optnewton) -1/2 log det H for val -- its hyp / para gradients
+        need the n x p x nhyp design cube (hessgradhyp) and are not built."""
+        if self.fullhess:
+            if self.compute_gradhyp or self.compute_gradpara:
+                raise NotImplementedError("marginal adjustment gradients with the full Hessian")
+            sign, logdet = np.linalg.slogdet(self.hess())
+            self.val += float(-0.5 * logdet)
+            return
+        D = self.diaghess()
+        self._settotdiaghess(D)
         self.val += float(-0.5 * np.sum(np.log(D)))
         if self.compute_gradhyp:
             dgh = self.lpdflist[0].diaghessgradhyp() + self.lpdflist[1].diaghessgradhyp()
@@ -687,11 +830,19 @@ class lpdfvec(lpdf):
         diagH = np.zeros(p)
         call("obhip_fit_newton", self.loglik.ob._h, self.loglik._t._h, self.loglik.om._h,
              ptr(self.loglik.y), sigma, rho, ptr(theta), ptr(diagH), None)
-        self.totdiaghess = diagH
+        self._settotdiaghess(diagH)
+        # fit.cpp:122-128 evaluates gradhyp / gradpara at the solution; with the marginal
+        # adjustment on, those need the full-Hessian gradient cubes (see _margadj), so
+        # they are only produced for domarg = False
+        self.compute_gradhyp = self.compute_gradpara = not self.domarg
         self.update(theta)
+        self.compute_gradhyp = self.compute_gradpara = False
 
     def optcg(self, tol, maxepch):
-        """lpdf::optcg (fit.cpp:37-96): matrix-free PCG on the device."""
+        """lpdf::optcg (fit.cpp:37-96): matrix-free PCG, device-resident for a likelihood
+        with one noise level; the generic loop of lpdf.optcg otherwise (loglik_gda)."""
+        if isinstance(self.loglik, loglik_gda):
+            return lpdf.optcg(self, tol, maxepch)
         self.fullhess = False
         sigma, rho = self._sigma_rho()
         p = self.nterms
@@ -702,9 +853,11 @@ class lpdfvec(lpdf):
         call("obhip_fit_cg", self.loglik.ob._h, self.loglik._t._h, self.loglik.om._h,
              ptr(self.loglik.y), sigma, rho, float(tol), int(maxepch), ptr(theta), C.byref(iters),
              ptr(diagH), C.byref(val))
-        self.totdiaghess = diagH
+        self._settotdiaghess(diagH)
         self.cgiters = iters.value
+        self.compute_gradhyp = self.compute_gradpara = True    # fit.cpp:87-93
         self.update(theta)
+        self.compute_gradhyp = self.compute_gradpara = False
 
 
 class predictor:
@@ -719,7 +872,7 @@ class predictor:
         self.coeff = np.array(lik.coeff if len(lik.coeff) == lik.nterms
                               else np.zeros(lik.nterms), dtype=np.float64)
         self.sigma = float(lik.para[0])
-        td = getattr(logpdf, "totdiaghess", None)
+        td = getattr(logpdf, "totdiaghess", None)   # lpdfvec::settotdiaghess hands it to its members
         self.coeffvar = (1.0 / np.asarray(td)) if td is not None else np.zeros(lik.nterms)
         self.x = lik.x
         self._mean = None

@@ -481,6 +481,7 @@ def test_lpdf_gradhyp_matches_oracle():
     lik = ob.loglik_gauss(om_d, terms, y, x)
     pr = ob.logpr_gauss(om_d, terms)
     lp = ob.lpdfvec(lik, pr)
+    lp.domarg = False                     # the adjustment has its own test below
     lp.compute_gradhyp = lp.compute_gradpara = True
     lp.updatepara([-1.3, 5.0])
     lp.update(coeff)
@@ -574,3 +575,59 @@ def test_lpdfvec_marginal_adjustment_diagonal_form():
         vals.append(lp2.val)
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - gh0 @ hd) < 1e-3 * abs(fd)
+
+
+def test_loglik_gda_matches_oracle():
+    """loglik_gda (src/lpdfs/loglik_gda.cpp:117-235) composed from the device products: val,
+    grad, gradhyp, gradpara and the diaghess family against the oracle; the generic optcg
+    on lpdfvec(logpr, loglik_gda) reaches a stationary point of the combined objective."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25pow", "mat25", "mat25"]
+    rng = np.random.default_rng(2)
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 20))
+    x, y = O.synth_xy(42, 0, 300, kinds)
+    y = (y - y.mean()) / y.std(ddof=1)
+    terms = om_o.selectterms(30)
+    coeff = 0.05 * rng.standard_normal(30)
+    para = np.array([-1.2, 0.3])
+    lik = ob.loglik_gda(om_d, terms, y, x)
+    assert np.allclose(lik.para0, [0.5 * math.log(0.01 * np.var(y, ddof=1)), 0.0])
+    lik.updatepara(para)
+    lik.compute_gradhyp = lik.compute_gradpara = True
+    lik.update(coeff)
+    r = O.loglik_gda_update(O.OuterBase(om_o, x, dograd=True), terms, y, para, coeff)
+    assert abs(lik.val - r["val"]) < 1e-10 * abs(r["val"])
+    assert relerr(lik.grad, r["grad"]) < 1e-9
+    assert relerr(lik.gradhyp, r["gradhyp"]) < 1e-8
+    assert relerr(lik.gradpara, r["gradpara"]) < 1e-10
+    assert relerr(lik.diaghess(), r["diaghess"]) < 1e-10
+    assert relerr(lik.diaghessgradhyp(), r["diaghessgradhyp"]) < 1e-8
+    assert relerr(lik.diaghessgradpara(), r["diaghessgradpara"]) < 1e-10
+    pr = ob.logpr_gauss(om_d, terms)
+    lp = ob.lpdfvec(pr, lik)
+    lp.optcg(1e-12, 500)
+    assert np.max(np.abs(lp.grad)) < 1e-5 * np.max(np.abs(lik.ob.tmatmul(terms, y)))
+    assert lp.gradhyp.shape == (4,) and lp.gradpara.shape == (3,)
+
+
+def test_obfit_and_obpred_end_to_end():
+    """obfit / obpred (R/fitting.R:27-155) on the Borehole function (R/testfuncs.R:32-46) as
+    the package's own examples use it: hyper-parameters move, predictions on fresh points
+    are far better than the mean predictor, variances are positive."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    rng = np.random.default_rng(42)
+    x = rng.random((400, 8))
+    y = O.borehole8d(x)
+    obmodel = ob.obfit(x, y, numb=100, seed=1)
+    xt = rng.random((200, 8))
+    pred = ob.obpred(obmodel, xt)
+    yt = O.borehole8d(xt)
+    rmse = math.sqrt(np.mean((pred["mean"] - yt) ** 2))
+    assert rmse < 0.05 * np.std(yt)
+    assert np.all(pred["var"] > 0)
+    assert np.max(np.abs(ob.gethyp(obmodel["om"]))) > 1e-3     # moved away from the defaults
+    # standardised residuals are of order one (var is a calibrated scale, not decoration)
+    z = (pred["mean"] - yt) / np.sqrt(pred["var"])
+    assert 0.05 < np.sqrt(np.mean(z ** 2)) < 20

@@ -7,6 +7,8 @@ import ctypes as C
 import os
 import subprocess
 
+import math
+
 import numpy as np
 import pytest
 
@@ -222,3 +224,54 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "ob_oracle" not in txt and "oracle/" not in txt, f
+
+
+# ---- the R-side harness restated (outerbase_amd/fitting.py) -----------------------------------
+def test_bfgs_std_minimises_and_steps_away_from_infinite_values():
+    """BFGS_std (R/outersupport.R:30-171): a smooth bowl with an infinite wall next to
+    the start, as hyper-parameter priors produce (".lpdfwrapper" returns Inf, :224)."""
+    from outerbase_amd.fitting import BFGS_std
+
+    # the reference stops once the predicted decrease st.g is above -length(g)/4 twice
+    # (:133-137), a rule made for log-likelihoods of many observations: scale accordingly
+    sc = 1e6
+
+    def funcw(pl, shift):
+        u = np.concatenate([pl["hyp"], pl["para"]]) - shift
+        if pl["hyp"][0] > 1.5:                       # outside the box
+            return {"val": math.inf, "gval": None}
+        val = sc * float(np.sum(u ** 2) + 0.1 * np.sum(u ** 4))
+        g = sc * (2 * u + 0.4 * u ** 3)
+        return {"val": val, "gval": {"hyp": g[:2], "para": g[2:]}}
+
+    shift = np.array([1.0, -0.5, 0.3])
+    start = {"hyp": np.array([1.4, 1.0]), "para": np.array([2.0])}
+    out = BFGS_std(funcw, start, lr=0.5, shift=shift)
+    got = np.concatenate([out["parlist"]["hyp"], out["parlist"]["para"]])
+    assert np.max(np.abs(got - shift)) < 2e-3
+    assert out["optid"]["val"] < 1e-6 * funcw(start, shift)["val"]
+    assert out["B"].shape == (3, 3)
+
+
+def test_fitting_helpers_and_argument_checks():
+    """.genknotlist / .getsteps / .checkcov and obfit's stop() conditions
+    (R/fitting.R:30-53, 158-195)."""
+    from outerbase_amd import fitting as F
+    rng = np.random.default_rng(0)
+    x = rng.random((200, 4))
+    kn = F._genknotlist([40, 16, 70, 5], x)
+    ref = O.genknotlist([40, 16, 70, 5], x)
+    assert all(np.allclose(a, b) for a, b in zip(kn, ref))
+    assert F._getsteps(4096, 1e6, 1e4) == O.getsteps(4096, 1e6, 1e4) == 35
+    with pytest.raises(ValueError, match="do not align"):
+        F.obfit(x, np.zeros(10))
+    with pytest.raises(ValueError, match="dimension 2"):
+        F.obfit(x[:, :2], np.zeros(200))
+    with pytest.raises(ValueError, match="twice the dimension"):
+        F.obfit(x, np.zeros(200), numb=7)
+    with pytest.raises(ValueError, match="listcov"):
+        F.obfit(x, rng.random(200), numb=20, covnames=["nope"] * 4)
+    with pytest.raises(ValueError, match="exceed limits"):
+        F.obfit(x * 3, rng.random(200), numb=20)
+    with pytest.raises(ValueError, match="too small"):
+        F.obfit(0.5 + 0.01 * x, rng.random(200), numb=20)
