@@ -295,6 +295,15 @@ int obhip_predict(const obhip_model *m, const obhip_terms *t,
                   const double *theta, const double *x, uint64_t n,
                   uint64_t ldx, double *mean, const double *coeffvar,
                   double sigma, double *var);
+/* predr_std (loglik_std.cpp:218-256), the predictor of the loglik_std model with the full
+ * posterior covariance of the coefficients: mean = B theta, var_i = b_i^T inv(H) b_i +
+ * e^{2 sigma} (:249-256; the reference uses arma::inv, here H = L L^T and one triangular
+ * solve).  H: total Hessian, p x p symmetric (host); var may be NULL (then H may be too).
+ * The triangular solve is rocBLAS dtrsm, loaded at run time (OBHIP_ERR_STATE without it). */
+int obhip_predict_std(const obhip_model *m, const obhip_terms *t, const double *theta,
+                      const double *H, const double *x, uint64_t n, uint64_t ldx, double *mean,
+                      double sigma, double *var);
+
 /* ---- synthetic workload of BASELINE.md section 3 (benchmark input) ------ */
 /* rows [row0, row0+n) of the counter-based SplitMix64 stream; d_x is n x d
  * column-major, d_y n (raw, not standardised).  kinds: d entries. */

@@ -316,22 +316,27 @@ bool gram_panel_supports(const obhip_basis &b, const obhip_terms &t) {
   return need <= free_b / 2;
 }
 
+// d_B: n_pad x p_pad doubles, row-major (= column-major p_pad x n_pad); padding rows are 0
+int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B) {
+  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  if (t.Mu > 280) return fail(OBHIP_ERR_INVALID, "terms touch too many basis columns for the LDS tile");
+  ProfScope ps("materialize_B");
+  switch (t.W / 2) {
+    case 1: return run_materialize<1>(b, t, d_B);
+    case 2: return run_materialize<2>(b, t, d_B);
+    case 3: return run_materialize<3>(b, t, d_B);
+    case 4: return run_materialize<4>(b, t, d_B);
+    default: return run_materialize<0>(b, t, d_B);
+  }
+}
+
 int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
   obhip_basis &b = const_cast<obhip_basis &>(bc);
   if (!gram_panel_supports(b, t))
     return fail(OBHIP_ERR_INVALID, "materialised-B Gram kernel: not enough free HBM for n x p doubles");
   const size_t need = (size_t)b.n_pad * t.p_pad;
   if (b.bmat.n < need) OB_TRY(b.bmat.alloc(need));
-  {
-    ProfScope ps("materialize_B");
-    switch (t.W / 2) {
-      case 1: OB_TRY(run_materialize<1>(b, t, b.bmat.p)); break;
-      case 2: OB_TRY(run_materialize<2>(b, t, b.bmat.p)); break;
-      case 3: OB_TRY(run_materialize<3>(b, t, b.bmat.p)); break;
-      case 4: OB_TRY(run_materialize<4>(b, t, b.bmat.p)); break;
-      default: OB_TRY(run_materialize<0>(b, t, b.bmat.p)); break;
-    }
-  }
+  OB_TRY(launch_materialize_rows(b, t, b.bmat.p));
   // OBHIP_GRAM_DBG=1: print one block's s_memtime / s_memrealtime span (clock and
   // matrix-pipe cycles per chunk under load)
   const bool dbg = getenv("OBHIP_GRAM_DBG") && atoi(getenv("OBHIP_GRAM_DBG")) != 0;

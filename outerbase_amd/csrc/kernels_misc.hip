@@ -145,6 +145,29 @@ int launch_synth(uint64_t seed, uint64_t row0, uint64_t n, uint64_t d, const int
   return 0;
 }
 
+// out[i] = add + sum_{k < p} Z[k + i * ld]^2, one wave per column
+__global__ void __launch_bounds__(256)
+k_colnorm2(const double *__restrict__ Z, uint64_t ld, uint64_t p, uint64_t n, double add,
+           double *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const double *z = Z + i * ld;
+  double s = 0.0;
+  for (uint64_t k = lane; k < p; k += 64) s = fma(z[k], z[k], s);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) out[i] = s + add;
+}
+
+int launch_colnorm2(const double *d_Z, uint64_t ld, uint64_t p, uint64_t n, double add,
+                    double *d_out) {
+  hipLaunchKernelGGL(k_colnorm2, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, cur_stream(), d_Z, ld,
+                     p, n, add, d_out);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_sum_sumsq(const double *d_v, uint64_t n, double *d_out2, double *d_part /* 2*kRedBlocks */) {
   const int nblk = (int)std::min<uint64_t>(kRedBlocks, std::max<uint64_t>(1, (n + 255) / 256));
   hipLaunchKernelGGL(k_sum2_stage1, dim3(nblk), dim3(256), 0, cur_stream(), d_v, n, d_part);

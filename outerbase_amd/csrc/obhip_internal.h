@@ -242,6 +242,8 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a,
 int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G);
 void set_gram_backend(int b);
 int get_gram_backend();
+// kernels_gram_panel.hip
+int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B);
 // kernels_grad.hip
 int ensure_gradbasis(obhip_basis &b);
 int ensure_gradbasis_sq(obhip_basis &b);

@@ -861,7 +861,9 @@ class lpdfvec(lpdf):
 
 
 class predictor:
-    """interfaceR.cpp:725-731; pred_gauss (loglik_gauss.cpp:196-227)."""
+    """interfaceR.cpp:725-731: the predictor that belongs to the likelihood (lpdf::pred):
+    pred_gauss (loglik_gauss.cpp:196-227), predr_std (loglik_std.cpp:218-256) with the full
+    posterior covariance, pred_gda (loglik_gda.cpp:247-281)."""
 
     def __init__(self, logpdf):
         lik = logpdf.loglik if isinstance(logpdf, lpdfvec) else logpdf
@@ -869,11 +871,20 @@ class predictor:
             raise ValueError("cannot produce a predictor from this obj.")  # fit.h:53
         self.om = lik.om
         self._t = lik._t
+        self._lik = lik
         self.coeff = np.array(lik.coeff if len(lik.coeff) == lik.nterms
                               else np.zeros(lik.nterms), dtype=np.float64)
+        self.para = np.array(lik.para, dtype=np.float64)
         self.sigma = float(lik.para[0])
-        td = getattr(logpdf, "totdiaghess", None)   # lpdfvec::settotdiaghess hands it to its members
-        self.coeffvar = (1.0 / np.asarray(td)) if td is not None else np.zeros(lik.nterms)
+        # lpdfvec::settotdiaghess / settothess hand the Hessian pieces to the members
+        td = getattr(logpdf, "totdiaghess", None)
+        if td is None:
+            td = getattr(lik, "totdiaghess", None)
+        self.totdiaghess = None if td is None else np.asarray(td, dtype=np.float64)
+        self.coeffvar = (1.0 / self.totdiaghess) if td is not None else np.zeros(lik.nterms)
+        self.tothess = None
+        if isinstance(lik, loglik_std) and isinstance(logpdf, lpdfvec) and logpdf.fullhess:
+            self.tothess = _fmat(logpdf.hess())      # loglik_std.cpp:226-227 (didfulltothess)
         self.x = lik.x
         self._mean = None
         self._var = None
@@ -888,9 +899,26 @@ class predictor:
         n = x.shape[0]
         self._mean = np.empty(n)
         self._var = np.empty(n)
-        cv = _f64(self.coeffvar)
-        call("obhip_predict", self.om._h, self._t._h, ptr(_f64(self.coeff)), ptr(x), n, n,
-             ptr(self._mean), ptr(cv), self.sigma, ptr(self._var))
+        lik = self._lik
+        if isinstance(lik, loglik_std) and self.tothess is not None:
+            # predr_std::var with coeffcov = inv(tothess), loglik_std.cpp:249-256
+            call("obhip_predict_std", self.om._h, self._t._h, ptr(_f64(self.coeff)),
+                 ptr(self.tothess), ptr(x), n, n, ptr(self._mean), self.sigma, ptr(self._var))
+        else:
+            # pred_gauss::var = B^2 (1 / totdiaghess) + e^{2 sigma} (loglik_gauss.cpp:224-225);
+            # predr_std without a full Hessian puts totdiaghess ITSELF on the diagonal of
+            # coeffcov (loglik_std.cpp:228-232) -- kept as the reference has it
+            cv = self.coeffvar
+            if isinstance(lik, loglik_std):
+                cv = self.totdiaghess if self.totdiaghess is not None else np.zeros(lik.nterms)
+            cv = _f64(cv)
+            call("obhip_predict", self.om._h, self._t._h, ptr(_f64(self.coeff)), ptr(x), n, n,
+                 ptr(self._mean), ptr(cv), self.sigma, ptr(self._var))
+            if isinstance(lik, loglik_gda) and lik.dodiag:
+                # pred_gda::var adds the residual variance of the truncated expansion
+                # (loglik_gda.cpp:276-281)
+                obn = outerbase(self.om, x, levelcap=self._t.maxlevels())
+                self._var = self._var + math.exp(2 * self.para[1]) * obn.residvar(self._t)
         self.x = x
 
     def mean(self):

@@ -45,10 +45,13 @@ def test_device_reproduces_golden(path):
     pred = ob.predictor(lp)
     pred.update(g["xnew"])
     assert relerr(pred.mean(), g["mean"]) < 1e-6          # north_star tolerance
-    assert relerr(pred.var(), g["var_gauss"]) < 1e-9
+    assert relerr(pred.var(), g["var_std"]) < 1e-7         # predr_std: b^T inv(H) b + e^{2 sigma}
     likg = ob.loglik_gauss(om, terms, g["y"], g["x"])
     lpg = ob.lpdfvec(ob.logpr_gauss(om, terms), likg)
     lpg.optcg(0.0, 12)   # tol 0: exactly 12 iterations on both sides
     assert lpg.cgiters == int(g["cg_iters"])
     assert relerr(lpg.totdiaghess, g["diagH"]) < 2e-9
     assert relerr(likg.yhat, g["B"] @ g["theta_cg"]) < 1e-6
+    predg = ob.predictor(lpg)                              # pred_gauss: B^2 / diag(H) + e^{2 sigma}
+    predg.update(g["xnew"])
+    assert relerr(predg.var(), g["var_gauss"]) < 1e-9

@@ -295,9 +295,9 @@ def test_newton_fit_and_predict(kinds, n, p):
     mean_o = O.predict_mean(om_o, terms, theta_o, xnew)
     assert relerr(pred.mean(), mean_o) < 1e-6
     assert relerr(lik.yhat, O.ob_mm(bo, terms, theta_o)) < 1e-6
-    # pred_gauss variance from the diagonal of H (loglik_gauss.cpp:223-227)
-    var_o = O.predict_var_gauss(om_o, terms, np.diag(H_o), O.default_sigma(y), xnew)
-    assert relerr(pred.var(), var_o) < 1e-9
+    # predr_std variance with the full posterior covariance (loglik_std.cpp:249-256)
+    var_o = O.predict_var_std(om_o, terms, H_o, O.default_sigma(y), xnew)
+    assert relerr(pred.var(), var_o) < 1e-7
     # Newton stationarity: H theta = e^{-2 sigma} B^T y
     rhs = math.exp(-2 * O.default_sigma(y)) * O.ob_tmm(bo, terms, y)
     assert relerr(H_o @ lp.coeff, rhs) < 1e-7
@@ -631,3 +631,53 @@ def test_obfit_and_obpred_end_to_end():
     # standardised residuals are of order one (var is a calibrated scale, not decoration)
     z = (pred["mean"] - yt) / np.sqrt(pred["var"])
     assert 0.05 < np.sqrt(np.mean(z ** 2)) < 20
+
+
+def test_predr_std_full_posterior_covariance():
+    """predictor of lpdfvec(loglik_std, logpr_gauss) after optnewton = predr_std with
+    coeffcov = inv(tothess): var = rowsum((B C) % B) + e^{2 sigma} (loglik_std.cpp:218-256),
+    against the oracle; without the full Hessian the reference's diagonal fallback."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25pow", "mat25", "mat25ang", "mat25"]
+    rng = np.random.default_rng(77)
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 24))
+    x, y = O.synth_xy(42, 0, 700, kinds)
+    y = (y - y.mean()) / y.std(ddof=1)
+    terms = om_o.selectterms(130)
+    lik = ob.loglik_std(om_d, terms, y, x)
+    lp = ob.lpdfvec(lik, ob.logpr_gauss(om_d, terms))
+    lp.optnewton()
+    xnew, _ = O.synth_xy(43, 0, 333, kinds)
+    pred = ob.predictor(lp)
+    pred.update(xnew)
+    bo = O.OuterBase(om_o, x)
+    sigma = float(lik.para[0])
+    theta_o, H_o = O.fit_newton(bo, terms, y, sigma=sigma)
+    assert relerr(pred.mean(), O.predict_mean(om_o, terms, theta_o, xnew)) < 1e-9
+    want = O.predict_var_std(om_o, terms, H_o, sigma, xnew)
+    assert relerr(pred.var(), want) < 1e-8
+    assert np.all(pred.var() > math.exp(2 * sigma))
+
+
+def test_pred_gda_adds_the_residual_variance():
+    """pred_gda::var (loglik_gda.cpp:276-281) = B^2 coeffvar + e^{2 para0} + e^{2 para1} residvar."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25", "mat25pow", "mat25"]
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 20))
+    x, y = O.synth_xy(42, 0, 300, kinds)
+    y = (y - y.mean()) / y.std(ddof=1)
+    terms = om_o.selectterms(40)
+    lik = ob.loglik_gda(om_d, terms, y, x)
+    lp = ob.lpdfvec(ob.logpr_gauss(om_d, terms), lik)
+    lp.optcg(1e-10, 200)
+    pred = ob.predictor(lik)
+    xnew, _ = O.synth_xy(43, 0, 111, kinds)
+    pred.update(xnew)
+    bn = O.OuterBase(om_o, xnew)
+    cv = 1.0 / lp.totdiaghess
+    want = O.ob_sqmm(bn, terms, cv) + math.exp(2 * lik.para[0]) + \
+        math.exp(2 * lik.para[1]) * O.ob_residvar(bn, terms)
+    assert relerr(pred.var(), want) < 1e-9
+    assert relerr(pred.mean(), O.ob_mm(bn, terms, lp.coeff)) < 1e-9
