@@ -49,6 +49,7 @@ int basis_setup(obhip_basis *b, const obhip_model *m, const int64_t *levelcap) {
   if (levelcap) cap.assign(levelcap, levelcap + m->d);
   OB_TRY(b->md.build(*m, cap));
   b->grad.reset();  // the gradient basis follows the value basis
+  b->bmat_terms = 0;  // and so does the materialised design matrix
   const uint64_t tiles = b->n_pad / kTileRows;
   OB_TRY(b->bm.alloc(tiles * b->md.Mc * kTileRows));
   OB_TRY(b->scale.alloc(b->n_pad));

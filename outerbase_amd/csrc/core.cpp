@@ -269,6 +269,8 @@ int obhip_terms_create(obhip_terms **out, const obhip_model *m,
   if (!out || !m || !terms || p == 0) return fail(OBHIP_ERR_INVALID, "terms_create: bad argument");
   if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
   obhip_terms *t = new obhip_terms();
+  static uint64_t next_uid = 1;
+  t->uid = next_uid++;
   t->p = p;
   t->d = m->d;
   t->lev.resize(p * m->d);

@@ -16,6 +16,8 @@
 // dimension pointing at the gradient block carries level t_kl + 1; the value kernels
 // k_mm / k_tmm (kernels_prod.hip) then compute the gradient products unchanged, one pass
 // per hyper-parameter.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
 #include "obhip_internal.h"
 #include "device_common.h"
 
@@ -215,6 +217,8 @@ int ensure_gradbasis(obhip_basis &b) {
     OB_HIP(hipStreamSynchronize(cur_stream()));  // dhypst is a local
   }
   g->model_version = m.version;
+  static uint64_t next_id = 1;
+  g->id = next_id++;
   b.grad = std::move(g);
   return 0;
 }
@@ -276,6 +280,326 @@ int ensure_gradbasis_sq(obhip_basis &b) {
   OB_HIP(hipStreamSynchronize(cur_stream()));  // dpair is a local
   g.gbsq = std::move(sq);
   return 0;
+}
+
+namespace {
+
+// ---- all hyper-parameters of B a in ONE pass -------------------------------------------------
+// With P_k the term product (without basescale), E_kj the product without factor j and, per
+// row, delta[h, t] = ge[h, t] - basemat[col(dim h, t)] ge[h, 0] the identities above give
+//   out_gradhyp[i, h] = s_i ( ge[h, 0] . sum_k a_k P_k  +  sum_{k, j: dim(j) = dim(h)} a_k E_kj delta[h, t_kj] )
+// so a term touches only the hyper-parameters of its own non-zero dimensions.  Same tiling
+// as k_mm (lane = row, 64-row tile in LDS, term tables in registers broadcast by
+// v_readlane); the gradient columns are staged behind the basemat columns and the nhyp
+// per-row accumulators live in LDS (ds_add_f64, every lane its own address).
+// Table per term and slot: w0 = tile column of ge[h, t] | tile column of ge[h, 0] << 16,
+// w1 = h | second hyper-parameter of the dimension << 8 | columns per block << 16 | valid << 31.
+template <int W2>
+__global__ void __launch_bounds__(256)
+k_mmge(const double *__restrict__ bm, const double *__restrict__ scale,
+       const uint32_t *__restrict__ ucol, int Mu, uint64_t Mtot, int Mc, int Mge,
+       const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ getab, int p,
+       const double *__restrict__ a, const int *__restrict__ ge0col, int nhyp,
+       double *__restrict__ out, double *__restrict__ outge, uint64_t n) {
+  constexpr int W = 2 * W2;
+  extern __shared__ double lds[];
+  double *gl = lds + (size_t)Mu * kTileRows;     // gradient columns [Mge][64]
+  double *accL = gl + (size_t)Mge * kTileRows;   // [nhyp][64]
+  double *red = accL + (size_t)nhyp * kTileRows; // [4][64]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t tile = blockIdx.x;
+  const uint64_t row = tile * kTileRows + lane;
+  const double *tile_in = bm + tile * Mtot * kTileRows;
+  stage_tile<false, false>(lds, tile_in, ucol, Mu, threadIdx.x, 256);
+  for (int e = threadIdx.x; e < Mge * kTileRows; e += 256) gl[e] = tile_in[(size_t)Mc * kTileRows + e];
+  for (int e = threadIdx.x; e < nhyp * kTileRows; e += 256) accL[e] = 0.0;
+  __syncthreads();
+  const double s = row < n ? scale[row] : 0.0;
+  double acc = 0.0;
+  const int ngroups = (p + 63) / 64;
+  for (int g = wave; g < ngroups; g += 4) {
+    const int k0 = g * 64, cnt = min(64, p - k0);
+    uint32_t cw[W2], gw[2 * W];
+    load_cw(cw, colsw, k0 + lane);
+#pragma unroll
+    for (int q = 0; q < 2 * W; ++q) gw[q] = getab[(size_t)(k0 + lane) * 2 * W + q];
+    const double av = a[min(k0 + lane, p - 1)];
+    for (int t = 0; t < cnt; ++t) {
+      const double at = readlane_f64(av, t);
+      double bv[W];
+#pragma unroll
+      for (int w = 0; w < W2; ++w) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cw[w], t);
+        bv[2 * w] = lds[(c & 0xffffu) * kTileRows + lane];
+        bv[2 * w + 1] = lds[(c >> 16) * kTileRows + lane];
+      }
+      // exclusive products: E[w] = prod_{q != w} bv[q]
+      double pre[W], E[W];
+      pre[0] = at;
+#pragma unroll
+      for (int w = 1; w < W; ++w) pre[w] = pre[w - 1] * bv[w - 1];
+      double suf = 1.0;
+#pragma unroll
+      for (int w = W - 1; w >= 0; --w) {
+        E[w] = pre[w] * suf;   // a_k included
+        suf *= bv[w];
+      }
+      acc = fma(pre[W - 1], bv[W - 1], acc);
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)gw[2 * w + 1], t);
+        if (w1 >> 31) {
+          const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)gw[2 * w], t);
+          const int ct = w0 & 0xffffu, c0 = w0 >> 16, h = w1 & 0xffu;
+          const double dl = fma(-bv[w], gl[c0 * kTileRows + lane], gl[ct * kTileRows + lane]);
+          unsafeAtomicAdd(&accL[h * kTileRows + lane], E[w] * dl);
+          if ((w1 >> 8) & 1u) {
+            const int nc = (w1 >> 16) & 0x7fffu;
+            const double d2 =
+                fma(-bv[w], gl[(c0 + nc) * kTileRows + lane], gl[(ct + nc) * kTileRows + lane]);
+            unsafeAtomicAdd(&accL[(h + 1) * kTileRows + lane], E[w] * d2);
+          }
+        }
+      }
+    }
+  }
+  red[wave * kTileRows + lane] = acc;
+  __syncthreads();
+  const double tot = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+  if (row < n) {
+    if (wave == 0 && out) out[row] = tot * s;
+    for (int h = wave; h < nhyp; h += 4)
+      outge[(uint64_t)h * n + row] = s * fma(gl[ge0col[h] * kTileRows + lane], tot, accL[h * kTileRows + lane]);
+  }
+}
+
+// per term and slot the two table words of k_mmge (host)
+void build_getab(const obhip_terms &t, const obhip_basis &b, const obhip_gradbasis &g,
+                 std::vector<uint32_t> &tab) {
+  const obhip_model &m = *b.model;
+  const uint64_t W = t.W, d = t.d;
+  tab.assign(t.p_pad * W * 2, 0u);
+  const uint64_t Mc = b.md.Mc;
+  for (uint64_t k = 0; k < t.p; ++k) {
+    uint64_t w = 0;
+    for (uint64_t l = 0; l < d; ++l) {
+      const uint32_t lv = t.lev[k * d + l];
+      if (lv == 0) continue;
+      const uint64_t h = m.hypst[l], nh = m.hypst[l + 1] - m.hypst[l];
+      const uint32_t c0 = (uint32_t)(g.hyps_h[h].gecol - Mc);  // gradient-tile column of ge[h, 0]
+      const uint32_t nc = (uint32_t)b.md.dims_h[l].ncol;
+      tab[(k * W + w) * 2] = (c0 + lv) | (c0 << 16);
+      tab[(k * W + w) * 2 + 1] = (uint32_t)h | ((nh > 1 ? 1u : 0u) << 8) | (nc << 16) | (1u << 31);
+      ++w;
+    }
+  }
+}
+
+template <int W2>
+int run_mmge(const obhip_basis &gb, const obhip_basis &b, obhip_terms &t, const uint32_t *getab,
+             const int *ge0col, int nhyp, const double *d_a, double *d_out, double *d_outge) {
+  const int Mge = (int)(gb.md.Mc - b.md.Mc);
+  const size_t lds = ((size_t)t.Mu + Mge + nhyp + 4) * kTileRows * sizeof(double);
+  OB_HIP(hipFuncSetAttribute((const void *)k_mmge<W2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds));
+  hipLaunchKernelGGL(k_mmge<W2>, dim3((unsigned)(b.n_pad / kTileRows)), dim3(256), lds, cur_stream(),
+                     gb.bm.p, gb.scale.p, t.ucol.p, (int)t.Mu, gb.md.Mc, (int)b.md.Mc, Mge,
+                     (const uint32_t *)t.cols.p, getab, (int)t.p, d_a, ge0col, nhyp, d_out, d_outge,
+                     b.n);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// out_gradhyp for every hyper-parameter in one pass; false if the tile does not fit the LDS
+// (the caller then falls back to one k_mm pass per hyper-parameter through the views)
+bool mmge_fits(const obhip_basis &b, const obhip_terms &t) {
+  if (!b.grad) return false;
+  const uint64_t Mge = b.grad->gb->md.Mc - b.md.Mc;
+  return t.W <= 8 && (t.Mu + Mge + b.model->nhyp() + 4) * kTileRows * sizeof(double) <= 152 * 1024;
+}
+
+int launch_mmge(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a, double *d_out,
+                double *d_outge) {
+  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  obhip_gradbasis &g = *b.grad;
+  const int nhyp = (int)b.model->nhyp();
+  if (t.getab_version != g.id || !t.getab.p) {
+    std::vector<uint32_t> tab;
+    build_getab(t, b, g, tab);
+    OB_TRY(t.getab.upload(tab.data(), tab.size()));
+    std::vector<int> c0(nhyp);
+    for (int h = 0; h < nhyp; ++h) c0[h] = g.hyps_h[h].gecol - (int)b.md.Mc;
+    OB_TRY(t.ge0col.upload(c0.data(), c0.size()));
+    t.getab_version = g.id;
+  }
+  const obhip_basis &src = squared ? *g.gbsq : *g.gb;
+  ProfScope ps(squared ? "sqmm_gradhyp" : "mm_gradhyp");
+  switch (t.W / 2) {
+    case 1: return run_mmge<1>(src, b, t, t.getab.p, t.ge0col.p, nhyp, d_a, d_out, d_outge);
+    case 2: return run_mmge<2>(src, b, t, t.getab.p, t.ge0col.p, nhyp, d_a, d_out, d_outge);
+    case 3: return run_mmge<3>(src, b, t, t.getab.p, t.ge0col.p, nhyp, d_a, d_out, d_outge);
+    default: return run_mmge<4>(src, b, t, t.getab.p, t.ge0col.p, nhyp, d_a, d_out, d_outge);
+  }
+}
+
+namespace {
+
+// ---- transposed products: the dense part of every hyper-parameter in one streaming pass ---------
+// out_gradhyp[k, h] = sum_i w_i dB_ik/dhyp_h.  For the terms WITHOUT hyper-parameter h's
+// dimension that is sum_i (w_i ge[h, 0]_i) B_ik: a tall-skinny product of the materialised
+// row-major design matrix (obhip_basis::bmat, as the Gram kernel uses it) with an n x nhyp
+// weight matrix -- one pass over B for all hyper-parameters, HBM-bound.  The terms that do
+// have the dimension are recomputed by k_tmm on a view restricted to them (grad_view_sparse).
+// Thread = 4 consecutive terms x NH hyper-parameters; the row weights sit in lane registers
+// (lane = row of the 64-row tile) and are broadcast with v_readlane.  SQ: squared stores
+// (B^2; the level-0 gradient column of the squared store is 2 ge[h, 0]).
+constexpr int kNHB = 20;  // hyper-parameters per pass
+
+template <bool SQ>
+__global__ void __launch_bounds__(512)
+k_bt_times_u(const double *__restrict__ Bmat, uint64_t p_pad, const double *__restrict__ gtile,
+             uint64_t Mtot, const int *__restrict__ ge0abs, int nhyp, int h0,
+             const double *__restrict__ a, uint64_t n, uint64_t ntiles, uint64_t tiles_per_split,
+             double *__restrict__ part) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint64_t k4 = (uint64_t)blockIdx.y * 2048 + (uint64_t)tid * 4;
+  if (k4 >= p_pad) return;
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+  double acc[4][kNHB];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int h = 0; h < kNHB; ++h) acc[q][h] = 0.0;
+  int gcol[kNHB];
+#pragma unroll
+  for (int h = 0; h < kNHB; ++h) gcol[h] = h0 + h < nhyp ? ge0abs[h0 + h] : -1;
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    const uint64_t row = tile * kTileRows + lane;
+    const double av = row < n ? a[row] : 0.0;
+    double uw[kNHB];
+#pragma unroll
+    for (int h = 0; h < kNHB; ++h)
+      uw[h] = gcol[h] >= 0 ? av * gtile[(tile * Mtot + (uint64_t)gcol[h]) * kTileRows + lane] : 0.0;
+    const double *brow = Bmat + tile * kTileRows * p_pad + k4;
+#pragma unroll 4
+    for (int r = 0; r < kTileRows; ++r) {
+      const double4 v4 = *(const double4 *)(brow + (uint64_t)r * p_pad);
+      double v[4] = {v4.x, v4.y, v4.z, v4.w};
+      if (SQ) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] *= v[q];
+      }
+#pragma unroll
+      for (int h = 0; h < kNHB; ++h) {
+        const double wh = readlane_f64(uw[h], r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q][h] = fma(v[q], wh, acc[q][h]);
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < kNHB; ++h)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      part[((uint64_t)blockIdx.x * kNHB + h) * p_pad + k4 + q] = acc[q][h];
+}
+
+// D[h0 + h][k] = sum of the row-split partials
+__global__ void k_btu_reduce(const double *__restrict__ part, int nsplit, uint64_t p_pad, int p,
+                             int nh, double *__restrict__ out /* [nh][p] */) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y;
+  if (k >= (uint64_t)p || h >= nh) return;
+  double s = 0.0;
+  for (int r = 0; r < nsplit; ++r) s += part[((uint64_t)r * kNHB + h) * p_pad + k];
+  out[(uint64_t)h * p + k] = s;
+}
+
+}  // namespace
+
+// d_out: p x nhyp column-major (device) = sum_i a_i ge[h, 0]_i B_ik (SQ: squared stores)
+int launch_bt_times_ge0(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a,
+                        double *d_out) {
+  OB_TRY(ensure_bmat(b, t));
+  obhip_gradbasis &g = *b.grad;
+  const obhip_basis &src = squared ? *g.gbsq : *g.gb;
+  const int nhyp = (int)b.model->nhyp();
+  std::vector<int> c0(nhyp);
+  for (int h = 0; h < nhyp; ++h) c0[h] = g.hyps_h[h].gecol;  // absolute column in the combined array
+  DevBuf<int> dc0;
+  OB_TRY(dc0.upload(c0.data(), c0.size()));
+  const uint64_t ntiles = b.n_pad / kTileRows;
+  const unsigned gy = (unsigned)((t.p_pad + 2047) / 2048);
+  uint64_t nsplit = std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 1024 / gy));
+  const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  double *part = nullptr;
+  OB_TRY(b.workspace(nsplit * kNHB * t.p_pad * sizeof(double), (void **)&part));
+  ProfScope ps(squared ? "sqtmm_gradhyp_dense" : "tmm_gradhyp_dense");
+  for (int h0 = 0; h0 < nhyp; h0 += kNHB) {
+    const int nh = std::min(kNHB, nhyp - h0);
+    if (squared)
+      hipLaunchKernelGGL(k_bt_times_u<true>, dim3((unsigned)nsplit, gy), dim3(512), 0, cur_stream(),
+                         b.bmat.p, t.p_pad, src.bm.p, src.md.Mc, dc0.p, nhyp, h0, d_a, b.n, ntiles,
+                         tps, part);
+    else
+      hipLaunchKernelGGL(k_bt_times_u<false>, dim3((unsigned)nsplit, gy), dim3(512), 0, cur_stream(),
+                         b.bmat.p, t.p_pad, src.bm.p, src.md.Mc, dc0.p, nhyp, h0, d_a, b.n, ntiles,
+                         tps, part);
+    hipLaunchKernelGGL(k_btu_reduce, dim3((unsigned)((t.p + 255) / 256), (unsigned)nh), dim3(256), 0,
+                       cur_stream(), part, (int)nsplit, t.p_pad, (int)t.p, nh,
+                       d_out + (uint64_t)h0 * t.p);
+  }
+  OB_HIP(hipGetLastError());
+  OB_HIP(hipStreamSynchronize(cur_stream()));  // dc0 is a local
+  return 0;
+}
+
+// View restricted to the terms whose level in hyper-parameter h's dimension is non-zero;
+// idx receives their term indices.  nullptr when there is none.
+obhip_terms *grad_view_sparse(obhip_terms &t, const obhip_basis &b, uint64_t h,
+                              const std::vector<uint32_t> **idx) {
+  const obhip_model &m = *b.model;
+  const uint64_t nh = m.nhyp(), d = t.d, de = d + nh;
+  if (t.ge_sviews.size() != nh) {
+    t.ge_sviews.clear();
+    t.ge_sviews.resize(nh);
+    t.ge_sidx.assign(nh, {});
+    for (uint64_t hh = 0; hh < nh; ++hh) {
+      const uint64_t l = m.hypmatch[hh];
+      std::vector<uint32_t> &ix = t.ge_sidx[hh];
+      for (uint64_t k = 0; k < t.p; ++k)
+        if (t.lev[k * d + l] > 0) ix.push_back((uint32_t)k);
+      if (ix.empty()) continue;
+      auto v = std::make_unique<obhip_terms>();
+      v->p = ix.size();
+      v->d = de;
+      v->lev.assign(v->p * de, 0);
+      v->maxlev.assign(de, 0);
+      for (uint64_t j = 0; j < v->p; ++j) {
+        const uint64_t k = ix[j];
+        uint64_t nnz = 1;
+        for (uint64_t q = 0; q < d; ++q) {
+          const uint32_t lv = q == l ? 0u : t.lev[k * d + q];
+          v->lev[j * de + q] = lv;
+          v->maxlev[q] = std::max<int64_t>(v->maxlev[q], lv);
+          nnz += lv > 0;
+        }
+        const uint32_t gl = t.lev[k * d + l] + 1;
+        v->lev[j * de + d + hh] = gl;
+        v->maxlev[d + hh] = std::max<int64_t>(v->maxlev[d + hh], gl);
+        v->nnz_total += nnz;
+        v->max_nnz = std::max(v->max_nnz, nnz);
+      }
+      t.ge_sviews[hh] = std::move(v);
+    }
+  }
+  *idx = &t.ge_sidx[h];
+  return t.ge_sviews[h].get();
 }
 
 // View of the terms for hyper-parameter h: dimension hypmatch[h] dropped, pseudo-dimension
@@ -364,6 +688,13 @@ int obhip_basis_mm_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const d
   DevBuf<double> da, dout;
   OB_TRY(da.upload(a, t.p));
   OB_TRY(dout.alloc(b.n));
+  if (mmge_fits(b, t)) {
+    DevBuf<double> dge;
+    OB_TRY(dge.alloc(b.n * b.model->nhyp()));
+    OB_TRY(launch_mmge(b, t, false, da.p, dout.p, dge.p));
+    if (out) OB_TRY(d2h(out, dout.p, b.n * sizeof(double)));
+    return d2h(out_gradhyp, dge.p, b.n * b.model->nhyp() * sizeof(double));
+  }
   if (out) {
     OB_TRY(launch_mm(b, t, da.p, dout.p, false));
     OB_TRY(d2h(out, dout.p, b.n * sizeof(double)));
@@ -374,6 +705,9 @@ int obhip_basis_mm_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const d
   }
   return 0;
 }
+
+static int tmm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a,
+                           double *out_gradhyp);
 
 // products on the squared stores: ob$sqmm_gradhyp / ob$sqtmm_gradhyp
 // (modandbase.cpp:798-809, 845-856)
@@ -388,11 +722,15 @@ static int sq_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const double
   DevBuf<double> da, dout;
   OB_TRY(da.upload(a, nin));
   OB_TRY(dout.alloc(nout));
+  if (!transposed && mmge_fits(b, t)) {
+    DevBuf<double> dge;
+    OB_TRY(dge.alloc(b.n * b.model->nhyp()));
+    OB_TRY(launch_mmge(b, t, true, da.p, nullptr, dge.p));
+    return d2h(out_gradhyp, dge.p, b.n * b.model->nhyp() * sizeof(double));
+  }
+  if (transposed) return tmm_gradhyp_all(b, t, true, da.p, out_gradhyp);
   for (uint64_t h = 0; h < b.model->nhyp(); ++h) {
-    if (transposed)
-      OB_TRY(launch_tmm(*b.grad->gbsq, *grad_view(t, b, h), da.p, dout.p, false));
-    else
-      OB_TRY(launch_mm(*b.grad->gbsq, *grad_view(t, b, h), da.p, dout.p, false));
+    OB_TRY(launch_mm(*b.grad->gbsq, *grad_view(t, b, h), da.p, dout.p, false));
     OB_TRY(d2h(out_gradhyp + h * nout, dout.p, nout * sizeof(double)));
   }
   return 0;
@@ -438,6 +776,38 @@ int obhip_basis_residvar_gradhyp(const obhip_basis *b, const obhip_terms *t, con
   return 0;
 }
 
+// out_gradhyp (host, p x nhyp) = sum_i a_i dB_ik/dhyp_h: one streaming pass over the design
+// matrix for the terms without the hyper-parameter's dimension, k_tmm on the restricted views
+// for those with it; one k_tmm pass per hyper-parameter when the design matrix does not fit
+static int tmm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a,
+                           double *out_gradhyp) {
+  const uint64_t nh = b.model->nhyp(), p = t.p;
+  const obhip_basis &src = squared ? *b.grad->gbsq : *b.grad->gb;
+  DevBuf<double> dout;
+  OB_TRY(dout.alloc(p * nh));
+  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  if (!gram_panel_supports(b, t)) {
+    for (uint64_t h = 0; h < nh; ++h) {
+      OB_TRY(launch_tmm(src, *grad_view(t, b, h), d_a, dout.p, false));
+      OB_TRY(d2h(out_gradhyp + h * p, dout.p, p * sizeof(double)));
+    }
+    return 0;
+  }
+  OB_TRY(launch_bt_times_ge0(b, t, squared, d_a, dout.p));
+  OB_TRY(d2h(out_gradhyp, dout.p, p * nh * sizeof(double)));
+  std::vector<double> tmp;
+  for (uint64_t h = 0; h < nh; ++h) {
+    const std::vector<uint32_t> *idx = nullptr;
+    obhip_terms *v = grad_view_sparse(t, b, h, &idx);
+    if (!v) continue;
+    OB_TRY(launch_tmm(src, *v, d_a, dout.p, false));
+    tmp.resize(idx->size());
+    OB_TRY(d2h(tmp.data(), dout.p, tmp.size() * sizeof(double)));
+    for (size_t j = 0; j < tmp.size(); ++j) out_gradhyp[h * p + (*idx)[j]] = tmp[j];
+  }
+  return 0;
+}
+
 int obhip_basis_tmm_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const double *a,
                             double *out, double *out_gradhyp) {
   OB_TRY(check_grad_args(bc, tc));
@@ -447,16 +817,12 @@ int obhip_basis_tmm_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const 
   OB_TRY(ensure_gradbasis(b));
   DevBuf<double> da, dout;
   OB_TRY(da.upload(a, b.n));
-  OB_TRY(dout.alloc(t.p));
   if (out) {
+    OB_TRY(dout.alloc(t.p));
     OB_TRY(launch_tmm(b, t, da.p, dout.p, false));
     OB_TRY(d2h(out, dout.p, t.p * sizeof(double)));
   }
-  for (uint64_t h = 0; h < b.model->nhyp(); ++h) {
-    OB_TRY(launch_tmm(*b.grad->gb, *grad_view(t, b, h), da.p, dout.p, false));
-    OB_TRY(d2h(out_gradhyp + h * t.p, dout.p, t.p * sizeof(double)));
-  }
-  return 0;
+  return tmm_gradhyp_all(b, t, false, da.p, out_gradhyp);
 }
 
 }  // extern "C"

@@ -330,13 +330,26 @@ int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B) {
   }
 }
 
+// b.bmat = row-major design matrix of (b, t); kept until the basis is rebuilt or other
+// terms need the buffer
+int ensure_bmat(obhip_basis &b, obhip_terms &t) {
+  if (b.bmat_terms == t.uid && t.uid != 0) return 0;
+  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  if (!gram_panel_supports(b, t))
+    return fail(OBHIP_ERR_INVALID, "not enough free HBM for the n x p design matrix");
+  const size_t need = (size_t)b.n_pad * t.p_pad;
+  if (b.bmat.n < need) OB_TRY(b.bmat.alloc(need));
+  b.bmat_terms = 0;
+  OB_TRY(launch_materialize_rows(b, t, b.bmat.p));
+  b.bmat_terms = t.uid;
+  return 0;
+}
+
 int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
   obhip_basis &b = const_cast<obhip_basis &>(bc);
   if (!gram_panel_supports(b, t))
     return fail(OBHIP_ERR_INVALID, "materialised-B Gram kernel: not enough free HBM for n x p doubles");
-  const size_t need = (size_t)b.n_pad * t.p_pad;
-  if (b.bmat.n < need) OB_TRY(b.bmat.alloc(need));
-  OB_TRY(launch_materialize_rows(b, t, b.bmat.p));
+  OB_TRY(ensure_bmat(b, t));
   // OBHIP_GRAM_DBG=1: print one block's s_memtime / s_memrealtime span (clock and
   // matrix-pipe cycles per chunk under load)
   const bool dbg = getenv("OBHIP_GRAM_DBG") && atoi(getenv("OBHIP_GRAM_DBG")) != 0;

@@ -152,6 +152,7 @@ struct ModelDev {
 
 // ---- terms --------------------------------------------------------------------
 struct obhip_terms {
+  uint64_t uid = 0;                   // unique per object (caches keyed by terms use it)
   uint64_t p = 0, d = 0;
   std::vector<uint32_t> lev;          // p x d row-major levels
   std::vector<int64_t> maxlev;        // d
@@ -166,6 +167,13 @@ struct obhip_terms {
   uint64_t p_pad = 0;
   // per hyper-parameter views for the gradient products (kernels_grad.hip)
   std::vector<std::unique_ptr<obhip_terms>> ge_views;
+  // the same restricted to the terms that HAVE the hyper-parameter's dimension, with
+  // their indices (transposed gradient products: the other terms come from one dense pass)
+  std::vector<std::unique_ptr<obhip_terms>> ge_sviews;
+  std::vector<std::vector<uint32_t>> ge_sidx;
+  obhip::DevBuf<uint32_t> getab;      // slot table of the one-pass gradient kernel k_mmge
+  obhip::DevBuf<int> ge0col;          // gradient-tile column of ge[h, 0] per hyper-parameter
+  uint64_t getab_version = ~0ull;
   // device view of the model capped at maxlev, for the fused predictor
   obhip::ModelDev pred_md;
   const obhip_model *pred_model = nullptr;
@@ -189,6 +197,7 @@ struct obhip_basis;
 // so that the ordinary product kernels can run on it with per-hyper-parameter term views.
 struct obhip_gradbasis {
   uint64_t model_version = ~0ull;
+  uint64_t id = 0;  // unique per build: tables derived from the column layout are keyed by it
   std::vector<obhip::GradHyp> hyps_h;
   obhip::DevBuf<obhip::GradHyp> hyps;
   obhip::DevBuf<double> rotg;  // per hyper-parameter [m][ncolp]
@@ -208,6 +217,7 @@ struct obhip_basis {
   obhip::DevBuf<char> work;     // scratch for split-reduction partials (grown on demand)
   obhip::DevBuf<double> bmat;   // row-major design matrix [n_pad][p_pad], staging of the
                                 // materialised-B Gram kernel (allocated on first use)
+  uint64_t bmat_terms = 0;      // uid of the terms bmat currently holds (0: none)
   obhip::DevBuf<uint32_t> gram_pairs;  // XCD-aware tile-pair order of that kernel
   int gram_pairs_nb = -1;
   std::unique_ptr<obhip_gradbasis> grad;  // built on first *_gradhyp call, dropped on rebuild
@@ -244,6 +254,8 @@ void set_gram_backend(int b);
 int get_gram_backend();
 // kernels_gram_panel.hip
 int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B);
+int ensure_bmat(obhip_basis &b, obhip_terms &t);  // b.bmat = design matrix of (b, t)
+bool gram_panel_supports(const obhip_basis &b, const obhip_terms &t);
 // kernels_grad.hip
 int ensure_gradbasis(obhip_basis &b);
 int ensure_gradbasis_sq(obhip_basis &b);
