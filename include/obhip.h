@@ -304,6 +304,15 @@ int obhip_predict_std(const obhip_model *m, const obhip_terms *t, const double *
                       const double *H, const double *x, uint64_t n, uint64_t ldx, double *mean,
                       double sigma, double *var);
 
+/* Marginal adjustment of lpdfvec(loglik_std, logpr_gauss) with the full Hessian
+ * (lpdfvec::buildhess, fit.cpp:270-299): val = -1/2 log det H, gradhyp[l] =
+ * -1/2 sum(dH/dhyp_l % inv(H)) (nhyp entries) and gradpara = {noisescale, coeffscale}
+ * parts (loglik_std.cpp:180-203, logpr_gauss.cpp:165-186).  H: total Hessian (host);
+ * gradhyp / gradpara may be NULL.  Uses rocBLAS dtrsm like obhip_predict_std. */
+int obhip_margadj_full(const obhip_basis *b, const obhip_terms *t, const obhip_model *m,
+                       const double *H, double sigma, double rho, double *val, double *gradhyp,
+                       double *gradpara);
+
 /* ---- synthetic workload of BASELINE.md section 3 (benchmark input) ------ */
 /* rows [row0, row0+n) of the counter-based SplitMix64 stream; d_x is n x d
  * column-major, d_y n (raw, not standardised).  kinds: d entries. */

@@ -801,6 +801,32 @@ def margadj_diag(ob, terms, sigma, rho):
             float(-0.5 * np.sum(dgp_lik / D)), float(-0.5 * np.sum(dgp_pr / D)))
 
 
+def margadj_full(ob, terms, sigma, rho):
+    """Marginal adjustment of lpdfvec with the full Hessian (lpdfvec::buildhess,
+    fit.cpp:270-299; loglik_std::hessgradhyp / hessgradpara loglik_std.cpp:180-203,
+    logpr_gauss::hessgradhyp / hessgradpara logpr_gauss.cpp:165-186):
+      val = -1/2 log det H,  gradhyp[l] = -1/2 sum(dH/dhyp_l % inv(H)),  same for para.
+    Returns (val, gradhyp, gradpara_loglik, gradpara_logpr); ob needs dograd."""
+    om = ob.om
+    B = ob_getmat(ob, terms)
+    Bge = ob_getmat_gradhyp(ob, terms)
+    prec = prior_prec(om, terms, rho)
+    e2 = math.exp(-2 * sigma)
+    H = e2 * (B.T @ B) + np.diag(prec)
+    heig, hvec = np.linalg.eigh(H)                       # :277-281
+    Hinv = (hvec / heig[None, :]) @ hvec.T
+    val = float(-0.5 * np.sum(np.log(heig)))             # :283
+    lv = om.getlvar_gradhyp(terms)
+    gh = np.zeros(Bge.shape[2])
+    for l in range(Bge.shape[2]):
+        S = e2 * (B.T @ Bge[:, :, l])
+        dH = S + S.T - np.diag(lv[:, l] * prec)          # loglik_std.cpp:185-189, logpr :168-171
+        gh[l] = -0.5 * np.sum(dH * Hinv)                 # fit.cpp:286-290
+    gp_lik = float(-0.5 * np.sum((-2 * e2 * (B.T @ B)) * Hinv))       # loglik_std.cpp:199-203
+    gp_pr = float(-0.5 * np.sum(-2 * prec * np.diag(Hinv)))           # logpr_gauss.cpp:181-186
+    return val, gh, gp_lik, gp_pr
+
+
 def fit_cg(ob, terms, y, sigma=None, rho=DEFAULT_RHO, tol=1e-10, maxit=100,
            coeff0=None):
     """lpdf::optcg on lpdfvec(logpr_gauss, loglik_gauss) (fit.cpp:37-96) with

@@ -168,6 +168,52 @@ int launch_colnorm2(const double *d_Z, uint64_t ld, uint64_t p, uint64_t n, doub
   return 0;
 }
 
+// out = sum_{i < n, k < p} A[k + i ld] B[k + i ld] (two stages, fixed order)
+__global__ void __launch_bounds__(256)
+k_dot_cols1(const double *__restrict__ A, const double *__restrict__ B, uint64_t ld, uint64_t p,
+            uint64_t n, double *__restrict__ part) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const double *a = A + i * ld, *b = B + i * ld;
+    for (uint64_t k = threadIdx.x; k < p; k += 256) s = fma(a[k], b[k], s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void k_dot_cols2(const double *__restrict__ part, int nblk, double *__restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += part[i];
+    *out = s;
+  }
+}
+__global__ void k_set_identity(double *__restrict__ A, uint64_t p) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < p * p) A[e] = (e / p == e % p) ? 1.0 : 0.0;
+}
+
+int launch_dot_cols(const double *d_A, const double *d_B, uint64_t ld, uint64_t p, uint64_t n,
+                    double *d_out, double *d_part /* 4096 doubles */) {
+  const int nblk = (int)std::min<uint64_t>(4096, std::max<uint64_t>(1, n));
+  hipLaunchKernelGGL(k_dot_cols1, dim3(nblk), dim3(256), 0, cur_stream(), d_A, d_B, ld, p, n, d_part);
+  hipLaunchKernelGGL(k_dot_cols2, dim3(1), dim3(64), 0, cur_stream(), d_part, nblk, d_out);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_set_identity(double *d_A, uint64_t p) {
+  hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((p * p + 255) / 256)), dim3(256), 0, cur_stream(),
+                     d_A, p);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_sum_sumsq(const double *d_v, uint64_t n, double *d_out2, double *d_part /* 2*kRedBlocks */) {
   const int nblk = (int)std::min<uint64_t>(kRedBlocks, std::max<uint64_t>(1, (n + 255) / 256));
   hipLaunchKernelGGL(k_sum2_stage1, dim3(nblk), dim3(256), 0, cur_stream(), d_v, n, d_part);

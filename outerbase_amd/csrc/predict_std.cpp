@@ -30,7 +30,7 @@ typedef int (*rb_dtrsm64_t)(rb_handle, int side, int uplo, int trans, int diag, 
                             const double *alpha, const double *A, int64_t lda, double *B,
                             int64_t ldb);
 // enum values of rocblas-types.h
-constexpr int kSideLeft = 141, kFillUpper = 121, kOpTranspose = 112, kDiagNonUnit = 131;
+constexpr int kSideLeft = 141, kFillUpper = 121, kOpNone = 111, kOpTranspose = 112, kDiagNonUnit = 131;
 
 struct RocBlas {
   void *lib = nullptr;
@@ -75,6 +75,9 @@ int rocblas(RocBlas **out) {
 namespace obhip {
 int launch_colnorm2(const double *d_Z, uint64_t ld, uint64_t p, uint64_t n, double add,
                     double *d_out);
+int launch_dot_cols(const double *d_A, const double *d_B, uint64_t ld, uint64_t p, uint64_t n,
+                    double *d_out, double *d_part);
+int launch_set_identity(double *d_A, uint64_t p);
 }
 
 extern "C" int obhip_predict_std(const obhip_model *m, const obhip_terms *tc, const double *theta,
@@ -125,5 +128,104 @@ extern "C" int obhip_predict_std(const obhip_model *m, const obhip_terms *tc, co
   OB_TRY(launch_colnorm2(dB.p, t.p_pad, p, n, std::exp(2.0 * sigma), dvar.p));
   OB_HIP(hipMemcpyAsync(var, dvar.p, n * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
   OB_HIP(hipStreamSynchronize(cur_stream()));
+  return 0;
+}
+
+
+// Marginal adjustment of lpdfvec(loglik_std, logpr_gauss) with the full Hessian
+// (lpdfvec::buildhess, fit.cpp:270-299): val = -1/2 log det H and
+//   gradhyp[l] = -1/2 tr(inv(H) dH/dhyp_l),  dH/dhyp_l = e^{-2 sigma}(B^T Bge_l + Bge_l^T B) - diag(lvarge_l prec)
+// (loglik_std.cpp:180-192, logpr_gauss.cpp:165-173), likewise for the two para.  The
+// reference forms the p x p x nhyp cubes and inv(H); here tr(inv(H) B^T Bge_l) =
+// sum_i (inv(H) b_i) . bge_l,i needs Y = inv(H) B^T once (two triangular solves on the
+// design matrix) and then one streaming dot product per hyper-parameter.
+extern "C" int obhip_margadj_full(const obhip_basis *bc, const obhip_terms *tc, const obhip_model *m,
+                                  const double *H, double sigma, double rho, double *val,
+                                  double *gradhyp, double *gradpara) {
+  if (!bc || !tc || !m || !H || !val) return fail(OBHIP_ERR_INVALID, "margadj_full: null argument");
+  if (bc->model != m) return fail(OBHIP_ERR_INVALID, "margadj_full: basis belongs to another model");
+  obhip_basis &b = *const_cast<obhip_basis *>(bc);
+  obhip_terms &t = *const_cast<obhip_terms *>(tc);
+  const uint64_t p = t.p, d = m->d, nh = m->nhyp();
+  // H = L L^T
+  DevBuf<double> dH, drhs, dth, dI, ddiag, dscal;
+  DevBuf<char> ws;
+  OB_TRY(dH.upload(H, p * p));
+  std::vector<double> zero(p, 0.0);
+  OB_TRY(drhs.upload(zero.data(), p));
+  OB_TRY(dth.alloc(p));
+  const uint64_t wsb = newton_workspace_bytes(p);
+  OB_TRY(ws.alloc(wsb));
+  OB_TRY(launch_newton_solve(p, dH.p, drhs.p, dth.p, ws.p, wsb));
+  std::vector<double> ld(p);
+  OB_HIP(hipMemcpy2DAsync(ld.data(), sizeof(double), dH.p, (p + 1) * sizeof(double), sizeof(double), p,
+                          hipMemcpyDeviceToHost, cur_stream()));
+  OB_HIP(hipStreamSynchronize(cur_stream()));
+  double logdet = 0;
+  for (double v : ld) logdet += 2.0 * std::log(v);
+  *val = -0.5 * logdet;
+  if (!gradhyp && !gradpara) return 0;
+
+  RocBlas *rb = nullptr;
+  OB_TRY(rocblas(&rb));
+  if (rb->set_stream(rb->h, cur_stream()) != 0) return fail(OBHIP_ERR_HIP, "rocblas_set_stream failed");
+  const double one = 1.0;
+  // diag(inv(H)) = squared column norms of L^{-1}
+  OB_TRY(dI.alloc(p * p));
+  OB_TRY(launch_set_identity(dI.p, p));
+  if (rb->dtrsm(rb->h, kSideLeft, kFillUpper, kOpTranspose, kDiagNonUnit, (int64_t)p, (int64_t)p, &one,
+                dH.p, (int64_t)p, dI.p, (int64_t)p) != 0)
+    return fail(OBHIP_ERR_HIP, "rocblas_dtrsm failed");
+  OB_TRY(ddiag.alloc(p));
+  OB_TRY(launch_colnorm2(dI.p, p, p, p, 0.0, ddiag.p));
+  std::vector<double> hinv(p);
+  OB_HIP(hipMemcpyAsync(hinv.data(), ddiag.p, p * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+  dI.release();
+  // Y = inv(H) B^T on a copy of the design matrix (column-major p_pad x n_pad)
+  OB_TRY(ensure_gradbasis(b));
+  OB_TRY(ensure_bmat(b, t));
+  const uint64_t nel = b.n_pad * t.p_pad;
+  DevBuf<double> dY, dG;
+  OB_TRY(dY.alloc(nel));
+  OB_HIP(hipMemcpyAsync(dY.p, b.bmat.p, nel * sizeof(double), hipMemcpyDeviceToDevice, cur_stream()));
+  if (rb->dtrsm(rb->h, kSideLeft, kFillUpper, kOpTranspose, kDiagNonUnit, (int64_t)p, (int64_t)b.n, &one,
+                dH.p, (int64_t)p, dY.p, (int64_t)t.p_pad) != 0 ||
+      rb->dtrsm(rb->h, kSideLeft, kFillUpper, kOpNone, kDiagNonUnit, (int64_t)p, (int64_t)b.n, &one, dH.p,
+                (int64_t)p, dY.p, (int64_t)t.p_pad) != 0)
+    return fail(OBHIP_ERR_HIP, "rocblas_dtrsm failed");
+  OB_TRY(dscal.alloc(nh + 1 + 4096));
+  double *part = dscal.p + nh + 1;
+  // tr(inv(H) B^T B) and tr(inv(H) B^T Bge_l)
+  OB_TRY(launch_dot_cols(b.bmat.p, dY.p, t.p_pad, p, b.n, dscal.p + nh, part));
+  OB_TRY(dG.alloc(nel));
+  for (uint64_t h = 0; h < nh; ++h) {
+    OB_TRY(launch_materialize_rows(*b.grad->gb, *grad_view(t, b, h), dG.p));
+    OB_TRY(launch_dot_cols(dG.p, dY.p, t.p_pad, p, b.n, dscal.p + h, part));
+  }
+  std::vector<double> q(nh + 1);
+  OB_HIP(hipMemcpyAsync(q.data(), dscal.p, (nh + 1) * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+  OB_HIP(hipStreamSynchronize(cur_stream()));
+  // prior parts (logpr_gauss.cpp:165-186): prec_k = 1 / (sd_k e^rho)^2
+  const double e2 = std::exp(-2.0 * sigma);
+  std::vector<double> prec(p);
+  for (uint64_t k = 0; k < p; ++k) {
+    double sv = 0;
+    for (uint64_t l = 0; l < d; ++l) sv += m->basisvar[m->knotptst[l] + t.lev[k * d + l]];
+    prec[k] = 1.0 / (std::exp(sv) * std::exp(2.0 * rho));
+  }
+  if (gradhyp)
+    for (uint64_t h = 0; h < nh; ++h) {
+      const uint64_t l = m->hypmatch[h];
+      double pr = 0;
+      for (uint64_t k = 0; k < p; ++k)
+        pr += hinv[k] * prec[k] * m->logbasisvar_gradhyp[m->gest[h] + t.lev[k * d + l]];
+      gradhyp[h] = -0.5 * (2.0 * e2 * q[h] - pr);
+    }
+  if (gradpara) {
+    gradpara[0] = e2 * q[nh];  // -1/2 tr(inv(H) (-2 e^{-2 sigma} G)), loglik_std.cpp:199-203
+    double pr = 0;
+    for (uint64_t k = 0; k < p; ++k) pr += hinv[k] * prec[k];
+    gradpara[1] = pr;          // -1/2 sum(-2 prec_k inv(H)_kk), logpr_gauss.cpp:181-186
+  }
   return 0;
 }

@@ -789,13 +789,24 @@ class lpdfvec(lpdf):
     def _margadj(self):
         """Marginal adjustment (lpdfvec::buildhess fit.cpp:252-299, margadj :371-380):
         -1/2 sum log diag(H) and its hyp / para gradients in the diagonal form; with the
-        full Hessian (after optnewton) -1/2 log det H for val -- its hyp / para gradients
-        need the n x p x nhyp design cube (hessgradhyp) and are not built."""
+        full Hessian (after optnewton) -1/2 log det H and -1/2 tr(inv(H) dH)."""
         if self.fullhess:
-            if self.compute_gradhyp or self.compute_gradpara:
-                raise NotImplementedError("marginal adjustment gradients with the full Hessian")
-            sign, logdet = np.linalg.slogdet(self.hess())
-            self.val += float(-0.5 * logdet)
+            # -1/2 log det H and -1/2 tr(inv(H) dH) on the device (obhip_margadj_full)
+            lik, pr = self.loglik, self.logpr
+            nh = len(lik.om.grad_layout()[0])
+            H = _fmat(self.hess())
+            val = C.c_double(0)
+            gh, gp = np.zeros(nh), np.zeros(2)
+            want_g = self.compute_gradhyp or self.compute_gradpara
+            call("obhip_margadj_full", lik.ob._h, lik._t._h, lik.om._h, ptr(H), float(lik.para[0]),
+                 float(pr.para[0]), C.byref(val), ptr(gh) if want_g else None,
+                 ptr(gp) if want_g else None)
+            self.val += val.value
+            if self.compute_gradhyp:
+                self.gradhyp = self.gradhyp + gh
+            if self.compute_gradpara:
+                order = [gp[0] if o is lik else gp[1] for o in self.lpdflist]
+                self.gradpara = self.gradpara + np.array(order)
             return
         D = self.diaghess()
         self._settotdiaghess(D)
@@ -831,10 +842,7 @@ class lpdfvec(lpdf):
         call("obhip_fit_newton", self.loglik.ob._h, self.loglik._t._h, self.loglik.om._h,
              ptr(self.loglik.y), sigma, rho, ptr(theta), ptr(diagH), None)
         self._settotdiaghess(diagH)
-        # fit.cpp:122-128 evaluates gradhyp / gradpara at the solution; with the marginal
-        # adjustment on, those need the full-Hessian gradient cubes (see _margadj), so
-        # they are only produced for domarg = False
-        self.compute_gradhyp = self.compute_gradpara = not self.domarg
+        self.compute_gradhyp = self.compute_gradpara = True    # fit.cpp:122-128
         self.update(theta)
         self.compute_gradhyp = self.compute_gradpara = False
 

@@ -681,3 +681,30 @@ def test_pred_gda_adds_the_residual_variance():
         math.exp(2 * lik.para[1]) * O.ob_residvar(bn, terms)
     assert relerr(pred.var(), want) < 1e-9
     assert relerr(pred.mean(), O.ob_mm(bn, terms, lp.coeff)) < 1e-9
+
+
+def test_full_hessian_marginal_adjustment_after_optnewton():
+    """optnewton on lpdfvec(loglik_std, logpr_gauss) with the marginal adjustment on (the
+    default): val, gradhyp and gradpara include -1/2 log det H and -1/2 tr(inv(H) dH)
+    (fit.cpp:122-128, 270-299), against the oracle."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25pow", "mat25", "mat25ang"]
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 20))
+    x, y = O.synth_xy(42, 0, 350, kinds)
+    y = (y - y.mean()) / y.std(ddof=1)
+    terms = om_o.selectterms(45)
+    lik = ob.loglik_std(om_d, terms, y, x)
+    pr = ob.logpr_gauss(om_d, terms)
+    lp = ob.lpdfvec(lik, pr)
+    assert lp.domarg
+    lp.optnewton()
+    sigma, rho = float(lik.para[0]), float(pr.para[0])
+    bo = O.OuterBase(om_o, x, dograd=True)
+    theta, _ = O.fit_newton(bo, terms, y, sigma=sigma, rho=rho)
+    v, g, gh, gp = O.loglik_update(bo, terms, y, sigma, theta)
+    pv, pg, pgh, pgp = O.logpr_update(om_o, terms, rho, theta)
+    mv, mgh, mgl, mgp = O.margadj_full(bo, terms, sigma, rho)
+    assert abs(lp.val - (v + pv + mv)) < 1e-9 * abs(v + pv + mv)
+    assert relerr(lp.gradhyp, gh + pgh + mgh) < 1e-7
+    assert relerr(lp.gradpara, np.array([gp[0] + mgl, pgp[0] + mgp])) < 1e-8
