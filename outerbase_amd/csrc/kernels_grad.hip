@@ -14,8 +14,17 @@
 // (basemat columns, then per hyper-parameter the gradient columns of levels 0..cap) and
 // per hyper-parameter a *view* of the terms in which dimension l is dropped and a pseudo-
 // dimension pointing at the gradient block carries level t_kl + 1; the value kernels
-// k_mm / k_tmm (kernels_prod.hip) then compute the gradient products unchanged, one pass
-// per hyper-parameter.
+// k_mm / k_tmm / getmat (kernels_prod.hip) then compute gradient products unchanged.
+//
+// Who computes what:
+//   getmat_gradhyp            getmat on the view, one pass per hyper-parameter
+//   matmul / sqmm _gradhyp    k_mmge: all hyper-parameters in one pass (a term only touches
+//                             the hyper-parameters of its own non-zero dimensions)
+//   tmatmul / sqtmm _gradhyp  k_bt_times_u: one streaming pass over the materialised design
+//                             matrix for the terms without the hyper-parameter's dimension,
+//                             + k_tmm on views restricted to the terms that have it
+//   fallback (tiles too large for the LDS, design matrix too large for the HBM): k_mm /
+//   k_tmm on the full views, one pass per hyper-parameter
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "obhip_internal.h"
