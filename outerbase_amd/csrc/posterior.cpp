@@ -1,15 +1,20 @@
-// predr_std (src/lpdfs/loglik_std.cpp:218-256): prediction of the loglik_std model with the
-// posterior covariance of the coefficients,
-//   mean = B theta,   var_i = b_i^T C b_i + e^{2 sigma},   C = inv(total Hessian)
-// (SURVEY.md 8f-2).  The reference forms C with arma::inv (:227) and
-// rowsum((B C) % B) (:251-255); here H = L L^T is factorised by the library's own Cholesky
-// (kernels_chol.hip) and var_i = || L^{-1} b_i ||^2 + e^{2 sigma}: one triangular solve with
-// n right-hand sides on the row-major design matrix of the new points (which is exactly
-// the column-major p x n matrix B^T), then a column norm.
+// Posterior-covariance quantities of the loglik_std model (SURVEY.md 8f-2 and the
+// full-Hessian part of 8f-4), both built on H = L L^T from the library's own Cholesky
+// (kernels_chol.hip) and on the row-major design matrix, which is exactly the column-major
+// p x n matrix B^T:
 //
-// The triangular solve is a plain library call (rocBLAS dtrsm, p^2 n flop); rocBLAS is
-// loaded at run time so that the hot path neither links nor needs it.  Every other step
-// (basis, design matrix, Cholesky, norms) is this library's own HIP code.
+//   obhip_predict_std   predr_std (src/lpdfs/loglik_std.cpp:218-256): mean = B theta,
+//                       var_i = b_i^T inv(H) b_i + e^{2 sigma} = || L^{-1} b_i ||^2 + e^{2 sigma}
+//                       (the reference forms inv(tothess), :227, and rowsum((B C) % B), :251-255)
+//   obhip_margadj_full  lpdfvec::buildhess with the full Hessian (src/fit.cpp:270-299):
+//                       -1/2 log det H and -1/2 tr(inv(H) dH) for every hyper-parameter and
+//                       parameter, from Y = inv(H) B^T and streaming dot products instead of
+//                       the reference's p x p x nhyp cubes
+//
+// The triangular solves with n right-hand sides are plain library calls (rocBLAS dtrsm,
+// p^2 n flop each); rocBLAS is loaded at run time so that the hot path neither links nor
+// needs it.  Every other step (basis, design matrices, Cholesky, norms, dot products) is
+// this library's own HIP code.
 #include <dlfcn.h>
 
 #include <cmath>
