@@ -121,7 +121,7 @@ __device__ __forceinline__ void potrf_cols(std::integer_sequence<int, Cs...>, do
 
 __global__ void __launch_bounds__(256)
 k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict__ Wt, int pw, int p,
-              int j0, int *__restrict__ info) {
+              int j0, int *__restrict__ info, double *__restrict__ Ljj) {
   __shared__ __attribute__((aligned(16))) double Lt[NB * LT];  // Lt[c][k] = L[k][c], 0 for k < c
   __shared__ double P[NB * LDP];    // diagonal block; later X (solved rows), per wave 16 rows
   __shared__ double Ap[NB * LDP];   // panel rows
@@ -178,11 +178,11 @@ k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict
   __syncthreads();  // Lt, dinv, Ap complete; P (diagonal block) is free
 
   if (blockIdx.x == 0) {
-    // write L_jj (lower triangle) back
-    for (int e = tid; e < NB * NB; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      if (r < jb && c <= r) H[(size_t)(j0 + r) * p + j0 + c] = Lt[c * LT + r];
-    }
+    // L_jj goes to a scratch block, NOT into H: the other workgroups of this launch read the
+    // diagonal block of H to re-factorise it, and with more workgroups than the GPU holds
+    // at once (p >= 16384 on 256 CUs) late ones would see it half overwritten.  The next
+    // launch in the stream (k_chol_update or a copy) moves it into place.
+    for (int e = tid; e < NB * NB; e += 256) Ljj[e] = (e & 63) <= (e >> 6) ? Lt[(e & 63) * LT + (e >> 6)] : 0.0;
     return;
   }
 
@@ -266,11 +266,14 @@ constexpr int UP = 128 + 16;  // LDS pitch of a staged panel row (doubles)
 
 __global__ void __launch_bounds__(256)
 k_chol_update(double *__restrict__ H, double *__restrict__ z, const double *__restrict__ Wt, int pw,
-              int p, int j0, int nt, int npairs) {
+              int p, int j0, int nt, int npairs, const double *__restrict__ Ljj) {
   __shared__ __attribute__((aligned(16))) double Sa[NB * UP];
   __shared__ __attribute__((aligned(16))) double Sb[NB * UP];
   const int t0 = j0 + NB;
   if ((int)blockIdx.x >= npairs) {
+    if ((int)blockIdx.x == npairs)  // L_jj from the panel step's scratch block into place
+      for (int e = threadIdx.x; e < NB * NB; e += 256)
+        if ((e & 63) <= (e >> 6)) H[(size_t)(j0 + (e >> 6)) * p + j0 + (e & 63)] = Ljj[e];
     // z[c] -= sum_k z[j0 + k] * L[c][j0 + k], all 64 loads in flight at once
     const int c = t0 + ((int)blockIdx.x - npairs) * 256 + (int)threadIdx.x;
     if (c < p) {
@@ -413,9 +416,12 @@ __global__ void k_form_hessian(double *__restrict__ G, const double *__restrict_
 
 }  // namespace
 
-// z (p), info (64 doubles reserved), k-major panel copy Wt (64 rows of chol_pitch(p) doubles)
+// z (p), info (64 doubles reserved), k-major panel copy Wt (64 rows of chol_pitch(p)
+// doubles), scratch block for L_jj (64 x 64)
 static uint64_t chol_pitch(uint64_t p) { return (p + 127) / 128 * 128 + 128; }
-uint64_t newton_workspace_bytes(uint64_t p) { return (p + 64 + NB * chol_pitch(p)) * sizeof(double); }
+uint64_t newton_workspace_bytes(uint64_t p) {
+  return (p + 64 + NB * chol_pitch(p) + NB * NB) * sizeof(double);
+}
 
 int launch_form_hessian(uint64_t p, double *d_G, const double *d_prec, double e2, double *d_diagH) {
   ProfScope ps("form_hessian");
@@ -435,6 +441,7 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
   int *info = (int *)(z + p);
   double *Wt = z + p + 64;
   const int pw = (int)chol_pitch(p64);
+  double *Ljj = Wt + (size_t)NB * pw;
   hipStream_t st = cur_stream();
   OB_HIP(hipMemsetAsync(Wt, 0, sizeof(double) * NB * pw, st));  // rows beyond p stay zero
   OB_HIP(hipMemcpyAsync(z, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, st));
@@ -444,14 +451,21 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
     for (int j0 = 0; j0 < p; j0 += NB) {
       const int nrowblk = (p - j0 + NB - 1) / NB;  // block 0 = diagonal block
       hipLaunchKernelGGL(k_chol_panel2, dim3((unsigned)(nrowblk + 1)), dim3(256), 0, st, d_H, z, Wt,
-                         pw, p, j0, info);
+                         pw, p, j0, info, Ljj);
       const int m = p - (j0 + NB);
       if (m > 0) {
         const int nt = (m + 127) / 128;
         const int npairs = nt * (nt + 1) / 2;
         const int nz = (m + 255) / 256;
         hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(npairs + nz)), dim3(256), 0, st, d_H, z, Wt,
-                           pw, p, j0, nt, npairs);
+                           pw, p, j0, nt, npairs, Ljj);
+      } else {
+        // last block column: nothing to update, only L_jj to put in place (its zero upper
+        // part lands in H's scratch triangle)
+        const int jb = p - j0;
+        OB_HIP(hipMemcpy2DAsync(d_H + (size_t)j0 * p + j0, (size_t)p * sizeof(double), Ljj,
+                                NB * sizeof(double), jb * sizeof(double), jb,
+                                hipMemcpyDeviceToDevice, st));
       }
     }
     OB_HIP(hipGetLastError());

@@ -1,5 +1,5 @@
-"""BASELINE.json configs[2] at FULL size (d=20, n=1e6, p=4096) through
-size-independent properties: the oracle cannot produce a reference at this size
+"""BASELINE.json configs at FULL size (configs[2]: d=20, n=1e6, p=4096; also configs[1],
+one rank's shard of configs[4] and configs[0]) through size-independent properties: the oracle cannot produce a reference at this size
 in seconds, but the kernels must agree with EACH OTHER (the Gram / Cholesky
 kernels vs the matrix-free kernels vs the fused predictor)."""
 import ctypes as C
@@ -110,3 +110,72 @@ def test_fused_predictor_equals_stored_basis_path(hot):
     # and the fit explains the data: residual variance well below the prior noise guess
     resid = via_mm - hot.y
     assert float(resid.var()) < 0.5
+
+
+# ---- the other BASELINE.json configs ----------------------------------------------------------
+def _fit_is_stationary(hp, tol):
+    """Newton stationarity with H applied matrix-free + fused predictor vs stored basis."""
+    import torch
+    from outerbase_amd._lib import call
+    e2 = math.exp(-2 * hp.sigma)
+    tmp, hv = _vec(torch, hp.n), _vec(torch, hp.p)
+    call("obhip_basis_mm_dev", hp.basis, hp.t._h, hp.theta.data_ptr(), tmp.data_ptr(), 0)
+    call("obhip_basis_tmm_dev", hp.basis, hp.t._h, tmp.data_ptr(), hv.data_ptr(), 0)
+    torch.cuda.synchronize()
+    prec = torch.from_numpy(1.0 / (hp.om.getvar(hp.terms) * math.exp(2 * hp.rho))).cuda()
+    lhs = e2 * hv + prec * hp.theta
+    rhs = e2 * hp.g
+    assert float((lhs - rhs).norm() / rhs.norm()) < tol
+    via_pred = _vec(torch, hp.n)
+    call("obhip_predict_dev", hp.om._h, hp.t._h, hp.theta.data_ptr(), hp.x.data_ptr(), hp.n,
+         via_pred.data_ptr(), None, hp.sigma, None)
+    torch.cuda.synchronize()
+    assert float((tmp - via_pred).abs().max() / tmp.abs().max()) < 1e-11
+
+
+def test_config1_d10_n1e5_p1024():
+    """BASELINE.json configs[1]: d=10, n=1e5, p=1024, mat25."""
+    import torch
+    from outerbase_amd.driver import HotPath
+    hp = HotPath(["mat25"] * 10, 40, 1024, 100_000)
+    hp.setup()
+    hp.step()
+    torch.cuda.synchronize()
+    try:
+        _fit_is_stationary(hp, 1e-10)
+    finally:
+        hp.close()
+
+
+def test_config4_one_rank_shard_d40_p16384_mixed_covariances():
+    """BASELINE.json configs[4] (d=40, n=1e6, p=16384, mixed covariance functions over 8
+    GPUs): the 125 000-row shard of one rank -- p = 16384 through the Gram, Cholesky and
+    predict kernels (8256 tile pairs, 256 panel steps, all three covariances)."""
+    import torch
+    from outerbase_amd.driver import HotPath
+    kinds = (["mat25", "mat25pow", "mat25ang"] * 14)[:40]
+    hp = HotPath(kinds, 40, 16384, 125_000)
+    hp.setup()
+    hp.step()
+    torch.cuda.synchronize()
+    try:
+        assert hp.terms_info["max_nnz"] <= 8
+        # high levels of the periodic kernel: the conditioning note of test_gpu_parity applies
+        _fit_is_stationary(hp, 1e-8)
+    finally:
+        hp.close()
+
+
+def test_config0_borehole_obfit():
+    """BASELINE.json configs[0]: Borehole d=8, n=1000, p=256 through obfit / obpred."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    rng = np.random.default_rng(0)
+    x = rng.random((1000, 8))
+    y = O.borehole8d(x)
+    m = ob.obfit(x, y, numb=256, seed=0)
+    xt = rng.random((500, 8))
+    pred = ob.obpred(m, xt)
+    yt = O.borehole8d(xt)
+    assert math.sqrt(np.mean((pred["mean"] - yt) ** 2)) < 0.01 * np.std(yt)
+    assert np.all(pred["var"] > 0)

@@ -3,6 +3,7 @@ same seeded inputs.  All arithmetic is FP64; tolerances are stated per test.
 The reference's own identities (tests/testthat/test-obombasic.R) are restated
 through the device path in test_reference_identities.
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -708,3 +709,36 @@ def test_full_hessian_marginal_adjustment_after_optnewton():
     assert abs(lp.val - (v + pv + mv)) < 1e-9 * abs(v + pv + mv)
     assert relerr(lp.gradhyp, gh + pgh + mgh) < 1e-7
     assert relerr(lp.gradpara, np.array([gp[0] + mgl, pgp[0] + mgp])) < 1e-8
+
+
+def test_cholesky_with_more_workgroups_than_the_gpu_holds():
+    """p = 16448: 258 panel workgroups per step on 256 CUs and a ragged last block.  Guards
+    the in-place write-back race found at p >= 16384 (late workgroups re-factorising a
+    diagonal block that workgroup 0 had already overwritten with L_jj)."""
+    import torch
+    import outerbase_amd as ob
+    from outerbase_amd._lib import call
+    from outerbase_amd.driver import bench_knots
+    p = 16448
+    kinds = (["mat25", "mat25pow", "mat25ang"] * 14)[:40]
+    om = ob.outermod()
+    ob.setcovfs(om, kinds)
+    ob.setknot(om, bench_knots(kinds, 40))
+    terms = om.selectterms(p)
+    t = ob.obmod._Terms(om, terms)
+    torch.manual_seed(0)
+    A = torch.randn((p, 256), dtype=torch.float64, device="cuda")
+    G = A @ A.T + 10.0 * torch.eye(p, dtype=torch.float64, device="cuda")
+    g = torch.randn(p, dtype=torch.float64, device="cuda")
+    sigma, rho = 0.0, 20.0
+    prec = torch.from_numpy(1.0 / (om.getvar(terms) * math.exp(2 * rho))).cuda()
+    want = torch.linalg.solve(G + torch.diag(prec), g)
+    wsb = C.c_uint64(0)
+    call("obhip_newton_workspace_bytes", p, C.byref(wsb))
+    ws = torch.empty(wsb.value, dtype=torch.uint8, device="cuda")
+    th = torch.empty(p, dtype=torch.float64, device="cuda")
+    dH = torch.empty(p, dtype=torch.float64, device="cuda")
+    call("obhip_newton_solve_dev", om._h, t._h, G.data_ptr(), g.data_ptr(), sigma, rho,
+         th.data_ptr(), dH.data_ptr(), ws.data_ptr(), wsb.value)
+    torch.cuda.synchronize()
+    assert float((th - want).norm() / want.norm()) < 1e-10
