@@ -711,6 +711,43 @@ def test_full_hessian_marginal_adjustment_after_optnewton():
     assert relerr(lp.gradpara, np.array([gp[0] + mgl, pgp[0] + mgp])) < 1e-8
 
 
+@pytest.mark.parametrize("p", [1, 2, 63, 64, 65, 127, 128, 129, 1000, 4097])
+def test_newton_solve_sizes_against_library_solve(p):
+    """obhip_newton_solve_dev (Cholesky + two triangular solves, fit.cpp:120) on random SPD
+    systems of awkward sizes (single element, one block, ragged blocks, tile edges)
+    against torch.linalg.solve on the same H."""
+    import torch
+    import outerbase_amd as ob
+    from outerbase_amd._lib import call
+    kinds = ["mat25"] * 6
+    om = ob.outermod()
+    ob.setcovfs(om, kinds)
+    ob.setknot(om, knots_for(kinds, 40))
+    terms = om.selectterms(p)
+    t = ob.obmod._Terms(om, terms)
+    torch.manual_seed(p)
+    A = torch.randn((p, p + 3), dtype=torch.float64, device="cuda")
+    G = A @ A.T + 0.5 * torch.eye(p, dtype=torch.float64, device="cuda")
+    g = torch.randn(p, dtype=torch.float64, device="cuda")
+    sigma, rho = 0.3, 2.0
+    e2 = math.exp(-2 * sigma)
+    prec = torch.from_numpy(1.0 / (om.getvar(terms) * math.exp(2 * rho))).cuda()
+    H = e2 * G + torch.diag(prec)
+    want = torch.linalg.solve(H, e2 * g)
+    wsb = C.c_uint64(0)
+    call("obhip_newton_workspace_bytes", p, C.byref(wsb))
+    ws = torch.empty(wsb.value, dtype=torch.uint8, device="cuda")
+    th = torch.empty(p, dtype=torch.float64, device="cuda")
+    dH = torch.empty(p, dtype=torch.float64, device="cuda")
+    Gc = G.clone()
+    call("obhip_newton_solve_dev", om._h, t._h, Gc.data_ptr(), g.data_ptr(), sigma, rho,
+         th.data_ptr(), dH.data_ptr(), ws.data_ptr(), wsb.value)
+    torch.cuda.synchronize()
+    cond = float(torch.linalg.cond(H))
+    assert float((th - want).norm() / want.norm()) < 1e-13 * max(cond, 10.0)
+    assert float((dH - torch.diagonal(H)).abs().max() / torch.diagonal(H).abs().max()) < 1e-14
+
+
 def test_cholesky_with_more_workgroups_than_the_gpu_holds():
     """p = 16448: 258 panel workgroups per step on 256 CUs and a ragged last block.  Guards
     the in-place write-back race found at p >= 16384 (late workgroups re-factorising a
