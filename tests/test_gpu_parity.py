@@ -434,6 +434,26 @@ def test_gradhyp_products_match_oracle(kinds, n, p):
         assert relerr(bd.getmat_gradhyp(terms), O.ob_getmat_gradhyp(bo, terms)) < tol
 
 
+def test_gradhyp_with_more_hyperparameters_than_one_pass_holds():
+    """26 hyper-parameters (the transposed streaming kernel takes 20 per pass) and 22
+    dimensions: matmul / tmatmul / sqcolsums _gradhyp against the oracle."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25"] * 18 + ["mat25pow", "mat25ang", "mat25pow", "mat25ang"]
+    rng = np.random.default_rng(26)
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 16))
+    assert len(om_o.hypmatch) == 26
+    n, p = 300, 260
+    x = sample_x(rng, n, kinds)
+    terms = om_o.selectterms(p)
+    bo = O.OuterBase(om_o, x, dograd=True)
+    bd = ob.outerbase(om_d, x)
+    a, v = rng.standard_normal(p), rng.standard_normal(n)
+    assert relerr(bd.matmul_gradhyp(terms, a), O.ob_mm_gradhyp(bo, terms, a)[1]) < 1e-9
+    assert relerr(bd.tmatmul_gradhyp(terms, v), O.ob_tmm_gradhyp(bo, terms, v)[1]) < 1e-9
+    assert relerr(bd.sqcolsums_gradhyp(terms), O.ob_sqcolsums_gradhyp(bo, terms)) < 1e-9
+
+
 def test_gradhyp_follows_the_reference_finite_difference_test():
     """test-obomgrad.R:21-67 on the device: the gradient along a random direction equals the
     difference quotient of two rebuilt bases (updatehyp + build)."""
