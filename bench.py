@@ -254,6 +254,25 @@ def main():
         split[name + "_ms"] = dt * 1e3
         split[name + "_only_points_per_s"] = float(n_rows_all(hp)) / dt
 
+    # what a host-buffer caller pays on top: x, y, xnew in, mean out over PCIe
+    # (pinned buffers); reported beside `value`, never part of it
+    pcie = None
+    if rank == 0:
+        hx = torch.empty(hp.x.shape, dtype=torch.float64).pin_memory()
+        hy = torch.empty(hp.n, dtype=torch.float64).pin_memory()
+        sync_local = torch.cuda.synchronize
+        sync_local()
+        t0 = time.perf_counter()
+        hp.x.copy_(hx, non_blocking=True)
+        hp.xnew.copy_(hx, non_blocking=True)
+        hp.y_raw.copy_(hy, non_blocking=True)
+        hy.copy_(hp.mean, non_blocking=True)
+        sync_local()
+        pcie = (time.perf_counter() - t0) * 1e3
+        # restore the synthetic inputs the copies overwrote
+        hp.setup_inputs()
+        sync_local()
+
     # parity of this very run against the oracle on a row sample (cheap, untimed)
     check = check_against_oracle(hp) if rank == 0 else None
 
@@ -310,6 +329,10 @@ def main():
             "parallelism": "rows sharded over %d rank(s); all-reduce of G and g" % world,
         },
         "fit_predict_split": split,
+        "host_buffer_overhead": None if pcie is None else {
+            "pcie_ms_per_step": pcie,
+            "what": "x, xnew, y host->device and mean device->host, pinned, one GPU",
+            "points_per_s_including_copies": float(n) * world / (ms_per_step * 1e-3 + pcie * 1e-3)},
         "kernels_ms": prof,
         "parity_check": check,
         "alt_backend": alt,

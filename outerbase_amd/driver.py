@@ -107,15 +107,7 @@ class HotPath:
         call("obhip_newton_workspace_bytes", p, C.byref(wsb))
         self.ws = torch.empty(wsb.value, dtype=torch.uint8, device=dev)
         self.wsb = wsb.value
-        kid = (C.c_int * d)(*[KIND_ID[k] for k in self.kinds])
-        row0, _ = shard_rows(self.rank, n)
-        scratch = torch.empty(n, dtype=f64, device=dev)
-        call("obhip_synth_xy_dev", self.seed_train, row0, n, d, C.cast(kid, C.c_void_p),
-             self.x.data_ptr(), self.y_raw.data_ptr())
-        call("obhip_synth_xy_dev", self.seed_pred, row0, n, d, C.cast(kid, C.c_void_p),
-             self.xnew.data_ptr(), scratch.data_ptr())
-        torch.cuda.synchronize()
-        del scratch
+        self.setup_inputs()
         if self.world > 1:
             self._cgbuf = torch.empty(p + 2, dtype=f64, device=dev)
 
@@ -133,6 +125,20 @@ class HotPath:
             self._cb = _lib.ALLREDUCE_FN(_cb)
         else:
             self._cb = None
+
+    def setup_inputs(self):
+        """(Re)generate this rank's rows of the synthetic stream in HBM."""
+        torch = self.torch
+        n, d = self.n, self.d
+        kid = (C.c_int * d)(*[KIND_ID[k] for k in self.kinds])
+        row0, _ = shard_rows(self.rank, n)
+        scratch = torch.empty(n, dtype=torch.float64, device=self.x.device)
+        call("obhip_synth_xy_dev", self.seed_train, row0, n, d, C.cast(kid, C.c_void_p),
+             self.x.data_ptr(), self.y_raw.data_ptr())
+        call("obhip_synth_xy_dev", self.seed_pred, row0, n, d, C.cast(kid, C.c_void_p),
+             self.xnew.data_ptr(), scratch.data_ptr())
+        torch.cuda.synchronize()
+        del scratch
 
     def _allreduce(self, t):
         if self.world > 1:
