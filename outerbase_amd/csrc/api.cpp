@@ -402,16 +402,35 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_mo
     for (uint64_t i = 0; i < p; ++i) pv[i] = rm[i] = grad[i] / mdiag[i];
     OB_TRY(hessmult(pv, q));
     double valdiff = 10;
+    // The objective is exactly quadratic in coeff, so the gradient and value after the step
+    // follow from the Hessian product already in hand: grad -= alpha q, val += alpha g.p -
+    // alpha^2 p.q / 2.  The reference re-evaluates both with a full update() (two more
+    // passes over the basis) in every iteration (fit.cpp:79); here that happens every
+    // `refresh` iterations and once at the end, which halves the passes and keeps the same
+    // iterates up to rounding.  OBHIP_CG_REFRESH=1 restores the reference's schedule.
+    static const uint64_t refresh =
+        getenv("OBHIP_CG_REFRESH") ? std::max(1, atoi(getenv("OBHIP_CG_REFRESH"))) : 8;
+    bool exact = true;  // grad / val come from update(), not from the recurrence
     for (k = 0; k < maxit; ++k) {  // fit.cpp:71-85
       double num = 0;
       for (uint64_t i = 0; i < p; ++i) num += grad[i] * rm[i];
       if (num < tol && valdiff < tol) break;
-      double denom = 0;
-      for (uint64_t i = 0; i < p; ++i) denom += q[i] * pv[i];
+      double denom = 0, gp = 0;
+      for (uint64_t i = 0; i < p; ++i) {
+        denom += q[i] * pv[i];
+        gp += grad[i] * pv[i];
+      }
       const double alpha = num / denom;
       for (uint64_t i = 0; i < p; ++i) coeff[i] += alpha * pv[i];
       const double valo = val;
-      OB_TRY(update(coeff, val));
+      if ((k + 1) % refresh == 0) {
+        OB_TRY(update(coeff, val));
+        exact = true;
+      } else {
+        val += alpha * gp - 0.5 * alpha * alpha * denom;
+        for (uint64_t i = 0; i < p; ++i) grad[i] -= alpha * q[i];
+        exact = false;
+      }
       valdiff = val - valo;
       double num2 = 0;
       for (uint64_t i = 0; i < p; ++i) {
@@ -422,6 +441,7 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_mo
       for (uint64_t i = 0; i < p; ++i) pv[i] = rm[i] + beta * pv[i];
       OB_TRY(hessmult(pv, q));
     }
+    if (!exact) OB_TRY(update(coeff, val));  // the value reported is a true evaluation
   }
   OB_HIP(hipMemcpyAsync(d_theta, coeff.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
   if (d_diagH)
