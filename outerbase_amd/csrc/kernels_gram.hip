@@ -132,21 +132,35 @@ k_gram(const double *__restrict__ bm, const double *__restrict__ scale,
 __global__ void __launch_bounds__(256)
 k_gram_reduce(const double *__restrict__ part, int npairs, int nsplit, int nb, int p,
               double *__restrict__ G) {
+  __shared__ double S[64 * 65];  // one 64 x 64 quadrant, so that the mirror goes out in rows too
   int I = 0, rem = blockIdx.x;
   while (rem >= nb - I) {
     rem -= nb - I;
     ++I;
   }
   const int J = I + rem;
-  for (int e = threadIdx.x; e < kGT * kGT; e += 256) {
-    const int r = e / kGT, c = e % kGT;
-    if (I == J && r > c) continue;  // diagonal tiles: upper half, mirrored below
-    const int gi = I * kGT + r, gj = J * kGT + c;
-    if (gi >= p || gj >= p) continue;
-    double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += part[((uint64_t)k * npairs + blockIdx.x) * (kGT * kGT) + e];
-    G[(uint64_t)gi * p + gj] = s;
-    G[(uint64_t)gj * p + gi] = s;
+  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+  for (int qd = 0; qd < 4; ++qd) {
+    const int qr = qd >> 1, qc = qd & 1;
+    if (I == J && qr > qc) continue;  // diagonal tiles: the lower-left quadrant is the mirror
+    // sum of the row-split partials, 64 consecutive doubles per wave load
+    for (int r = r4; r < 64; r += 4) {
+      const int e = (qr * 64 + r) * kGT + qc * 64 + c;
+      double s = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < nsplit; ++k) s += part[((uint64_t)k * npairs + blockIdx.x) * (kGT * kGT) + e];
+      S[r * 65 + c] = s;
+    }
+    __syncthreads();
+    const int gi0 = I * kGT + qr * 64, gj0 = J * kGT + qc * 64;
+    for (int r = r4; r < 64; r += 4) {
+      // G[gi0 + r][gj0 + c] and, mirrored, G[gj0 + r][gi0 + c] = S[c][r]
+      if (gi0 + r < p && gj0 + c < p && !(I == J && qr == qc && c < r))
+        G[(uint64_t)(gi0 + r) * p + gj0 + c] = S[r * 65 + c];
+      if (gj0 + r < p && gi0 + c < p && !(I == J && qr == qc && c >= r))
+        G[(uint64_t)(gj0 + r) * p + gi0 + c] = S[c * 65 + r];
+    }
+    __syncthreads();
   }
 }
 
