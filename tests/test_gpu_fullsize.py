@@ -112,6 +112,25 @@ def test_fused_predictor_equals_stored_basis_path(hot):
     assert float(resid.var()) < 0.5
 
 
+def test_gradient_products_are_adjoint_at_full_size(hot):
+    """v^T (d(B a)/dhyp_h) == a^T (d(B^T v)/dhyp_h) for every hyper-parameter: the one-pass
+    kernel k_mmge against the streaming + restricted-view path of the transposed products,
+    at n = 1e6, p = 4096 (and the same for the squared stores)."""
+    import outerbase_amd as ob
+    rng = np.random.default_rng(5)
+    x = np.ascontiguousarray(hot.x.cpu().numpy().T)          # n x d
+    b = ob.outerbase(hot.om, x, levelcap=hot.t.maxlevels())
+    a = rng.standard_normal(hot.p)
+    v = rng.standard_normal(hot.n)
+    lhs = v @ b.matmul_gradhyp(hot.t, a)
+    rhs = a @ b.tmatmul_gradhyp(hot.t, v)
+    assert np.max(np.abs(lhs - rhs)) < 1e-10 * np.max(np.abs(lhs))
+    aa = np.abs(a)
+    lhs = v @ b.sqmm_gradhyp(hot.t, aa)
+    rhs = aa @ b.sqtmm_gradhyp(hot.t, v)
+    assert np.max(np.abs(lhs - rhs)) < 1e-10 * np.max(np.abs(lhs))
+
+
 # ---- the other BASELINE.json configs ----------------------------------------------------------
 def _fit_is_stationary(hp, tol):
     """Newton stationarity with H applied matrix-free + fused predictor vs stored basis."""
