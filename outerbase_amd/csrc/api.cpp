@@ -415,6 +415,9 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_mo
       double num = 0;
       for (uint64_t i = 0; i < p; ++i) num += grad[i] * rm[i];
       if (num < tol && valdiff < tol) break;
+      // an exactly vanishing gradient (e.g. p = 1 after one step) would make the next
+      // search direction zero and alpha = 0 / 0; the reference has no guard for this
+      if (!(num > 0.0)) break;
       double denom = 0, gp = 0;
       for (uint64_t i = 0; i < p; ++i) {
         denom += q[i] * pv[i];

@@ -424,8 +424,9 @@ int run_mmge(const obhip_basis &gb, const obhip_basis &b, obhip_terms &t, const 
 
 // out_gradhyp for every hyper-parameter in one pass; false if the tile does not fit the LDS
 // (the caller then falls back to one k_mm pass per hyper-parameter through the views)
-bool mmge_fits(const obhip_basis &b, const obhip_terms &t) {
+bool mmge_fits(const obhip_basis &b, obhip_terms &t) {
   if (!b.grad) return false;
+  if (t.prepare(b.md.cap, b.md.dims_h) != 0) return false;  // Mu must be this basis' value
   const uint64_t Mge = b.grad->gb->md.Mc - b.md.Mc;
   return t.W <= 8 && (t.Mu + Mge + b.model->nhyp() + 4) * kTileRows * sizeof(double) <= 152 * 1024;
 }

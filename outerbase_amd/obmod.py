@@ -492,6 +492,8 @@ class lpdf:
             num = float(np.sum(self.grad * rm))
             if num < tol and valdiff < tol:
                 break
+            if not num > 0.0:     # exactly stationary: the next direction would be 0 / 0
+                break
             alpha = num / float(np.sum(q * pv))
             coeff = coeff + alpha * pv
             valo = self.val

@@ -799,3 +799,57 @@ def test_cholesky_with_more_workgroups_than_the_gpu_holds():
          th.data_ptr(), dH.data_ptr(), ws.data_ptr(), wsb.value)
     torch.cuda.synchronize()
     assert float((th - want).norm() / want.norm()) < 1e-10
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_shapes_against_oracle(seed):
+    """Seeded fuzz over shapes the other tests do not enumerate: random d, n, p, covariance
+    mix and knot counts; products, Gram, Newton fit, predictor and one gradient product
+    against the oracle."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.integers(3, 11))
+    kinds = [["mat25", "mat25pow", "mat25ang"][int(k)] for k in rng.integers(0, 3, d)]
+    m = int(rng.integers(8, 31))
+    n = int(rng.choice([1, 2, 63, 64, 65, 130, 777, 2049]))
+    p = int(rng.choice([1, 2, 5, 64, 100, 129, 300]))
+    om_o, om_d = make_pair(kinds, knots_for(kinds, m))
+    x = sample_x(rng, n, kinds)
+    terms = om_o.selectterms(p)
+    bo = O.OuterBase(om_o, x, dograd=True)
+    bd = ob.outerbase(om_d, x)
+    a, v = rng.standard_normal(p), rng.standard_normal(n)
+    # high levels (few knots, many terms) lose digits on both sides, see test_gram_backends
+    tol = 1e-6 if terms.max() >= 8 else 1e-9
+    assert relerr(bd.matmul(terms, a), O.ob_mm(bo, terms, a)) < tol
+    assert relerr(bd.tmatmul(terms, v), O.ob_tmm(bo, terms, v)) < tol
+    assert relerr(bd.getmat(terms), O.ob_getmat(bo, terms)) < tol
+    assert relerr(bd.sqcolsums(terms), O.ob_sqcolsums(bo, terms)) < tol
+    assert relerr(bd.matmul_gradhyp(terms, a), O.ob_mm_gradhyp(bo, terms, a)[1]) < 100 * tol
+    assert relerr(bd.tmatmul_gradhyp(terms, v), O.ob_tmm_gradhyp(bo, terms, v)[1]) < 100 * tol
+    aa = np.abs(a)
+    assert relerr(bd.sqmm(terms, aa), O.ob_sqmm(bo, terms, aa)) < tol
+    assert relerr(bd.sqtmm(terms, v), O.ob_sqtmm(bo, terms, v)) < tol
+    assert relerr(bd.residvar(terms), O.ob_residvar(bo, terms)) < 100 * tol
+    assert relerr(bd.sqcolsums_gradhyp(terms), O.ob_sqcolsums_gradhyp(bo, terms)) < 100 * tol
+    assert relerr(bd.sqmm_gradhyp(terms, aa), O.ob_sqmm_gradhyp(bo, terms, aa)) < 100 * tol
+    y = rng.standard_normal(n)
+    if n >= 2:
+        lik = ob.loglik_std(om_d, terms, y, x)
+        lp = ob.lpdfvec(lik, ob.logpr_gauss(om_d, terms))
+        lp.domarg = False
+        B = O.ob_getmat(bo, terms)
+        assert relerr(lp.hess() - np.diag(lp.logpr.diaghess()), math.exp(-2 * lik.para[0]) * (B.T @ B)) < tol
+        lp.optnewton()
+        theta_o, H_o = O.fit_newton(bo, terms, y, sigma=float(lik.para[0]))
+        xnew = sample_x(rng, 37, kinds)
+        pred = ob.predictor(lp)
+        pred.update(xnew)
+        assert relerr(pred.mean(), O.predict_mean(om_o, terms, theta_o, xnew)) < 1e-6
+        if p <= 100:
+            # the matrix-free PCG reaches the same solution (tight tolerance, generous cap)
+            likg = ob.loglik_gauss(om_d, terms, y, x)
+            lpg = ob.lpdfvec(ob.logpr_gauss(om_d, terms), likg)
+            lpg.optcg(1e-14, 4000)
+            assert relerr(likg.yhat, O.ob_mm(bo, terms, theta_o)) < 1e-5
