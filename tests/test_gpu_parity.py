@@ -853,3 +853,66 @@ def test_random_shapes_against_oracle(seed):
             lpg = ob.lpdfvec(ob.logpr_gauss(om_d, terms), likg)
             lpg.optcg(1e-14, 4000)
             assert relerr(likg.yhat, O.ob_mm(bo, terms, theta_o)) < 1e-5
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_terms_caps_and_gram_backends(seed):
+    """Second fuzz: arbitrary (not downward closed) term sets with up to 8 factors, a basis
+    built up to per-dimension level caps, every Gram back end, the Gauss predictor variance
+    and a rebuild after updatehyp, all against the oracle."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    from outerbase_amd import _lib
+    rng = np.random.default_rng(5000 + seed)
+    d = int(rng.integers(3, 13))
+    kinds = [["mat25", "mat25pow", "mat25ang"][int(k)] for k in rng.integers(0, 3, d)]
+    m = int(rng.integers(10, 25))
+    n = int(rng.choice([3, 64, 100, 257, 1500]))
+    p = int(rng.choice([2, 7, 65, 128, 257]))
+    maxlev = int(rng.integers(1, 6))
+    max_nnz = int(rng.integers(1, min(8, d) + 1))
+    hyp = None
+    om_o, om_d = make_pair(kinds, knots_for(kinds, m), hyp=hyp)
+    x = sample_x(rng, n, kinds)
+    terms = random_terms(rng, p, d, maxlev, max_nnz)
+    terms = np.unique(terms, axis=0)
+    p = terms.shape[0]
+    bo = O.OuterBase(om_o, x)
+    caps = np.maximum(terms.max(axis=0), rng.integers(0, 3, d))      # at least what the terms use
+    caps = np.minimum(caps, m - 1)
+    bd = ob.outerbase(om_d, x, levelcap=caps)
+    a, v = rng.standard_normal(p), rng.standard_normal(n)
+    B = O.ob_getmat(bo, terms)
+    tol = 1e-9
+    assert relerr(bd.matmul(terms, a), B @ a) < tol
+    assert relerr(bd.tmatmul(terms, v), B.T @ v) < tol
+    y = rng.standard_normal(n)
+    lik = ob.loglik_std(om_d, terms, y, x)
+    e2 = math.exp(-2 * lik.para[0])
+    try:
+        for backend in (1, 2, 3, 4, 0):
+            _lib.call("obhip_set_gram_backend", backend)
+            if backend in (1, 2, 3) and max_nnz > 8:
+                continue
+            G = lik.hess() / e2
+            assert relerr(G, B.T @ B) < tol, backend
+            assert np.array_equal(G, G.T)
+    finally:
+        _lib.call("obhip_set_gram_backend", 0)
+    # pred_gauss variance with an arbitrary coefficient variance
+    likg = ob.loglik_gauss(om_d, terms, y, x)
+    lpg = ob.lpdfvec(ob.logpr_gauss(om_d, terms), likg)
+    lpg.optcg(1e-12, 50)
+    pred = ob.predictor(lpg)
+    xnew = sample_x(rng, 19, kinds)
+    pred.update(xnew)
+    want = O.predict_var_gauss(om_o, terms, lpg.totdiaghess, float(likg.para[0]), xnew)
+    assert relerr(pred.var(), want) < tol
+    # hyper-parameters move: the basis follows only after build()
+    hyp2 = ob.gethyp(om_d) + 0.05 * rng.standard_normal(len(ob.gethyp(om_d)))
+    om_o.hyp_set(hyp2)
+    om_d.updatehyp(hyp2)
+    om_d.set_rotation(om_o.rotmat, om_o.basisvar, om_o.maxlevel)
+    bd.build()
+    B2 = O.ob_getmat(O.OuterBase(om_o, x), terms)
+    assert relerr(bd.matmul(terms, a), B2 @ a) < tol
