@@ -916,3 +916,70 @@ def test_random_terms_caps_and_gram_backends(seed):
     bd.build()
     B2 = O.ob_getmat(O.OuterBase(om_o, x), terms)
     assert relerr(bd.matmul(terms, a), B2 @ a) < tol
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_lpdf_level_quantities(seed):
+    """Third fuzz: the lpdf-level values and gradients (loglik_gauss / loglik_std /
+    loglik_gda, logpr_gauss, both marginal adjustments, predr_std) on random shapes,
+    including more terms than rows."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    rng = np.random.default_rng(9000 + seed)
+    d = int(rng.integers(3, 9))
+    kinds = [["mat25", "mat25pow", "mat25ang"][int(k)] for k in rng.integers(0, 3, d)]
+    m = int(rng.integers(12, 25))
+    n = int(rng.choice([20, 65, 200, 513]))
+    p = int(rng.choice([3, 30, 64, 90]))
+    om_o, om_d = make_pair(kinds, knots_for(kinds, m))
+    x = sample_x(rng, n, kinds)
+    y = rng.standard_normal(n)
+    terms = om_o.selectterms(p)
+    coeff = 0.1 * rng.standard_normal(p)
+    sigma, rho = float(rng.uniform(-2, 0.5)), float(rng.uniform(1, 6))
+    bo = O.OuterBase(om_o, x, dograd=True)
+    gtol = 1e-5 if terms.max() >= 8 else 1e-7
+    # diagonal marginal adjustment on lpdfvec(logpr, loglik_gauss)
+    pr = ob.logpr_gauss(om_d, terms)
+    lik = ob.loglik_gauss(om_d, terms, y, x)
+    lp = ob.lpdfvec(pr, lik)
+    lp.compute_gradhyp = lp.compute_gradpara = True
+    lp.updatepara([rho, sigma])
+    lp.update(coeff)
+    v, g, gh, gp = O.loglik_update(bo, terms, y, sigma, coeff)
+    pv, pg, pgh, pgp = O.logpr_update(om_o, terms, rho, coeff)
+    mv, mgh, mgl, mgp = O.margadj_diag(bo, terms, sigma, rho)
+    assert abs(lp.val - (v + pv + mv)) < 1e-9 * abs(v + pv + mv)
+    assert relerr(lp.grad, g + pg) < 1e-8
+    assert relerr(lp.gradhyp, gh + pgh + mgh) < gtol
+    assert relerr(lp.gradpara, np.array([pgp[0] + mgp, gp[0] + mgl])) < 1e-8
+    # full marginal adjustment after optnewton on lpdfvec(loglik_std, logpr)
+    liks = ob.loglik_std(om_d, terms, y, x)
+    prs = ob.logpr_gauss(om_d, terms)
+    lps = ob.lpdfvec(liks, prs)
+    lps.updatepara([sigma, rho])
+    lps.optnewton()
+    theta, H = O.fit_newton(bo, terms, y, sigma=sigma, rho=rho)
+    v, g, gh, gp = O.loglik_update(bo, terms, y, sigma, theta)
+    pv, pg, pgh, pgp = O.logpr_update(om_o, terms, rho, theta)
+    fv, fgh, fgl, fgp = O.margadj_full(bo, terms, sigma, rho)
+    assert abs(lps.val - (v + pv + fv)) < 1e-8 * abs(v + pv + fv)
+    assert relerr(lps.gradhyp, gh + pgh + fgh) < 10 * gtol
+    assert relerr(lps.gradpara, np.array([gp[0] + fgl, pgp[0] + fgp])) < 1e-6
+    xnew = sample_x(rng, 23, kinds)
+    pred = ob.predictor(lps)
+    pred.update(xnew)
+    assert relerr(pred.var(), O.predict_var_std(om_o, terms, H, sigma, xnew)) < 1e-6
+    # loglik_gda
+    para = np.array([sigma, float(rng.uniform(-1, 1))])
+    lg = ob.loglik_gda(om_d, terms, y, x)
+    lg.updatepara(para)
+    lg.compute_gradhyp = lg.compute_gradpara = True
+    lg.update(coeff)
+    r = O.loglik_gda_update(bo, terms, y, para, coeff)
+    # residvar = 1 - B^2 var cancels to ~1e-7 relative when the expansion explains almost
+    # everything (modandbase.cpp:889-895), and val / gradients inherit that
+    assert abs(lg.val - r["val"]) < 1e-7 * abs(r["val"])
+    assert relerr(lg.gradhyp, r["gradhyp"]) < max(gtol, 1e-6)
+    assert relerr(lg.gradpara, r["gradpara"]) < 1e-6
+    assert relerr(lg.diaghessgradhyp(), r["diaghessgradhyp"]) < max(gtol, 1e-6)
