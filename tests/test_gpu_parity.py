@@ -983,3 +983,36 @@ def test_random_lpdf_level_quantities(seed):
     assert relerr(lg.gradhyp, r["gradhyp"]) < max(gtol, 1e-6)
     assert relerr(lg.gradpara, r["gradpara"]) < 1e-6
     assert relerr(lg.diaghessgradhyp(), r["diaghessgradhyp"]) < max(gtol, 1e-6)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_obfit_on_random_smooth_functions(seed):
+    """obfit / obpred end to end on random smooth test functions of 3..7 inputs with all
+    three covariance families in play: finite, positive variances, and a fit far better
+    than the mean predictor."""
+    import outerbase_amd as ob
+    rng = np.random.default_rng(300 + seed)
+    d = int(rng.integers(3, 8))
+    n = int(rng.choice([150, 400, 900]))
+    covnames = [["mat25pow", "mat25", "mat25ang"][int(k)] for k in rng.integers(0, 3, d)]
+    x = 0.05 + 0.9 * rng.random((n + 200, d))
+    for j, c in enumerate(covnames):
+        if c == "mat25ang":
+            x[:, j] *= 6.283185
+    w = rng.standard_normal(d)
+    ph = rng.uniform(0, 3, d)
+
+    def f(z):
+        u = z.copy()
+        for j, c in enumerate(covnames):
+            u[:, j] = np.sin(z[:, j]) if c == "mat25ang" else z[:, j]
+        return np.sin(u @ w + 0.5) + 0.3 * np.cos(2 * u[:, 0] + ph[0]) * u[:, 1] + 0.1 * (u ** 2) @ np.abs(w)
+
+    y = f(x)
+    numb = int(max(2 * d, min(80, n // 3)))
+    m = ob.obfit(x[:n], y[:n], numb=numb, covnames=covnames, seed=seed)
+    pred = ob.obpred(m, x[n:])
+    assert np.all(np.isfinite(pred["mean"])) and np.all(np.isfinite(pred["var"]))
+    assert np.all(pred["var"] > 0)
+    rmse = math.sqrt(np.mean((pred["mean"] - y[n:]) ** 2))
+    assert rmse < 0.5 * np.std(y[n:])
