@@ -2,14 +2,31 @@
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import numpy as np, ob_oracle as O
+import numpy as np
+
+
+def borehole8d(x):
+    """Borehole function on the unit cube (R/testfuncs.R:32-46)."""
+    rw = x[:, 0] * (0.15 - 0.05) + 0.05
+    r = x[:, 1] * (50000 - 100) + 100
+    Tu = x[:, 2] * (115600 - 63070) + 63070
+    Hu = x[:, 3] * (1110 - 990) + 990
+    Tl = x[:, 4] * (116 - 63.1) + 63.1
+    Hl = x[:, 5] * (820 - 700) + 700
+    L = x[:, 6] * (1680 - 1120) + 1120
+    Kw = x[:, 7] * (12045 - 9855) + 9855
+    m1 = 2 * np.pi * Tu * (Hu - Hl)
+    m2 = np.log(r / rw)
+    m3 = 1 + 2 * L * Tu / (m2 * rw ** 2 * Kw) + Tu / Tl
+    return m1 / m2 / m3 - 77
+
+
 import outerbase_amd as ob
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 numb = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 rng = np.random.default_rng(42)
-x = rng.random((n, 8)); y = O.borehole8d(x)
+x = rng.random((n, 8)); y = borehole8d(x)
 t0=time.time(); m = ob.obfit(x, y, numb=numb, seed=1, verbose=1); t1=time.time()
-xt = rng.random((200, 8)); pred = ob.obpred(m, xt); yt = O.borehole8d(xt)
+xt = rng.random((200, 8)); pred = ob.obpred(m, xt); yt = borehole8d(xt)
 print("fit s", t1-t0, "rmse/sd", math.sqrt(np.mean((pred["mean"]-yt)**2))/np.std(yt), "hyp", ob.gethyp(m["om"]), "para", ob.getpara(m["logpdf"]))
 z=(pred["mean"]-yt)/np.sqrt(pred["var"]); print("rms z", np.sqrt(np.mean(z**2)))
