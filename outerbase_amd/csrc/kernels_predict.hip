@@ -4,9 +4,9 @@
 // (src/lpdfs/loglik_gauss.cpp:214-227: a fresh outerbase (modandbase.cpp:547)
 // followed by prodmm_ (linalg.cpp:57-131) on basemat and on basematsq).
 //
-// Per 64-row tile: 4 waves evaluate the dimensions (wave w takes w, w+4, ...),
+// Per 64-row tile: 8 waves evaluate the dimensions (wave w takes w, w+8, ...),
 // lane = row, writing only the columns the terms use into the LDS tile; after
-// one barrier the 4 waves split the terms in groups of 64 with register-resident
+// one barrier the 8 waves split the terms in groups of 64 with register-resident
 // term tables, exactly as k_mm does.
 #include "obhip_internal.h"
 #include "device_common.h"
@@ -15,8 +15,11 @@ namespace obhip {
 
 namespace {
 
+// 8 waves per 64-row tile (see kMmThreads in kernels_prod.hip)
+constexpr int kPrThreads = 512, kPrWaves = kPrThreads / 64;
+
 template <int W2, bool VAR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kPrThreads)
 k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
           const double *__restrict__ kb, const double *__restrict__ kc,
           const double *__restrict__ rot, const int *__restrict__ cpos, int d, int Mu,
@@ -24,8 +27,8 @@ k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
           const double *__restrict__ coeffvar, double e2sigma, const double *__restrict__ x,
           uint64_t n, double *__restrict__ mean, double *__restrict__ var) {
   extern __shared__ double lds[];
-  double *red = lds + (size_t)Mu * kTileRows;  // [4][64] scale partials, then mean partials
-  double *redv = red + 4 * kTileRows;          // [4][64] variance partials
+  double *red = lds + (size_t)Mu * kTileRows;   // [kPrWaves][64] scale partials, then mean partials
+  double *redv = red + kPrWaves * kTileRows;    // [kPrWaves][64] variance partials
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint64_t row = (uint64_t)blockIdx.x * kTileRows + lane;
@@ -33,7 +36,7 @@ k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
 
   double sc = 1.0;
   const StoreLds store{lds, cpos, lane};
-  for (int l = wave; l < d; l += 4) {
+  for (int l = wave; l < d; l += kPrWaves) {
     const DimDesc D = dims[l];
     const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
     sc *= build_dim_any(D, ka, kb, kc, rot, xv, store);
@@ -41,14 +44,16 @@ k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
   if (wave == 0) lds[lane] = 1.0;  // used column 0 = all ones
   red[wave * kTileRows + lane] = sc;
   __syncthreads();
-  const double s = (red[lane] * red[64 + lane]) * (red[128 + lane] * red[192 + lane]);
+  double s = 1.0;
+#pragma unroll
+  for (int q = 0; q < kPrWaves; ++q) s *= red[q * kTileRows + lane];
   __syncthreads();
 
   double am = 0.0, av = 0.0;
   if constexpr (W2 > 0) {
     const int ngroups = (p + 63) / 64;
     uint32_t cw[W2];
-    for (int g = wave; g < ngroups; g += 4) {
+    for (int g = wave; g < ngroups; g += kPrWaves) {
       const int k0 = g * 64, cnt = min(64, p - k0);
       const int kk = min(k0 + lane, p - 1);
       load_cw(cw, colsw, k0 + lane);
@@ -70,7 +75,7 @@ k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
       }
     }
   } else {
-    for (int k = wave; k < p; k += 4) {
+    for (int k = wave; k < p; k += kPrWaves) {
       const double pr = term_prod_mem(lds, colsw + (size_t)k * W2rt, W2rt, lane, 1.0);
       am = fma(theta[k], pr, am);
       if (VAR) av = fma(coeffvar[k], pr * pr, av);
@@ -80,22 +85,26 @@ k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
   if (VAR) redv[wave * kTileRows + lane] = av;
   __syncthreads();
   if (wave == 0 && valid) {
-    mean[row] = ((red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane])) * s;
-    if (VAR)
-      var[row] = ((redv[lane] + redv[64 + lane]) + (redv[128 + lane] + redv[192 + lane])) * (s * s) +
-                 e2sigma;  // loglik_gauss.cpp:224-225
+    double tm = 0.0, tv = 0.0;
+#pragma unroll
+    for (int q = 0; q < kPrWaves; ++q) {
+      tm += red[q * kTileRows + lane];
+      if (VAR) tv += redv[q * kTileRows + lane];
+    }
+    mean[row] = tm * s;
+    if (VAR) var[row] = tv * (s * s) + e2sigma;  // loglik_gauss.cpp:224-225
   }
 }
 
 template <int W2, bool VAR>
 int run_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, const double *d_x,
                 uint64_t n, double *d_mean, const double *d_coeffvar, double e2sigma, double *d_var) {
-  const size_t lds = (t.Mu * kTileRows + 8 * kTileRows) * sizeof(double);
+  const size_t lds = (t.Mu * kTileRows + 2 * kPrWaves * kTileRows) * sizeof(double);
   if (lds > 64 * 1024)
     OB_HIP(hipFuncSetAttribute((const void *)k_predict<W2, VAR>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_predict<W2, VAR>), dim3((unsigned)((n + kTileRows - 1) / kTileRows)),
-                     dim3(256), lds, cur_stream(), t.pred_md.dims.p, t.pred_md.ka.p, t.pred_md.kb.p,
+                     dim3(kPrThreads), lds, cur_stream(), t.pred_md.dims.p, t.pred_md.ka.p, t.pred_md.kb.p,
                      t.pred_md.kc.p, t.pred_md.rot.p, t.cpos.p, (int)m.d, (int)t.Mu,
                      (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p, d_theta, d_coeffvar,
                      e2sigma, d_x, n, d_mean, d_var);

@@ -70,21 +70,25 @@ __device__ __forceinline__ void load_cw(uint32_t (&cw)[W2], const uint32_t *__re
 
 // ---- mm / getmat -----------------------------------------------------------------------
 // MODE 0: out = B a;  MODE 1: out = B^2 a;  MODE 2: materialise B (a unused)
+// 8 waves share one staged tile: 3 blocks x 8 waves per CU instead of 3 x 4 (the tile is
+// what limits residency), which is what hides the LDS latency of the products
+constexpr int kMmThreads = 512, kMmWaves = kMmThreads / 64;
+
 template <int W2, int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kMmThreads)
 k_mm(const double *__restrict__ bm, const double *__restrict__ scale,
      const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc, const uint32_t *__restrict__ colsw,
      int W2rt, int p, const double *__restrict__ a, double *__restrict__ out, uint64_t n) {
   extern __shared__ double lds[];
-  double *red = lds + (size_t)Mu * kTileRows;  // [4][64]
+  double *red = lds + (size_t)Mu * kTileRows;  // [kMmWaves][64]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint64_t tile = blockIdx.x;
   const uint64_t row = tile * kTileRows + lane;
   if (MODE == 1)
-    stage_tile<true, false>(lds, bm + tile * Mc * kTileRows, ucol, Mu, threadIdx.x, 256);
+    stage_tile<true, false>(lds, bm + tile * Mc * kTileRows, ucol, Mu, threadIdx.x, kMmThreads);
   else
-    stage_tile<false, false>(lds, bm + tile * Mc * kTileRows, ucol, Mu, threadIdx.x, 256);
+    stage_tile<false, false>(lds, bm + tile * Mc * kTileRows, ucol, Mu, threadIdx.x, kMmThreads);
   __syncthreads();
   const double s = row < n ? scale[row] : 0.0;
   double acc = 0.0;
@@ -98,8 +102,8 @@ k_mm(const double *__restrict__ bm, const double *__restrict__ scale,
       load_cw(cw, colsw, g * 64 + lane);
       if (MODE != 2) av = a[k];
     }
-    for (; g < ngroups; g += 4) {
-      const int gn = g + 4;
+    for (; g < ngroups; g += kMmWaves) {
+      const int gn = g + kMmWaves;
       if (gn < ngroups) {  // next group's table while this one is consumed
         load_cw(cwn, colsw, gn * 64 + lane);
         if (MODE != 2) avn = a[min(gn * 64 + lane, p - 1)];
@@ -131,7 +135,7 @@ k_mm(const double *__restrict__ bm, const double *__restrict__ scale,
       av = avn;
     }
   } else {
-    for (int k = wave; k < p; k += 4) {
+    for (int k = wave; k < p; k += kMmWaves) {
       if (MODE == 2) {
         const double v = term_prod_mem(lds, colsw + (size_t)k * W2rt, W2rt, lane, s);
         if (row < n) out[(uint64_t)k * n + row] = v;
@@ -143,9 +147,12 @@ k_mm(const double *__restrict__ bm, const double *__restrict__ scale,
   if (MODE == 2) return;
   red[wave * kTileRows + lane] = acc;
   __syncthreads();
-  if (wave == 0 && row < n)
-    out[row] = ((red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane])) *
-               (MODE == 1 ? s * s : s);
+  if (wave == 0 && row < n) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < kMmWaves; ++q) tot += red[q * kTileRows + lane];
+    out[row] = tot * (MODE == 1 ? s * s : s);
+  }
 }
 
 // ---- tmm -----------------------------------------------------------------------------------
@@ -263,9 +270,9 @@ int check_mu(const obhip_terms &t) {
 
 template <int W2, int MODE>
 int run_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out) {
-  const size_t lds = (t.Mu * kTileRows + 4 * kTileRows) * sizeof(double);
+  const size_t lds = (t.Mu * kTileRows + kMmWaves * kTileRows) * sizeof(double);
   OB_TRY(set_lds(k_mm<W2, MODE>, lds));
-  hipLaunchKernelGGL((k_mm<W2, MODE>), dim3((unsigned)(b.n_pad / kTileRows)), dim3(256), lds,
+  hipLaunchKernelGGL((k_mm<W2, MODE>), dim3((unsigned)(b.n_pad / kTileRows)), dim3(kMmThreads), lds,
                      cur_stream(), b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc,
                      (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p, d_a, d_out, b.n);
   OB_HIP(hipGetLastError());
