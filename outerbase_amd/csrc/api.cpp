@@ -411,10 +411,17 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_mo
     static const uint64_t refresh =
         getenv("OBHIP_CG_REFRESH") ? std::max(1, atoi(getenv("OBHIP_CG_REFRESH"))) : 8;
     bool exact = true;  // grad / val come from update(), not from the recurrence
+    double num0 = -1.0;
     for (k = 0; k < maxit; ++k) {  // fit.cpp:71-85
       double num = 0;
       for (uint64_t i = 0; i < p; ++i) num += grad[i] * rm[i];
       if (num < tol && valdiff < tol) break;
+      // Rounding floor: once the preconditioned gradient has dropped by 14 digits what is
+      // left of it is rounding noise, and the next direction rm + beta pv is a difference
+      // of two equal numbers (p = 1 reaches this after one step).  The reference has no
+      // such guard and takes a step of arbitrary length along that noise.
+      if (num0 < 0.0) num0 = num;
+      if (num <= 1e-28 * num0) break;
       // an exactly vanishing gradient (e.g. p = 1 after one step) would make the next
       // search direction zero and alpha = 0 / 0; the reference has no guard for this
       if (!(num > 0.0)) break;
@@ -423,6 +430,9 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_mo
         denom += q[i] * pv[i];
         gp += grad[i] * pv[i];
       }
+      // a search direction that cancelled to zero (p = 1: the second direction is
+      // rm - (eps / g) g, i.e. 0 up to rounding) has no step length either
+      if (!(denom > 0.0)) break;
       const double alpha = num / denom;
       for (uint64_t i = 0; i < p; ++i) coeff[i] += alpha * pv[i];
       const double valo = val;

@@ -243,6 +243,209 @@ k_tmm(const double *__restrict__ bm, const double *__restrict__ scale,
   part[(uint64_t)blockIdx.x * p_pad + k0 + lane] = mine;
 }
 
+// ---- tmm, term-per-lane ---------------------------------------------------------------------
+// The default B^T a kernel.  lane = term: the LDS byte addresses of a term's columns are
+// loop-invariant VGPRs and the row is the immediate offset of the ds_read_b64, so the inner
+// loop has no address arithmetic, no column broadcast and no cross-lane reduction; the
+// weight a[r]*scale[r] of the row is one v_readlane pair shared by all the terms a wave
+// holds.  Tile layout in LDS: [column][65] doubles -- with the odd pitch, lanes that read
+// different columns hit banks (2 col + 2 r) mod 64, lanes that read the same column (the
+// common case, neighbouring terms share factors) broadcast.
+// A block of 8 waves owns up to 8 * NPAIR * 2 * 64 terms (4096 for NPAIR = 4) and a
+// contiguous range of row tiles, so a tile is staged once per 4096 terms (the lane = row
+// kernel above stages it once per 256).
+// The reads are issued by hand (the compiler pairs the rows into ds_read2_b64, half the LDS
+// rate, and spills the addresses): one "unit" = the W reads of one term for one row, D units
+// in flight per wave (lgkmcnt counts to 15), LDS returns in order, so s_waitcnt
+// lgkmcnt((D-1) W) releases the oldest unit; the "+v" operands tie each wait to the
+// registers it releases.
+constexpr int kTlThreads = 512, kTlWaves = kTlThreads / 64, kTlGP = 2, kTlPitch = 65;
+constexpr int kTlPre = 16;    // prefetch registers per thread => Mu <= 8 * 16
+constexpr int kTlChunk = 16;  // rows per unrolled chunk (code size)
+
+template <int OFF>
+__device__ __forceinline__ double tl_rd(uint32_t addr) {
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int KEEP, int W>
+__device__ __forceinline__ void tl_wait(double (&b)[W]) {
+  static_assert(W == 2 || W == 4 || W == 6 || W == 8, "");
+  if constexpr (W == 2)
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(KEEP) : "memory");
+  else if constexpr (W == 4)
+    asm volatile("s_waitcnt lgkmcnt(%4)"
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(KEEP)
+                 : "memory");
+  else if constexpr (W == 6)
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5])
+                 : "n"(KEEP)
+                 : "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]),
+                   "+v"(b[6]), "+v"(b[7])
+                 : "n"(KEEP)
+                 : "memory");
+}
+
+template <int W, int NPAIR>
+struct TlCtx {
+  static constexpr int D = (12 / W) > 0 ? 12 / W : 1;  // units in flight
+  static constexpr int NU = NPAIR * kTlGP;             // units (terms of this lane) per row
+  static constexpr int TOT = kTlChunk * NU;            // units per chunk
+  uint32_t ad[NPAIR][kTlGP][W];
+  double acc[NPAIR][kTlGP];
+  double buf[D][W];
+  double vs;  // weight of row = lane
+  double vr;  // weight of the current row, wave-uniform
+  int rc;     // first row of the chunk
+};
+
+template <int U, int W, int NPAIR>
+__device__ __forceinline__ void tl_issue(TlCtx<W, NPAIR> &c) {
+  using C = TlCtx<W, NPAIR>;
+  constexpr int rr = U / C::NU, unit = U % C::NU, q = unit / kTlGP, i = unit % kTlGP;
+#pragma unroll
+  for (int j = 0; j < W; ++j) c.buf[U % C::D][j] = tl_rd<rr * 8>(c.ad[q][i][j]);
+}
+
+template <int U, int W, int NPAIR>
+__device__ __forceinline__ void tl_steps(TlCtx<W, NPAIR> &c) {
+  using C = TlCtx<W, NPAIR>;
+  if constexpr (U < C::TOT) {
+    constexpr int rr = U / C::NU, unit = U % C::NU, q = unit / kTlGP, i = unit % kTlGP;
+    if constexpr (U + C::D - 1 < C::TOT) tl_issue<U + C::D - 1>(c);
+    if constexpr (unit == 0) c.vr = readlane_f64(c.vs, c.rc + rr);
+    constexpr int newer = (C::TOT - 1 - U) < (C::D - 1) ? (C::TOT - 1 - U) : (C::D - 1);
+    tl_wait<newer * W>(c.buf[U % C::D]);
+    double v = c.buf[U % C::D][0];
+#pragma unroll
+    for (int j = 1; j < W; ++j) v *= c.buf[U % C::D][j];
+    c.acc[q][i] = fma(v, c.vr, c.acc[q][i]);
+    tl_steps<U + 1>(c);
+  }
+}
+
+template <int U, int W, int NPAIR>
+__device__ __forceinline__ void tl_prologue(TlCtx<W, NPAIR> &c) {
+  if constexpr (U < TlCtx<W, NPAIR>::D - 1) {
+    tl_issue<U>(c);
+    tl_prologue<U + 1>(c);
+  }
+}
+
+template <int W2, bool SQ, int NPAIR, bool PREFETCH>
+__global__ void __launch_bounds__(kTlThreads, 4)
+k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
+         const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc,
+         const uint32_t *__restrict__ colsw, const double *__restrict__ a, uint64_t n,
+         uint64_t ntiles, uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ part) {
+  extern __shared__ double lds[];
+  constexpr int W = 2 * W2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+
+  // my terms: group ((blockIdx.y * NPAIR + q) * 8 + wave) * 2 + i, term = group * 64 + lane
+  TlCtx<W, NPAIR> c;
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+    for (int i = 0; i < kTlGP; ++i) {
+      const uint64_t k =
+          ((((uint64_t)blockIdx.y * NPAIR + q) * kTlWaves + wave) * kTlGP + i) * 64 + lane;
+      c.acc[q][i] = 0.0;
+#pragma unroll
+      for (int w = 0; w < W2; ++w) {
+        const uint32_t cw = k < p_pad ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+        c.ad[q][i][2 * w] = (cw & 0xffffu) * (kTlPitch * 8);
+        c.ad[q][i][2 * w + 1] = (cw >> 16) * (kTlPitch * 8);
+      }
+    }
+
+  // this wave stages columns u = wave + 8 q of every tile: their tile offsets, wave-uniform
+  int lu[PREFETCH ? kTlPre : 1];
+  double pre[PREFETCH ? kTlPre : 1];
+  if (PREFETCH) {
+#pragma unroll
+    for (int q = 0; q < kTlPre; ++q) {
+      const int u = wave + kTlWaves * q;
+      lu[q] = u < Mu ? __builtin_amdgcn_readfirstlane((int)ucol[u] * kTileRows) : 0;
+    }
+  }
+  double vsn = 0.0;
+  auto weight = [&](uint64_t tile) {
+    const uint64_t row = tile * kTileRows + lane;
+    double v = 0.0;
+    if (row < n) {
+      const double s = scale[row];
+      v = a[row] * (SQ ? s * s : s);  // b = basescale % a, linalg.cpp:305
+    }
+    return v;
+  };
+  auto fetch = [&](uint64_t tile) {
+    const double *src = bm + tile * Mc * kTileRows + lane;
+#pragma unroll
+    for (int q = 0; q < kTlPre; ++q) {
+      const int u = wave + kTlWaves * q;
+      pre[q] = u < Mu ? src[lu[q]] : 0.0;
+    }
+    vsn = weight(tile);
+  };
+  if (PREFETCH && t0 < t1) fetch(t0);
+
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    __syncthreads();  // every wave is done with the previous tile
+    if (PREFETCH) {
+#pragma unroll
+      for (int q = 0; q < kTlPre; ++q) {
+        const int u = wave + kTlWaves * q;
+        if (u < Mu) lds[u * kTlPitch + lane] = SQ ? pre[q] * pre[q] : pre[q];
+      }
+      c.vs = vsn;
+    } else {
+      const double *src = bm + tile * Mc * kTileRows + lane;
+      for (int u = wave; u < Mu; u += kTlWaves) {
+        const double v = src[(size_t)ucol[u] * kTileRows];
+        lds[u * kTlPitch + lane] = SQ ? v * v : v;
+      }
+      c.vs = weight(tile);
+    }
+    __syncthreads();
+    if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
+#pragma unroll 1
+    for (int rc = 0; rc < kTileRows; rc += kTlChunk) {
+      c.rc = rc;
+      tl_prologue<0>(c);
+      tl_steps<0>(c);
+#pragma unroll
+      for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+        for (int i = 0; i < kTlGP; ++i)
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            // next chunk, or back to row 0; opaque so that no second copy of the addresses
+            // is kept (and spilled) across the tile loop
+            c.ad[q][i][j] += (rc + kTlChunk < kTileRows) ? kTlChunk * 8 : -(kTileRows - kTlChunk) * 8;
+            asm volatile("" : "+v"(c.ad[q][i][j]));
+          }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+    for (int i = 0; i < kTlGP; ++i) {
+      const uint64_t k =
+          ((((uint64_t)blockIdx.y * NPAIR + q) * kTlWaves + wave) * kTlGP + i) * 64 + lane;
+      if (k < p_pad) part[(uint64_t)blockIdx.x * p_pad + k] = c.acc[q][i];
+    }
+}
+
 __global__ void k_tmm_reduce(const double *__restrict__ part, int nsplit, uint64_t p_pad, int p,
                              double *__restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,18 +538,95 @@ int launch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d
   return squared ? dispatch_mm<1>(b, t, d_a, d_out) : dispatch_mm<0>(b, t, d_a, d_out);
 }
 
+template <int W2, bool SQ, int NPAIR>
+int run_tmm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, double *part, dim3 grid,
+               uint64_t ntiles, uint64_t tps) {
+  const size_t lds = t.Mu * kTlPitch * sizeof(double);
+  const bool pf = t.Mu <= (uint64_t)kTlWaves * kTlPre;
+  if (pf) {
+    OB_TRY(set_lds(k_tmm_tl<W2, SQ, NPAIR, true>, lds));
+    hipLaunchKernelGGL((k_tmm_tl<W2, SQ, NPAIR, true>), grid, dim3(kTlThreads), lds, cur_stream(),
+                       b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,
+                       d_a, b.n, ntiles, tps, t.p_pad, part);
+  } else {
+    OB_TRY(set_lds(k_tmm_tl<W2, SQ, NPAIR, false>, lds));
+    hipLaunchKernelGGL((k_tmm_tl<W2, SQ, NPAIR, false>), grid, dim3(kTlThreads), lds, cur_stream(),
+                       b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,
+                       d_a, b.n, ntiles, tps, t.p_pad, part);
+  }
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+// terms per block of k_tmm_tl: 8 waves x NPAIR x 2 groups of 64
+template <bool SQ>
+int dispatch_tmm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, double *part,
+                    unsigned nsplit, int npair, uint64_t ntiles, uint64_t tps) {
+  const uint64_t tpb = (uint64_t)kTlWaves * npair * kTlGP * 64;
+  const dim3 grid(nsplit, (unsigned)((t.p_pad + tpb - 1) / tpb));
+#define OB_TL(W2_, NP_) return run_tmm_tl<W2_, SQ, NP_>(b, t, d_a, part, grid, ntiles, tps)
+  switch (t.W / 2) {
+    case 1: if (npair == 4) OB_TL(1, 4); if (npair == 2) OB_TL(1, 2); OB_TL(1, 1);
+    case 2: if (npair == 4) OB_TL(2, 4); if (npair == 2) OB_TL(2, 2); OB_TL(2, 1);
+    case 3: if (npair == 2) OB_TL(3, 2); OB_TL(3, 1);
+    default: if (npair == 2) OB_TL(4, 2); OB_TL(4, 1);
+  }
+#undef OB_TL
+}
+
+int device_cus(int device) {
+  static int ncu = 0;
+  if (!ncu) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+        ncu <= 0)
+      ncu = 256;
+  }
+  return ncu;
+}
+
+int tmm_tl_supports(const obhip_terms &t) {
+  const int w2 = (int)(t.W / 2);
+  return w2 >= 1 && w2 <= kMaxW2 && t.Mu * kTlPitch * sizeof(double) <= 156 * 1024;
+}
+
 int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, bool squared) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   OB_TRY(check_mu(t));
   const uint64_t ntiles = b.n_pad / kTileRows;
+  const uint64_t p_pad = t.p_pad;  // multiple of 256 (obhip_terms::prepare)
+  double *part = nullptr;
+  static const bool force_rows = getenv("OBHIP_TMM_LANE_ROW") != nullptr;
+  if (tmm_tl_supports(t) && !force_rows) {
+    // term-per-lane kernel: the fewest blocks along p that the register budget allows
+    const int npmax = t.W / 2 <= 2 ? 4 : 2;
+    int npair = 1;
+    while (npair < npmax && (uint64_t)kTlWaves * npair * kTlGP * 64 < p_pad) npair *= 2;
+    const uint64_t tpb = (uint64_t)kTlWaves * npair * kTlGP * 64;
+    const uint64_t pblocks = (p_pad + tpb - 1) / tpb;
+    // two resident blocks per CU, two rounds
+    uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)device_cus(b.device) * 4 / pblocks);
+    nsplit = std::min(nsplit, std::max<uint64_t>(1, ntiles / 4));
+    const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
+    nsplit = (ntiles + tps - 1) / tps;
+    OB_TRY(const_cast<obhip_basis &>(b).workspace(nsplit * p_pad * sizeof(double), (void **)&part));
+    {
+      ProfScope ps(squared ? "sqtmm" : "tmm");
+      if (squared)
+        OB_TRY(dispatch_tmm_tl<true>(b, t, d_a, part, (unsigned)nsplit, npair, ntiles, tps));
+      else
+        OB_TRY(dispatch_tmm_tl<false>(b, t, d_a, part, (unsigned)nsplit, npair, ntiles, tps));
+    }
+    hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 255) / 256)), dim3(256), 0, cur_stream(),
+                       part, (int)nsplit, p_pad, (int)t.p, d_out);
+    OB_HIP(hipGetLastError());
+    return 0;
+  }
   const uint64_t pblocks = (t.p + 255) / 256;
   // enough blocks to fill 256 CUs a few times over, each with >= 4 tiles
   uint64_t nsplit = std::max<uint64_t>(1, (256 * 6 + pblocks - 1) / pblocks);
   nsplit = std::min(nsplit, std::max<uint64_t>(1, ntiles / 4));
   const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
   nsplit = (ntiles + tps - 1) / tps;
-  const uint64_t p_pad = t.p_pad;  // multiple of 256 (obhip_terms::prepare)
-  double *part = nullptr;
   OB_TRY(const_cast<obhip_basis &>(b).workspace(nsplit * p_pad * sizeof(double), (void **)&part));
   const dim3 grid((unsigned)nsplit, (unsigned)pblocks);
   {

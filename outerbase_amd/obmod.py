@@ -488,13 +488,21 @@ class lpdf:
         q = self.hessmult(pv)
         valdiff = 10.0
         self.cgiters = 0
+        num0 = None
         for _ in range(int(maxepch)):
             num = float(np.sum(self.grad * rm))
             if num < tol and valdiff < tol:
                 break
+            if num0 is None:
+                num0 = num
+            if num <= 1e-28 * num0:   # rounding floor, see obhip_fit_cg_dev
+                break
             if not num > 0.0:     # exactly stationary: the next direction would be 0 / 0
                 break
-            alpha = num / float(np.sum(q * pv))
+            denom = float(np.sum(q * pv))
+            if not denom > 0.0:   # the direction cancelled to zero (p = 1, second iteration)
+                break
+            alpha = num / denom
             coeff = coeff + alpha * pv
             valo = self.val
             self.update(coeff)

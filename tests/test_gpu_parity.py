@@ -918,6 +918,43 @@ def test_random_terms_caps_and_gram_backends(seed):
     assert relerr(bd.matmul(terms, a), B2 @ a) < tol
 
 
+@pytest.mark.parametrize("max_nnz,p,maxlev", [
+    (2, 64, 3), (2, 3000, 12), (2, 20000, 14),       # W = 2: NPAIR 1 / 2 / 4, two blocks along p
+    (4, 300, 4), (4, 2300, 6), (4, 9000, 6),          # W = 4, up to three blocks along p
+    (6, 700, 3), (6, 2500, 5),                        # W = 6: NPAIR 1 / 2
+    (8, 1030, 3), (8, 4200, 3),                       # W = 8, three blocks along p
+    (4, 3000, 14),                                    # > 128 used columns: staging without prefetch
+])
+def test_tmm_term_per_lane_variants(max_nnz, p, maxlev):
+    """Every instantiation of the term-per-lane B^T a kernel (k_tmm_tl: columns per term,
+    term pairs per wave, prefetch on / off, several blocks along p), plain and squared,
+    against the oracle's design matrix on ragged row counts."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    rng = np.random.default_rng(31 * max_nnz + p)
+    d = 10
+    kinds = ["mat25", "mat25pow", "mat25ang", "mat25", "mat25"] * 2
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 16))
+    terms = np.unique(random_terms(rng, p, d, maxlev, max_nnz), axis=0)
+    if maxlev == 14:
+        assert len({(l, t) for l in range(d) for t in set(terms[:, l]) if t > 0}) > 128
+    for n in (1, 191, 1100):
+        x = sample_x(rng, n, kinds)
+        B = O.ob_getmat(O.OuterBase(om_o, x), terms)
+        bd = ob.outerbase(om_d, x)
+        v = rng.standard_normal(n)
+        # high levels lose digits in cov x rotmat on both sides (see test_gram_backends), so
+        # the oracle pins the result loosely and the device's own design matrix (getmat, the
+        # lane = row kernel) pins the contraction tightly
+        tol = 1e-6 if maxlev >= 5 else 1e-9
+        Bd = bd.getmat(terms)
+        got, gotsq = bd.tmatmul(terms, v), bd.sqtmm(terms, v)
+        assert relerr(got, B.T @ v) < tol
+        assert relerr(gotsq, (B * B).T @ v) < tol
+        assert relerr(got, Bd.T @ v) < 1e-12
+        assert relerr(gotsq, (Bd * Bd).T @ v) < 1e-12
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_random_lpdf_level_quantities(seed):
     """Third fuzz: the lpdf-level values and gradients (loglik_gauss / loglik_std /
