@@ -446,6 +446,210 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
     }
 }
 
+// ---- mm, term-per-lane ----------------------------------------------------------------------
+// out = B a with the same lane = term layout: a wave holds NG terms per lane (addresses and
+// coefficient in registers for the whole launch), accumulates a_k * prod over its terms for
+// 8 rows at a time (acc[row], lane = term) and only then reduces across the 64 lanes: a
+// butterfly with v_permlane32_swap / v_permlane16_swap takes the 16 accumulators to 4 (each
+// 16-lane row of a register then belongs to one tile row), 4 DPP rotations finish the sum.
+// That is ~5 VALU instructions per row and wave against 4 per (term, row) for the products,
+// where the lane = row kernel spends 13 per (term, row) (column broadcast, address, product).
+constexpr int kMlChunk = 8;  // rows per chunk: 8 accumulators, the register budget is tight
+
+template <int W, int NG>
+struct MlCtx {
+  static constexpr int D = (12 / W) > 0 ? 12 / W : 1;  // units in flight
+  static constexpr int TOT = kMlChunk * NG;            // units per chunk
+  uint32_t ad[NG][W];
+  double av[NG];
+  double buf[D][W];
+  double acc[kMlChunk];
+};
+
+template <int U, int W, int NG>
+__device__ __forceinline__ void ml_issue(MlCtx<W, NG> &c) {
+  using C = MlCtx<W, NG>;
+  constexpr int rr = U / NG, g = U % NG;
+#pragma unroll
+  for (int j = 0; j < W; ++j) c.buf[U % C::D][j] = tl_rd<rr * 8>(c.ad[g][j]);
+}
+
+template <int U, int W, int NG>
+__device__ __forceinline__ void ml_steps(MlCtx<W, NG> &c) {
+  using C = MlCtx<W, NG>;
+  if constexpr (U < C::TOT) {
+    constexpr int rr = U / NG, g = U % NG;
+    if constexpr (U + C::D - 1 < C::TOT) ml_issue<U + C::D - 1>(c);
+    constexpr int newer = (C::TOT - 1 - U) < (C::D - 1) ? (C::TOT - 1 - U) : (C::D - 1);
+    tl_wait<newer * W>(c.buf[U % C::D]);
+    double v = c.buf[U % C::D][0];
+#pragma unroll
+    for (int j = 1; j < W; ++j) v *= c.buf[U % C::D][j];
+    c.acc[rr] = fma(v, c.av[g], c.acc[rr]);
+    ml_steps<U + 1>(c);
+  }
+}
+
+template <int U, int W, int NG>
+__device__ __forceinline__ void ml_prologue(MlCtx<W, NG> &c) {
+  if constexpr (U < MlCtx<W, NG>::D - 1 && U < MlCtx<W, NG>::TOT) {
+    ml_issue<U>(c);
+    ml_prologue<U + 1>(c);
+  }
+}
+
+// a + b where, afterwards, lanes 0-31 hold the sum of a over lanes (l, l + 32) and lanes
+// 32-63 the sum of b over (l - 32, l)
+__device__ __forceinline__ double swap32_sum(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a),
+                                                   (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a),
+                                                   (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// the same one level down: 16-lane rows 0 and 2 end with the sum of a over rows (0,1) and
+// (2,3), rows 1 and 3 with the sum of b
+__device__ __forceinline__ double swap16_sum(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a),
+                                                   (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a),
+                                                   (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <int ROR>
+__device__ __forceinline__ double row16_ror_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + ROR, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + ROR, 0xf, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+
+template <int W2, bool SQ, int NG, bool PREFETCH>
+__global__ void __launch_bounds__(kTlThreads, 4)
+k_mm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
+        const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc, const uint32_t *__restrict__ colsw,
+        const double *__restrict__ a, int p, uint64_t n, uint64_t n_pad, uint64_t ntiles,
+        uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ out,
+        double *__restrict__ part) {
+  extern __shared__ double lds[];
+  constexpr int W = 2 * W2;
+  double *red = lds + (size_t)Mu * kTlPitch;  // [8 waves][64 rows]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+
+  // my terms: group (blockIdx.y * NG + g) * 8 + wave, term = group * 64 + lane
+  MlCtx<W, NG> c;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const uint64_t k = (((uint64_t)blockIdx.y * NG + g) * kTlWaves + wave) * 64 + lane;
+    c.av[g] = k < (uint64_t)p ? a[k] : 0.0;
+#pragma unroll
+    for (int w = 0; w < W2; ++w) {
+      const uint32_t cw = k < p_pad ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+      c.ad[g][2 * w] = (cw & 0xffffu) * (kTlPitch * 8);
+      c.ad[g][2 * w + 1] = (cw >> 16) * (kTlPitch * 8);
+    }
+  }
+
+  int lu[PREFETCH ? kTlPre : 1];
+  double pre[PREFETCH ? kTlPre : 1];
+  if (PREFETCH) {
+#pragma unroll
+    for (int q = 0; q < kTlPre; ++q) {
+      const int u = wave + kTlWaves * q;
+      lu[q] = u < Mu ? __builtin_amdgcn_readfirstlane((int)ucol[u] * kTileRows) : 0;
+    }
+  }
+  auto fetch = [&](uint64_t tile) {
+    const double *src = bm + tile * Mc * kTileRows + lane;
+#pragma unroll
+    for (int q = 0; q < kTlPre; ++q) {
+      const int u = wave + kTlWaves * q;
+      pre[q] = u < Mu ? src[lu[q]] : 0.0;
+    }
+  };
+  // row sums of a finished tile: wave 0, lane = row
+  auto emit = [&](uint64_t tile) {
+    const uint64_t row = tile * kTileRows + lane;
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < kTlWaves; ++q) tot += red[q * kTileRows + lane];
+    if (part != nullptr) {
+      part[(uint64_t)blockIdx.y * n_pad + row] = tot;  // scaled by k_mm_tl_sum
+    } else if (row < n) {
+      const double sc = scale[row];
+      out[row] = tot * (SQ ? sc * sc : sc);
+    }
+  };
+  if (PREFETCH && t0 < t1) fetch(t0);
+
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    __syncthreads();  // every wave is done with the previous tile, its row sums are in red
+    if (tile > t0 && wave == 0) emit(tile - 1);
+    if (PREFETCH) {
+#pragma unroll
+      for (int q = 0; q < kTlPre; ++q) {
+        const int u = wave + kTlWaves * q;
+        if (u < Mu) lds[u * kTlPitch + lane] = SQ ? pre[q] * pre[q] : pre[q];
+      }
+    } else {
+      const double *src = bm + tile * Mc * kTileRows + lane;
+      for (int u = wave; u < Mu; u += kTlWaves) {
+        const double v = src[(size_t)ucol[u] * kTileRows];
+        lds[u * kTlPitch + lane] = SQ ? v * v : v;
+      }
+    }
+    __syncthreads();  // tile staged; wave 0 has read red
+    if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
+#pragma unroll 1
+    for (int rc = 0; rc < kTileRows; rc += kMlChunk) {
+#pragma unroll
+      for (int r = 0; r < kMlChunk; ++r) c.acc[r] = 0.0;
+      ml_prologue<0>(c);
+      ml_steps<0>(c);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          c.ad[g][j] += (rc + kMlChunk < kTileRows) ? kMlChunk * 8 : -(kTileRows - kMlChunk) * 8;
+          asm volatile("" : "+v"(c.ad[g][j]));
+        }
+      // 8 accumulators x 64 lanes -> 2 registers whose 16-lane row q holds tile row
+      // rc + i + 2 q, then the sum over the 16 lanes of the row
+      static_assert(kMlChunk == 8, "butterfly below reduces 8 rows");
+      double s4[4], s2[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s4[i] = swap32_sum(c.acc[i], c.acc[i + 4]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) s2[i] = swap16_sum(s4[i], s4[i + 2]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        double v = row16_ror_add<8>(s2[i]);
+        v = row16_ror_add<4>(v);
+        v = row16_ror_add<2>(v);
+        v = row16_ror_add<1>(v);
+        if ((lane & 15) == 0) red[wave * kTileRows + rc + i + 2 * (lane >> 4)] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (t0 < t1 && wave == 0) emit(t1 - 1);
+}
+
+// several blocks along p: out = scale * sum of their partial row sums
+template <bool SQ>
+__global__ void k_mm_tl_sum(const double *__restrict__ part, int pblocks, uint64_t n_pad,
+                            const double *__restrict__ scale, uint64_t n,
+                            double *__restrict__ out) {
+  const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  double tot = 0.0;
+  for (int y = 0; y < pblocks; ++y) tot += part[(uint64_t)y * n_pad + row];
+  const double sc = scale[row];
+  out[row] = tot * (SQ ? sc * sc : sc);
+}
+
 __global__ void k_tmm_reduce(const double *__restrict__ part, int nsplit, uint64_t p_pad, int p,
                              double *__restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -531,11 +735,95 @@ int launch_getmat(const obhip_basis &b, obhip_terms &t, double *d_out) {
   return dispatch_mm<2>(b, t, nullptr, d_out);
 }
 
+int device_cus(int device) {
+  static int ncu = 0;
+  if (!ncu) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+        ncu <= 0)
+      ncu = 256;
+  }
+  return ncu;
+}
+
+template <int W2, bool SQ, int NG>
+int run_mm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, double *part,
+              dim3 grid, uint64_t ntiles, uint64_t tps) {
+  const size_t lds = (t.Mu * kTlPitch + kTlWaves * kTileRows) * sizeof(double);
+  const bool pf = t.Mu <= (uint64_t)kTlWaves * kTlPre;
+  if (pf) {
+    OB_TRY(set_lds(k_mm_tl<W2, SQ, NG, true>, lds));
+    hipLaunchKernelGGL((k_mm_tl<W2, SQ, NG, true>), grid, dim3(kTlThreads), lds, cur_stream(), b.bm.p,
+                       b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, d_a,
+                       (int)t.p, b.n, b.n_pad, ntiles, tps, t.p_pad, d_out, part);
+  } else {
+    OB_TRY(set_lds(k_mm_tl<W2, SQ, NG, false>, lds));
+    hipLaunchKernelGGL((k_mm_tl<W2, SQ, NG, false>), grid, dim3(kTlThreads), lds, cur_stream(), b.bm.p,
+                       b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, d_a,
+                       (int)t.p, b.n, b.n_pad, ntiles, tps, t.p_pad, d_out, part);
+  }
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+template <bool SQ>
+int dispatch_mm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out,
+                   double *part, dim3 grid, int ng, uint64_t ntiles, uint64_t tps) {
+#define OB_ML(W2_, NG_) return run_mm_tl<W2_, SQ, NG_>(b, t, d_a, d_out, part, grid, ntiles, tps)
+  switch (t.W / 2) {
+    case 1: if (ng == 8) OB_ML(1, 8); if (ng == 4) OB_ML(1, 4); if (ng == 2) OB_ML(1, 2); OB_ML(1, 1);
+    case 2: if (ng == 8) OB_ML(2, 8); if (ng == 4) OB_ML(2, 4); if (ng == 2) OB_ML(2, 2); OB_ML(2, 1);
+    case 3: if (ng == 4) OB_ML(3, 4); if (ng == 2) OB_ML(3, 2); OB_ML(3, 1);
+    default: if (ng == 4) OB_ML(4, 4); if (ng == 2) OB_ML(4, 2); OB_ML(4, 1);
+  }
+#undef OB_ML
+}
+
+int mm_tl_supports(const obhip_terms &t) {
+  const int w2 = (int)(t.W / 2);
+  return w2 >= 1 && w2 <= kMaxW2 &&
+         (t.Mu * kTlPitch + kTlWaves * kTileRows) * sizeof(double) <= 156 * 1024;
+}
+
 int launch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, bool squared) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   OB_TRY(check_mu(t));
+  static const bool force_rows = getenv("OBHIP_MM_LANE_ROW") != nullptr;
+  if (!mm_tl_supports(t) || force_rows) {
+    ProfScope ps(squared ? "sqmm" : "mm");
+    return squared ? dispatch_mm<1>(b, t, d_a, d_out) : dispatch_mm<0>(b, t, d_a, d_out);
+  }
+  // term-per-lane kernel: a block of 8 waves x NG groups x 64 terms, as few blocks along p
+  // as the register budget allows
+  const int ngmax = t.W / 2 <= 2 ? 8 : 4;
+  int ng = 1;
+  while (ng < ngmax && (uint64_t)kTlWaves * ng * 64 < t.p_pad) ng *= 2;
+  const uint64_t tpb = (uint64_t)kTlWaves * ng * 64;
+  const uint64_t pblocks = (t.p_pad + tpb - 1) / tpb;
+  const uint64_t ntiles = b.n_pad / kTileRows;
+  uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)device_cus(b.device) * 4 / pblocks);
+  nsplit = std::min(nsplit, ntiles);
+  const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  double *part = nullptr;
+  if (pblocks > 1)
+    OB_TRY(const_cast<obhip_basis &>(b).workspace(pblocks * b.n_pad * sizeof(double), (void **)&part));
+  const dim3 grid((unsigned)nsplit, (unsigned)pblocks);
   ProfScope ps(squared ? "sqmm" : "mm");
-  return squared ? dispatch_mm<1>(b, t, d_a, d_out) : dispatch_mm<0>(b, t, d_a, d_out);
+  if (squared)
+    OB_TRY(dispatch_mm_tl<true>(b, t, d_a, d_out, part, grid, ng, ntiles, tps));
+  else
+    OB_TRY(dispatch_mm_tl<false>(b, t, d_a, d_out, part, grid, ng, ntiles, tps));
+  if (pblocks > 1) {
+    const dim3 g2((unsigned)((b.n + 255) / 256));
+    if (squared)
+      hipLaunchKernelGGL(k_mm_tl_sum<true>, g2, dim3(256), 0, cur_stream(), part, (int)pblocks,
+                         b.n_pad, b.scale.p, b.n, d_out);
+    else
+      hipLaunchKernelGGL(k_mm_tl_sum<false>, g2, dim3(256), 0, cur_stream(), part, (int)pblocks,
+                         b.n_pad, b.scale.p, b.n, d_out);
+    OB_HIP(hipGetLastError());
+  }
+  return 0;
 }
 
 template <int W2, bool SQ, int NPAIR>
@@ -572,16 +860,6 @@ int dispatch_tmm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, dou
     default: if (npair == 2) OB_TL(4, 2); OB_TL(4, 1);
   }
 #undef OB_TL
-}
-
-int device_cus(int device) {
-  static int ncu = 0;
-  if (!ncu) {
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-        ncu <= 0)
-      ncu = 256;
-  }
-  return ncu;
 }
 
 int tmm_tl_supports(const obhip_terms &t) {

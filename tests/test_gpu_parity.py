@@ -925,10 +925,10 @@ def test_random_terms_caps_and_gram_backends(seed):
     (8, 1030, 3), (8, 4200, 3),                       # W = 8, three blocks along p
     (4, 3000, 14),                                    # > 128 used columns: staging without prefetch
 ])
-def test_tmm_term_per_lane_variants(max_nnz, p, maxlev):
-    """Every instantiation of the term-per-lane B^T a kernel (k_tmm_tl: columns per term,
-    term pairs per wave, prefetch on / off, several blocks along p), plain and squared,
-    against the oracle's design matrix on ragged row counts."""
+def test_term_per_lane_variants(max_nnz, p, maxlev):
+    """Every instantiation of the term-per-lane kernels (k_tmm_tl for B^T a, k_mm_tl for B a:
+    columns per term, terms per lane, prefetch on / off, several blocks along p), plain and
+    squared, against the oracle's design matrix on ragged row counts."""
     import ob_oracle as O
     import outerbase_amd as ob
     rng = np.random.default_rng(31 * max_nnz + p)
@@ -938,7 +938,9 @@ def test_tmm_term_per_lane_variants(max_nnz, p, maxlev):
     terms = np.unique(random_terms(rng, p, d, maxlev, max_nnz), axis=0)
     if maxlev == 14:
         assert len({(l, t) for l in range(d) for t in set(terms[:, l]) if t > 0}) > 128
-    for n in (1, 191, 1100):
+    for n in (1, 191, 1100, 70000):
+        if n > 2000 and terms.shape[0] > 3000:
+            continue            # the oracle's n x p design matrix
         x = sample_x(rng, n, kinds)
         B = O.ob_getmat(O.OuterBase(om_o, x), terms)
         bd = ob.outerbase(om_d, x)
@@ -953,6 +955,12 @@ def test_tmm_term_per_lane_variants(max_nnz, p, maxlev):
         assert relerr(gotsq, (B * B).T @ v) < tol
         assert relerr(got, Bd.T @ v) < 1e-12
         assert relerr(gotsq, (Bd * Bd).T @ v) < 1e-12
+        a = rng.standard_normal(terms.shape[0])
+        got, gotsq = bd.matmul(terms, a), bd.sqmm(terms, np.abs(a))
+        assert relerr(got, B @ a) < tol
+        assert relerr(gotsq, (B * B) @ np.abs(a)) < tol
+        assert relerr(got, Bd @ a) < 1e-12
+        assert relerr(gotsq, (Bd * Bd) @ np.abs(a)) < 1e-12
 
 
 @pytest.mark.parametrize("seed", range(16))
