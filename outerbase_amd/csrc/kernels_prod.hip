@@ -650,13 +650,33 @@ __global__ void k_mm_tl_sum(const double *__restrict__ part, int pblocks, uint64
   out[row] = tot * (SQ ? sc * sc : sc);
 }
 
-__global__ void k_tmm_reduce(const double *__restrict__ part, int nsplit, uint64_t p_pad, int p,
-                             double *__restrict__ out) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= p) return;
-  double s = 0.0;
-  for (int r = 0; r < nsplit; ++r) s += part[(uint64_t)r * p_pad + k];
-  out[k] = s;
+// out[k] = sum over the row splits of part[split][k]: a block takes 64 terms, its 16 waves
+// every 16th split each (coalesced 512-byte reads), LDS tree over the waves.  Fixed order,
+// so the result does not depend on the launch.
+constexpr int kRedThreads = 1024;
+__global__ void __launch_bounds__(kRedThreads)
+k_tmm_reduce(const double *__restrict__ part, int nsplit, uint64_t p_pad, int p,
+             double *__restrict__ out) {
+  __shared__ double red[kRedThreads / 64][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int r = w;
+  for (; r + 48 < nsplit; r += 64) {
+    s0 += part[(uint64_t)r * p_pad + k];
+    s1 += part[(uint64_t)(r + 16) * p_pad + k];
+    s2 += part[(uint64_t)(r + 32) * p_pad + k];
+    s3 += part[(uint64_t)(r + 48) * p_pad + k];
+  }
+  for (; r < nsplit; r += 16) s0 += part[(uint64_t)r * p_pad + k];
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && k < p) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < kRedThreads / 64; ++q) tot += red[q][lane];
+    out[k] = tot;
+  }
 }
 
 template <typename K>
@@ -881,8 +901,8 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *
     while (npair < npmax && (uint64_t)kTlWaves * npair * kTlGP * 64 < p_pad) npair *= 2;
     const uint64_t tpb = (uint64_t)kTlWaves * npair * kTlGP * 64;
     const uint64_t pblocks = (p_pad + tpb - 1) / tpb;
-    // two resident blocks per CU, two rounds
-    uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)device_cus(b.device) * 4 / pblocks);
+    // two resident blocks per CU, one round
+    uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)device_cus(b.device) * 2 / pblocks);
     nsplit = std::min(nsplit, std::max<uint64_t>(1, ntiles / 4));
     const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
     nsplit = (ntiles + tps - 1) / tps;
@@ -894,8 +914,8 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *
       else
         OB_TRY(dispatch_tmm_tl<false>(b, t, d_a, part, (unsigned)nsplit, npair, ntiles, tps));
     }
-    hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 255) / 256)), dim3(256), 0, cur_stream(),
-                       part, (int)nsplit, p_pad, (int)t.p, d_out);
+    hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0,
+                       cur_stream(), part, (int)nsplit, p_pad, (int)t.p, d_out);
     OB_HIP(hipGetLastError());
     return 0;
   }
@@ -914,8 +934,8 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *
     else
       OB_TRY(dispatch_tmm<false>(b, t, d_a, part, grid, ntiles, tps));
   }
-  hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 255) / 256)), dim3(256), 0, cur_stream(),
-                     part, (int)nsplit, p_pad, (int)t.p, d_out);
+  hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0,
+                     cur_stream(), part, (int)nsplit, p_pad, (int)t.p, d_out);
   OB_HIP(hipGetLastError());
   return 0;
 }
