@@ -60,6 +60,10 @@ int obhip_set_device(int device);
 /* hipStream_t to launch on (NULL = default stream). */
 int obhip_set_stream(void *hip_stream);
 int obhip_synchronize(void);
+/* Device temporaries of the calls below are recycled through a size-keyed pool (at most
+ * OBHIP_POOL_MB, default 8192, of cached memory); this hands the cached blocks back to the
+ * driver. */
+int obhip_trim_pool(void);
 /* Per-kernel hipEvent timing (used by bench.py for the roofline line). */
 int obhip_profile_enable(int on);
 int obhip_profile_reset(void);
@@ -209,6 +213,11 @@ int obhip_basis_getmat_gradhyp(const obhip_basis *b, const obhip_terms *t, doubl
  * out (n, may be NULL) = B a, out_gradhyp n x nhyp column-major. */
 int obhip_basis_mm_gradhyp(const obhip_basis *b, const obhip_terms *t, const double *a,
                            double *out, double *out_gradhyp);
+/* w^T d(B a)/dhyp (nhyp values) with the n x nhyp matrix left on the device: the form the
+ * likelihoods use matmul_gradhyp in (src/lpdfs/loglik_gauss.cpp:127, loglik_std.cpp:143).
+ * out (n, B a) may be NULL. */
+int obhip_basis_mm_gradhyp_dot(const obhip_basis *b, const obhip_terms *t, const double *a,
+                               const double *w, double *out, double *out_dot);
 /* ob$tmatmul_gradhyp(terms, a): modandbase.cpp:755-776 (tprodmmge_, linalg.cpp:395-471);
  * out (p, may be NULL) = B^T a, out_gradhyp p x nhyp column-major. */
 int obhip_basis_tmm_gradhyp(const obhip_basis *b, const obhip_terms *t, const double *a,

@@ -4,7 +4,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <iterator>
+#include <map>
 #include <mutex>
 
 #include "obhip_internal.h"
@@ -39,6 +42,76 @@ int require_device() {
 }
 
 hipStream_t cur_stream() { return g_stream; }
+
+// ---- device memory pool (see obhip_internal.h) ------------------------------------------
+namespace {
+struct PoolBlock {
+  void *p;
+  int device;
+  hipStream_t stream;
+};
+std::mutex g_pool_mu;
+std::multimap<size_t, PoolBlock> g_pool;
+size_t g_pool_bytes = 0;
+size_t pool_cap() {
+  static const size_t cap = [] {
+    const char *e = getenv("OBHIP_POOL_MB");
+    return (size_t)(e ? std::max(0, atoi(e)) : 8192) << 20;
+  }();
+  return cap;
+}
+}  // namespace
+
+void pool_trim() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (auto &kv : g_pool) (void)hipFree(kv.second.p);
+  g_pool.clear();
+  g_pool_bytes = 0;
+}
+
+int pool_alloc(void **p, size_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto range = g_pool.equal_range(bytes);
+    for (auto it = range.first; it != range.second; ++it)
+      if (it->second.device == dev && it->second.stream == cur_stream()) {
+        *p = it->second.p;
+        g_pool.erase(it);
+        g_pool_bytes -= bytes;
+        return 0;
+      }
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    pool_trim();
+    e = hipMalloc(p, bytes);
+  }
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+  return 0;
+}
+
+void pool_free(void *p, size_t bytes) {
+  if (!p) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (bytes > pool_cap() / 2) {
+    (void)hipFree(p);
+    return;
+  }
+  g_pool.emplace(bytes, PoolBlock{p, dev, cur_stream()});
+  g_pool_bytes += bytes;
+  while (g_pool_bytes > pool_cap() && !g_pool.empty()) {  // largest first
+    auto it = std::prev(g_pool.end());
+    (void)hipFree(it->second.p);
+    g_pool_bytes -= it->first;
+    g_pool.erase(it);
+  }
+}
+
 
 // ---- profiling ----------------------------------------------------------------
 struct ProfEntry {
@@ -227,6 +300,13 @@ int obhip_set_device(int device) {
 
 int obhip_set_stream(void *hip_stream) {
   g_stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+int obhip_trim_pool(void) {
+  OB_TRY(require_device());
+  OB_HIP(hipStreamSynchronize(cur_stream()));
+  pool_trim();
   return 0;
 }
 

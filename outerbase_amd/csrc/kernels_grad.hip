@@ -18,13 +18,18 @@
 //
 // Who computes what:
 //   getmat_gradhyp            getmat on the view, one pass per hyper-parameter
-//   matmul / sqmm _gradhyp    k_mmge: all hyper-parameters in one pass (a term only touches
-//                             the hyper-parameters of its own non-zero dimensions)
+//   matmul / sqmm _gradhyp    with M = sum_k a_k P_k (one k_mm pass over all terms) and
+//                             delta[h, t] = ge[h, t] - basemat[col(dim h, t)] ge[h, 0]:
+//                             out[:, h] = s (ge[h, 0] M + sum_{k: t_kl > 0} a_k E_k delta[h, t_kl]),
+//                             so per hyper-parameter only the terms that HAVE its dimension are
+//                             multiplied out (k_mm on a restricted view whose pseudo-dimension
+//                             points at the delta columns): nnz(terms) products instead of
+//                             p x nhyp
 //   tmatmul / sqtmm _gradhyp  k_bt_times_u: one streaming pass over the materialised design
 //                             matrix for the terms without the hyper-parameter's dimension,
 //                             + k_tmm on views restricted to the terms that have it
-//   fallback (tiles too large for the LDS, design matrix too large for the HBM): k_mm /
-//   k_tmm on the full views, one pass per hyper-parameter
+//   fallback (design matrix too large for the HBM): k_tmm on the full views, one pass per
+//   hyper-parameter
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "obhip_internal.h"
@@ -73,7 +78,7 @@ __device__ __forceinline__ double build_dim_grad(const DimDesc &D, const GradHyp
   double a0, a1, a2;
   kernel_pre<KIND>(D, xv, a0, a1, a2);
   const double lx = KIND == OBHIP_COV_MAT25POW ? log(xv) : 0.0;
-  double cl = 1.0;
+  double cl = 1.0, g00 = 0.0, g10 = 0.0;  // level-0 gradient columns of the two hyper-parameters
   for (int c0 = 0; c0 < D.ncolp; c0 += 8) {
     double r[8], t0[8], t1[8];
 #pragma unroll
@@ -94,14 +99,24 @@ __device__ __forceinline__ double build_dim_grad(const DimDesc &D, const GradHyp
         if (KIND != OBHIP_COV_MAT25) t1[c] = fma(d1, rc, fma(kv, g1p[o + c], t1[c]));
       }
     }
-    if (c0 == 0) cl = r[0];
+    if (c0 == 0) {
+      cl = r[0];
+      g00 = t0[0] / cl;
+      g10 = t1[0] / cl;
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int col = c0 + c;
       if (col < D.ncol) {
-        if (col >= 1) tile_out[(size_t)(D.ccol0 + col - 1) * kTileRows] = r[c] / cl;
-        tile_out[(size_t)(hy[0].gecol + col) * kTileRows] = t0[c] / cl;
-        if (KIND != OBHIP_COV_MAT25) tile_out[(size_t)(hy[1].gecol + col) * kTileRows] = t1[c] / cl;
+        const double bv = r[c] / cl, ge0 = t0[c] / cl, ge1 = t1[c] / cl;
+        tile_out[(size_t)(hy[0].gecol + col) * kTileRows] = ge0;
+        if (KIND != OBHIP_COV_MAT25) tile_out[(size_t)(hy[1].gecol + col) * kTileRows] = ge1;
+        if (col >= 1) {
+          tile_out[(size_t)(D.ccol0 + col - 1) * kTileRows] = bv;
+          tile_out[(size_t)(hy[0].dcol + col - 1) * kTileRows] = fma(-bv, g00, ge0);
+          if (KIND != OBHIP_COV_MAT25)
+            tile_out[(size_t)(hy[1].dcol + col - 1) * kTileRows] = fma(-bv, g10, ge1);
+        }
       }
     }
   }
@@ -187,20 +202,25 @@ int ensure_gradbasis(obhip_basis &b) {
       }
   }
   hhypst[d] = (int)m.hypst[d];
+  for (uint64_t h = 0; h < nh; ++h) {  // the delta blocks behind all gradient blocks
+    g->hyps_h[h].dcol = (int)gecol;
+    gecol += (uint64_t)b.md.dims_h[m.hypmatch[h]].ncol - 1;
+  }
   OB_TRY(g->hyps.upload(g->hyps_h.data(), nh));
   OB_TRY(g->rotg.upload(hrotg.data(), hrotg.size()));
   OB_TRY(g->kd.upload(hkd.data(), hkd.size()));
   DevBuf<int> dhypst;
   OB_TRY(dhypst.upload(hhypst.data(), hhypst.size()));
 
-  // the combined array as an obhip_basis whose dimension table is extended by one
-  // pseudo-dimension per hyper-parameter: its level j >= 1 is gradient level j - 1
+  // the combined array as an obhip_basis whose dimension table is extended by two
+  // pseudo-dimensions per hyper-parameter: d + h, whose level j >= 1 is gradient level j - 1,
+  // and d + nhyp + h, whose level j >= 1 is delta level j
   g->gb = std::make_unique<obhip_basis>();
   obhip_basis &gb = *g->gb;
   gb.model = b.model;
   gb.n = b.n;
   gb.n_pad = b.n_pad;
-  gb.d = d + nh;
+  gb.d = d + 2 * nh;
   gb.device = b.device;
   gb.md.cap = b.md.cap;
   gb.md.dims_h = b.md.dims_h;
@@ -210,6 +230,13 @@ int ensure_gradbasis(obhip_basis &b) {
     P.ccol0 = g->hyps_h[h].gecol;  // level j -> column gecol + j - 1
     P.ncol = D.ncol + 1;
     gb.md.cap.push_back((int64_t)D.ncol);
+    gb.md.dims_h.push_back(P);
+  }
+  for (uint64_t h = 0; h < nh; ++h) {
+    const DimDesc &D = b.md.dims_h[m.hypmatch[h]];
+    DimDesc P = D;
+    P.ccol0 = g->hyps_h[h].dcol;  // level j -> column dcol + j - 1
+    gb.md.cap.push_back((int64_t)D.ncol - 1);
     gb.md.dims_h.push_back(P);
   }
   gb.md.Mc = gecol;
@@ -266,7 +293,11 @@ int ensure_gradbasis_sq(obhip_basis &b) {
   std::vector<uint32_t> pair(Mtot - Mc, 0u);
   for (size_t h = 0; h < g.hyps_h.size(); ++h) {
     const DimDesc &D = b.md.dims_h[g.hyps_h[h].dim];
-    for (int t = 1; t < D.ncol; ++t) pair[g.hyps_h[h].gecol - Mc + t] = (uint32_t)(D.ccol0 + t - 1);
+    for (int t = 1; t < D.ncol; ++t) {
+      pair[g.hyps_h[h].gecol - Mc + t] = (uint32_t)(D.ccol0 + t - 1);
+      // delta_sq[t] = ge_sq[t] - basemat[t]^2 ge_sq[0] = 2 basemat[t] delta[t]
+      pair[g.hyps_h[h].dcol - Mc + t - 1] = (uint32_t)(D.ccol0 + t - 1);
+    }
   }
   DevBuf<uint32_t> dpair;
   OB_TRY(dpair.upload(pair.data(), pair.size()));
@@ -293,167 +324,18 @@ int ensure_gradbasis_sq(obhip_basis &b) {
 
 namespace {
 
-// ---- all hyper-parameters of B a in ONE pass -------------------------------------------------
-// With P_k the term product (without basescale), E_kj the product without factor j and, per
-// row, delta[h, t] = ge[h, t] - basemat[col(dim h, t)] ge[h, 0] the identities above give
-//   out_gradhyp[i, h] = s_i ( ge[h, 0] . sum_k a_k P_k  +  sum_{k, j: dim(j) = dim(h)} a_k E_kj delta[h, t_kj] )
-// so a term touches only the hyper-parameters of its own non-zero dimensions.  Same tiling
-// as k_mm (lane = row, 64-row tile in LDS, term tables in registers broadcast by
-// v_readlane); the gradient columns are staged behind the basemat columns and the nhyp
-// per-row accumulators live in LDS (ds_add_f64, every lane its own address).
-// Table per term and slot: w0 = tile column of ge[h, t] | tile column of ge[h, 0] << 16,
-// w1 = h | second hyper-parameter of the dimension << 8 | columns per block << 16 | valid << 31.
-template <int W2>
-__global__ void __launch_bounds__(256)
-k_mmge(const double *__restrict__ bm, const double *__restrict__ scale,
-       const uint32_t *__restrict__ ucol, int Mu, uint64_t Mtot, int Mc, int Mge,
-       const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ getab, int p,
-       const double *__restrict__ a, const int *__restrict__ ge0col, int nhyp,
-       double *__restrict__ out, double *__restrict__ outge, uint64_t n) {
-  constexpr int W = 2 * W2;
-  extern __shared__ double lds[];
-  double *gl = lds + (size_t)Mu * kTileRows;     // gradient columns [Mge][64]
-  double *accL = gl + (size_t)Mge * kTileRows;   // [nhyp][64]
-  double *red = accL + (size_t)nhyp * kTileRows; // [4][64]
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint64_t tile = blockIdx.x;
-  const uint64_t row = tile * kTileRows + lane;
-  const double *tile_in = bm + tile * Mtot * kTileRows;
-  stage_tile<false, false>(lds, tile_in, ucol, Mu, threadIdx.x, 256);
-  for (int e = threadIdx.x; e < Mge * kTileRows; e += 256) gl[e] = tile_in[(size_t)Mc * kTileRows + e];
-  for (int e = threadIdx.x; e < nhyp * kTileRows; e += 256) accL[e] = 0.0;
-  __syncthreads();
-  const double s = row < n ? scale[row] : 0.0;
-  double acc = 0.0;
-  const int ngroups = (p + 63) / 64;
-  for (int g = wave; g < ngroups; g += 4) {
-    const int k0 = g * 64, cnt = min(64, p - k0);
-    uint32_t cw[W2], gw[2 * W];
-    load_cw(cw, colsw, k0 + lane);
-#pragma unroll
-    for (int q = 0; q < 2 * W; ++q) gw[q] = getab[(size_t)(k0 + lane) * 2 * W + q];
-    const double av = a[min(k0 + lane, p - 1)];
-    for (int t = 0; t < cnt; ++t) {
-      const double at = readlane_f64(av, t);
-      double bv[W];
-#pragma unroll
-      for (int w = 0; w < W2; ++w) {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cw[w], t);
-        bv[2 * w] = lds[(c & 0xffffu) * kTileRows + lane];
-        bv[2 * w + 1] = lds[(c >> 16) * kTileRows + lane];
-      }
-      // exclusive products: E[w] = prod_{q != w} bv[q]
-      double pre[W], E[W];
-      pre[0] = at;
-#pragma unroll
-      for (int w = 1; w < W; ++w) pre[w] = pre[w - 1] * bv[w - 1];
-      double suf = 1.0;
-#pragma unroll
-      for (int w = W - 1; w >= 0; --w) {
-        E[w] = pre[w] * suf;   // a_k included
-        suf *= bv[w];
-      }
-      acc = fma(pre[W - 1], bv[W - 1], acc);
-#pragma unroll
-      for (int w = 0; w < W; ++w) {
-        const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)gw[2 * w + 1], t);
-        if (w1 >> 31) {
-          const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)gw[2 * w], t);
-          const int ct = w0 & 0xffffu, c0 = w0 >> 16, h = w1 & 0xffu;
-          const double dl = fma(-bv[w], gl[c0 * kTileRows + lane], gl[ct * kTileRows + lane]);
-          unsafeAtomicAdd(&accL[h * kTileRows + lane], E[w] * dl);
-          if ((w1 >> 8) & 1u) {
-            const int nc = (w1 >> 16) & 0x7fffu;
-            const double d2 =
-                fma(-bv[w], gl[(c0 + nc) * kTileRows + lane], gl[(ct + nc) * kTileRows + lane]);
-            unsafeAtomicAdd(&accL[(h + 1) * kTileRows + lane], E[w] * d2);
-          }
-        }
-      }
-    }
-  }
-  red[wave * kTileRows + lane] = acc;
-  __syncthreads();
-  const double tot = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
-  if (row < n) {
-    if (wave == 0 && out) out[row] = tot * s;
-    for (int h = wave; h < nhyp; h += 4)
-      outge[(uint64_t)h * n + row] = s * fma(gl[ge0col[h] * kTileRows + lane], tot, accL[h * kTileRows + lane]);
-  }
-}
-
-// per term and slot the two table words of k_mmge (host)
-void build_getab(const obhip_terms &t, const obhip_basis &b, const obhip_gradbasis &g,
-                 std::vector<uint32_t> &tab) {
-  const obhip_model &m = *b.model;
-  const uint64_t W = t.W, d = t.d;
-  tab.assign(t.p_pad * W * 2, 0u);
-  const uint64_t Mc = b.md.Mc;
-  for (uint64_t k = 0; k < t.p; ++k) {
-    uint64_t w = 0;
-    for (uint64_t l = 0; l < d; ++l) {
-      const uint32_t lv = t.lev[k * d + l];
-      if (lv == 0) continue;
-      const uint64_t h = m.hypst[l], nh = m.hypst[l + 1] - m.hypst[l];
-      const uint32_t c0 = (uint32_t)(g.hyps_h[h].gecol - Mc);  // gradient-tile column of ge[h, 0]
-      const uint32_t nc = (uint32_t)b.md.dims_h[l].ncol;
-      tab[(k * W + w) * 2] = (c0 + lv) | (c0 << 16);
-      tab[(k * W + w) * 2 + 1] = (uint32_t)h | ((nh > 1 ? 1u : 0u) << 8) | (nc << 16) | (1u << 31);
-      ++w;
-    }
-  }
-}
-
-template <int W2>
-int run_mmge(const obhip_basis &gb, const obhip_basis &b, obhip_terms &t, const uint32_t *getab,
-             const int *ge0col, int nhyp, const double *d_a, double *d_out, double *d_outge) {
-  const int Mge = (int)(gb.md.Mc - b.md.Mc);
-  const size_t lds = ((size_t)t.Mu + Mge + nhyp + 4) * kTileRows * sizeof(double);
-  OB_HIP(hipFuncSetAttribute((const void *)k_mmge<W2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)lds));
-  hipLaunchKernelGGL(k_mmge<W2>, dim3((unsigned)(b.n_pad / kTileRows)), dim3(256), lds, cur_stream(),
-                     gb.bm.p, gb.scale.p, t.ucol.p, (int)t.Mu, gb.md.Mc, (int)b.md.Mc, Mge,
-                     (const uint32_t *)t.cols.p, getab, (int)t.p, d_a, ge0col, nhyp, d_out, d_outge,
-                     b.n);
-  OB_HIP(hipGetLastError());
-  return 0;
+// out_gradhyp[h][i] += ge[h, 0]_i * M_i  (M = B a or B^2 a, already scaled by basescale)
+__global__ void k_ge0_combine(const double *__restrict__ bm, uint64_t Mtot,
+                              const int *__restrict__ ge0col, const double *__restrict__ M,
+                              uint64_t n, double *__restrict__ outge) {
+  const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const int h = blockIdx.y;
+  const double g0 = bm[((row >> 6) * Mtot + (uint64_t)ge0col[h]) * kTileRows + (row & 63)];
+  outge[(uint64_t)h * n + row] = fma(g0, M[row], outge[(uint64_t)h * n + row]);
 }
 
 }  // namespace
-
-// out_gradhyp for every hyper-parameter in one pass; false if the tile does not fit the LDS
-// (the caller then falls back to one k_mm pass per hyper-parameter through the views)
-bool mmge_fits(const obhip_basis &b, obhip_terms &t) {
-  if (!b.grad) return false;
-  if (t.prepare(b.md.cap, b.md.dims_h) != 0) return false;  // Mu must be this basis' value
-  const uint64_t Mge = b.grad->gb->md.Mc - b.md.Mc;
-  return t.W <= 8 && (t.Mu + Mge + b.model->nhyp() + 4) * kTileRows * sizeof(double) <= 152 * 1024;
-}
-
-int launch_mmge(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a, double *d_out,
-                double *d_outge) {
-  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
-  obhip_gradbasis &g = *b.grad;
-  const int nhyp = (int)b.model->nhyp();
-  if (t.getab_version != g.id || !t.getab.p) {
-    std::vector<uint32_t> tab;
-    build_getab(t, b, g, tab);
-    OB_TRY(t.getab.upload(tab.data(), tab.size()));
-    std::vector<int> c0(nhyp);
-    for (int h = 0; h < nhyp; ++h) c0[h] = g.hyps_h[h].gecol - (int)b.md.Mc;
-    OB_TRY(t.ge0col.upload(c0.data(), c0.size()));
-    t.getab_version = g.id;
-  }
-  const obhip_basis &src = squared ? *g.gbsq : *g.gb;
-  ProfScope ps(squared ? "sqmm_gradhyp" : "mm_gradhyp");
-  switch (t.W / 2) {
-    case 1: return run_mmge<1>(src, b, t, t.getab.p, t.ge0col.p, nhyp, d_a, d_out, d_outge);
-    case 2: return run_mmge<2>(src, b, t, t.getab.p, t.ge0col.p, nhyp, d_a, d_out, d_outge);
-    case 3: return run_mmge<3>(src, b, t, t.getab.p, t.ge0col.p, nhyp, d_a, d_out, d_outge);
-    default: return run_mmge<4>(src, b, t, t.getab.p, t.ge0col.p, nhyp, d_a, d_out, d_outge);
-  }
-}
 
 namespace {
 
@@ -569,27 +451,32 @@ int launch_bt_times_ge0(obhip_basis &b, obhip_terms &t, bool squared, const doub
   return 0;
 }
 
-// View restricted to the terms whose level in hyper-parameter h's dimension is non-zero;
-// idx receives their term indices.  nullptr when there is none.
-obhip_terms *grad_view_sparse(obhip_terms &t, const obhip_basis &b, uint64_t h,
-                              const std::vector<uint32_t> **idx) {
+// Views restricted to the terms whose level in hyper-parameter h's dimension is non-zero,
+// that dimension dropped and replaced by a pseudo-dimension: the gradient block at level
+// t + 1 (ge_sviews) or the delta block at level t (ge_dviews).  idx receives the term
+// indices.  nullptr when no term has the dimension.
+static void build_sparse_views(obhip_terms &t, const obhip_basis &b) {
   const obhip_model &m = *b.model;
-  const uint64_t nh = m.nhyp(), d = t.d, de = d + nh;
-  if (t.ge_sviews.size() != nh) {
-    t.ge_sviews.clear();
-    t.ge_sviews.resize(nh);
-    t.ge_sidx.assign(nh, {});
-    for (uint64_t hh = 0; hh < nh; ++hh) {
-      const uint64_t l = m.hypmatch[hh];
-      std::vector<uint32_t> &ix = t.ge_sidx[hh];
-      for (uint64_t k = 0; k < t.p; ++k)
-        if (t.lev[k * d + l] > 0) ix.push_back((uint32_t)k);
-      if (ix.empty()) continue;
+  const uint64_t nh = m.nhyp(), d = t.d, de = d + 2 * nh;
+  if (t.ge_sviews.size() == nh && t.ge_dviews.size() == nh) return;
+  t.ge_sviews.clear();
+  t.ge_sviews.resize(nh);
+  t.ge_dviews.clear();
+  t.ge_dviews.resize(nh);
+  t.ge_sidx.assign(nh, {});
+  for (uint64_t hh = 0; hh < nh; ++hh) {
+    const uint64_t l = m.hypmatch[hh];
+    std::vector<uint32_t> &ix = t.ge_sidx[hh];
+    for (uint64_t k = 0; k < t.p; ++k)
+      if (t.lev[k * d + l] > 0) ix.push_back((uint32_t)k);
+    if (ix.empty()) continue;
+    for (int delta = 0; delta < 2; ++delta) {
       auto v = std::make_unique<obhip_terms>();
       v->p = ix.size();
       v->d = de;
       v->lev.assign(v->p * de, 0);
       v->maxlev.assign(de, 0);
+      const uint64_t pd = d + (delta ? nh : 0) + hh;
       for (uint64_t j = 0; j < v->p; ++j) {
         const uint64_t k = ix[j];
         uint64_t nnz = 1;
@@ -599,24 +486,36 @@ obhip_terms *grad_view_sparse(obhip_terms &t, const obhip_basis &b, uint64_t h,
           v->maxlev[q] = std::max<int64_t>(v->maxlev[q], lv);
           nnz += lv > 0;
         }
-        const uint32_t gl = t.lev[k * d + l] + 1;
-        v->lev[j * de + d + hh] = gl;
-        v->maxlev[d + hh] = std::max<int64_t>(v->maxlev[d + hh], gl);
+        const uint32_t gl = t.lev[k * d + l] + (delta ? 0 : 1);
+        v->lev[j * de + pd] = gl;
+        v->maxlev[pd] = std::max<int64_t>(v->maxlev[pd], gl);
         v->nnz_total += nnz;
         v->max_nnz = std::max(v->max_nnz, nnz);
       }
-      t.ge_sviews[hh] = std::move(v);
+      (delta ? t.ge_dviews : t.ge_sviews)[hh] = std::move(v);
     }
   }
+}
+
+obhip_terms *grad_view_sparse(obhip_terms &t, const obhip_basis &b, uint64_t h,
+                              const std::vector<uint32_t> **idx) {
+  build_sparse_views(t, b);
   *idx = &t.ge_sidx[h];
   return t.ge_sviews[h].get();
+}
+
+obhip_terms *grad_view_delta(obhip_terms &t, const obhip_basis &b, uint64_t h,
+                             const std::vector<uint32_t> **idx) {
+  build_sparse_views(t, b);
+  *idx = &t.ge_sidx[h];
+  return t.ge_dviews[h].get();
 }
 
 // View of the terms for hyper-parameter h: dimension hypmatch[h] dropped, pseudo-dimension
 // d + h at level t + 1 (so even level 0 picks up its gradient column).
 obhip_terms *grad_view(obhip_terms &t, const obhip_basis &b, uint64_t h) {
   const obhip_model &m = *b.model;
-  const uint64_t nh = m.nhyp(), d = t.d, de = d + nh;
+  const uint64_t nh = m.nhyp(), d = t.d, de = d + 2 * nh;
   if (t.ge_views.size() != nh) {
     t.ge_views.clear();
     t.ge_views.resize(nh);
@@ -669,6 +568,80 @@ int check_grad_args(const obhip_basis *b, const obhip_terms *t) {
   return 0;
 }
 
+// out_gradhyp (host, n x nhyp) = d(B a)/dhyp_h (squared: d(B^2 a)/dhyp_h); d_M receives
+// B a (B^2 a).  One k_mm pass over all terms for M, per hyper-parameter one k_mm pass over
+// the terms that have its dimension (delta view), then out[:, h] = ge[h, 0] M + that.
+int mm_gradhyp_dev(obhip_basis &b, obhip_terms &t, bool squared, const double *a, const double *d_a,
+                   double *d_M, DevBuf<double> &dge) {
+  obhip_gradbasis &g = *b.grad;
+  const obhip_basis &src = squared ? *g.gbsq : *g.gb;
+  const uint64_t nh = b.model->nhyp(), n = b.n;
+  DevBuf<double> dacat;
+  DevBuf<int> dc0;
+  OB_TRY(dge.alloc(n * nh));
+  OB_HIP(hipMemsetAsync(dge.p, 0, n * nh * sizeof(double), cur_stream()));
+  // coefficients of the restricted views, concatenated
+  std::vector<double> acat;
+  std::vector<uint64_t> off(nh + 1, 0);
+  for (uint64_t h = 0; h < nh; ++h) {
+    const std::vector<uint32_t> *idx = nullptr;
+    grad_view_delta(t, b, h, &idx);
+    for (uint32_t k : *idx) acat.push_back(a[k]);
+    off[h + 1] = acat.size();
+  }
+  std::vector<int> c0(nh);
+  for (uint64_t h = 0; h < nh; ++h) c0[h] = g.hyps_h[h].gecol;
+  OB_TRY(dc0.upload(c0.data(), c0.size()));
+  if (!acat.empty()) OB_TRY(dacat.upload(acat.data(), acat.size()));
+  OB_TRY(launch_mm(b, t, d_a, d_M, squared));
+  {
+    ProfScope ps(squared ? "sqmm_gradhyp" : "mm_gradhyp");
+    for (uint64_t h = 0; h < nh; ++h) {
+      const std::vector<uint32_t> *idx = nullptr;
+      obhip_terms *v = grad_view_delta(t, b, h, &idx);
+      if (!v) continue;
+      OB_TRY(launch_mm(src, *v, dacat.p + off[h], dge.p + h * n, false));
+    }
+    hipLaunchKernelGGL(k_ge0_combine, dim3((unsigned)((n + 255) / 256), (unsigned)nh), dim3(256), 0,
+                       cur_stream(), src.bm.p, src.md.Mc, dc0.p, d_M, n, dge.p);
+    OB_HIP(hipGetLastError());
+  }
+  OB_HIP(hipStreamSynchronize(cur_stream()));  // dc0, dacat are locals
+  return 0;
+}
+
+int mm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const double *a, const double *d_a,
+                   double *d_M, double *out_gradhyp) {
+  DevBuf<double> dge;
+  OB_TRY(mm_gradhyp_dev(b, t, squared, a, d_a, d_M, dge));
+  return d2h(out_gradhyp, dge.p, b.n * b.model->nhyp() * sizeof(double));
+}
+
+// part[h][blk] = partial sums of w_i G[h][i] over the rows blk, blk + gridDim.x, ...
+__global__ void __launch_bounds__(256)
+k_wdot1(const double *__restrict__ G, const double *__restrict__ w, uint64_t n,
+        double *__restrict__ part) {
+  __shared__ double red[256];
+  const double *g = G + (uint64_t)blockIdx.y * n;
+  double s = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    s = fma(w[i], g[i], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+__global__ void k_wdot2(const double *__restrict__ part, int nblk, double *__restrict__ out) {
+  const int h = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += part[(uint64_t)h * nblk + i];
+  out[h] = s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -698,22 +671,35 @@ int obhip_basis_mm_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const d
   DevBuf<double> da, dout;
   OB_TRY(da.upload(a, t.p));
   OB_TRY(dout.alloc(b.n));
-  if (mmge_fits(b, t)) {
-    DevBuf<double> dge;
-    OB_TRY(dge.alloc(b.n * b.model->nhyp()));
-    OB_TRY(launch_mmge(b, t, false, da.p, dout.p, dge.p));
-    if (out) OB_TRY(d2h(out, dout.p, b.n * sizeof(double)));
-    return d2h(out_gradhyp, dge.p, b.n * b.model->nhyp() * sizeof(double));
-  }
-  if (out) {
-    OB_TRY(launch_mm(b, t, da.p, dout.p, false));
-    OB_TRY(d2h(out, dout.p, b.n * sizeof(double)));
-  }
-  for (uint64_t h = 0; h < b.model->nhyp(); ++h) {
-    OB_TRY(launch_mm(*b.grad->gb, *grad_view(t, b, h), da.p, dout.p, false));
-    OB_TRY(d2h(out_gradhyp + h * b.n, dout.p, b.n * sizeof(double)));
-  }
+  OB_TRY(mm_gradhyp_all(b, t, false, a, da.p, dout.p, out_gradhyp));
+  if (out) OB_TRY(d2h(out, dout.p, b.n * sizeof(double)));
   return 0;
+}
+
+// w^T d(B a)/dhyp without moving the n x nhyp matrix to the host: what the likelihoods need
+// of matmul_gradhyp (loglik_gauss.cpp:127, loglik_std.cpp:143: gradhyp = r^T yhat_gradhyp)
+int obhip_basis_mm_gradhyp_dot(const obhip_basis *bc, const obhip_terms *tc, const double *a,
+                               const double *w, double *out, double *out_dot) {
+  OB_TRY(check_grad_args(bc, tc));
+  if (!a || !w || !out_dot) return fail(OBHIP_ERR_INVALID, "mm_gradhyp_dot: null argument");
+  obhip_basis &b = *const_cast<obhip_basis *>(bc);
+  obhip_terms &t = *const_cast<obhip_terms *>(tc);
+  OB_TRY(ensure_gradbasis(b));
+  const uint64_t nh = b.model->nhyp();
+  constexpr int nblk = 256;
+  DevBuf<double> da, dw, dout, dge, dpart, dres;
+  OB_TRY(da.upload(a, t.p));
+  OB_TRY(dw.upload(w, b.n));
+  OB_TRY(dout.alloc(b.n));
+  OB_TRY(dpart.alloc(nh * nblk));
+  OB_TRY(dres.alloc(nh));
+  OB_TRY(mm_gradhyp_dev(b, t, false, a, da.p, dout.p, dge));
+  hipLaunchKernelGGL(k_wdot1, dim3(nblk, (unsigned)nh), dim3(256), 0, cur_stream(), dge.p, dw.p, b.n,
+                     dpart.p);
+  hipLaunchKernelGGL(k_wdot2, dim3((unsigned)nh), dim3(64), 0, cur_stream(), dpart.p, nblk, dres.p);
+  OB_HIP(hipGetLastError());
+  if (out) OB_TRY(d2h(out, dout.p, b.n * sizeof(double)));
+  return d2h(out_dot, dres.p, nh * sizeof(double));
 }
 
 static int tmm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a,
@@ -732,18 +718,8 @@ static int sq_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const double
   DevBuf<double> da, dout;
   OB_TRY(da.upload(a, nin));
   OB_TRY(dout.alloc(nout));
-  if (!transposed && mmge_fits(b, t)) {
-    DevBuf<double> dge;
-    OB_TRY(dge.alloc(b.n * b.model->nhyp()));
-    OB_TRY(launch_mmge(b, t, true, da.p, nullptr, dge.p));
-    return d2h(out_gradhyp, dge.p, b.n * b.model->nhyp() * sizeof(double));
-  }
   if (transposed) return tmm_gradhyp_all(b, t, true, da.p, out_gradhyp);
-  for (uint64_t h = 0; h < b.model->nhyp(); ++h) {
-    OB_TRY(launch_mm(*b.grad->gbsq, *grad_view(t, b, h), da.p, dout.p, false));
-    OB_TRY(d2h(out_gradhyp + h * nout, dout.p, nout * sizeof(double)));
-  }
-  return 0;
+  return mm_gradhyp_all(b, t, true, a, da.p, dout.p, out_gradhyp);
 }
 
 int obhip_basis_sqmm_gradhyp(const obhip_basis *b, const obhip_terms *t, const double *a,

@@ -39,6 +39,18 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// ---- device memory pool -----------------------------------------------------------
+// Every C-ABI call allocates its device temporaries (vectors of n or p doubles, an n x nhyp
+// block, ...) and frees them on return; hipMalloc / hipFree cost far more than the kernels of
+// a small call and hipFree synchronises the device.  Freed blocks are therefore kept, keyed
+// by exact size, device and the stream they were last used on -- a block is handed out again
+// only to work queued on that same stream, so stream order protects it -- up to
+// OBHIP_POOL_MB (default 8192) of cached memory; larger blocks and the overflow go back to
+// the driver, and a failed hipMalloc empties the pool and retries.
+int pool_alloc(void **p, size_t bytes);
+void pool_free(void *p, size_t bytes);
+void pool_trim();
+
 // ---- device buffer ----------------------------------------------------------
 template <typename T>
 struct DevBuf {
@@ -49,7 +61,7 @@ struct DevBuf {
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) pool_free(p, n * sizeof(T));
     p = nullptr;
     n = 0;
   }
@@ -57,8 +69,8 @@ struct DevBuf {
     if (count == n && p) return 0;
     release();
     if (count == 0) return 0;
-    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    int rc = pool_alloc((void **)&p, count * sizeof(T));
+    if (rc) return rc;
     n = count;
     return 0;
   }
@@ -171,9 +183,8 @@ struct obhip_terms {
   // their indices (transposed gradient products: the other terms come from one dense pass)
   std::vector<std::unique_ptr<obhip_terms>> ge_sviews;
   std::vector<std::vector<uint32_t>> ge_sidx;
-  obhip::DevBuf<uint32_t> getab;      // slot table of the one-pass gradient kernel k_mmge
-  obhip::DevBuf<int> ge0col;          // gradient-tile column of ge[h, 0] per hyper-parameter
-  uint64_t getab_version = ~0ull;
+  // restricted likewise, the dimension's factor replaced by the delta column (products B a)
+  std::vector<std::unique_ptr<obhip_terms>> ge_dviews;
   // device view of the model capped at maxlev, for the fused predictor
   obhip::ModelDev pred_md;
   const obhip_model *pred_model = nullptr;
@@ -187,6 +198,7 @@ struct GradHyp {
   int which;    // its index within the dimension (0 or 1)
   int rotgoff;  // offset into rotg (doubles), block [m][ncolp] like ModelDev::rot
   int gecol;    // first gradient column of this hyper-parameter in the combined tile
+  int dcol;     // first delta column: delta[t] = ge[t] - basemat[level t] ge[0], t >= 1
 };
 }  // namespace obhip
 

@@ -365,6 +365,17 @@ class outerbase:
         call("obhip_basis_mm_gradhyp", self._h, t._h, ptr(a), None, ptr(out))
         return out
 
+    def matmul_gradhyp_dot(self, terms, a, w):
+        """w^T matmul_gradhyp(terms, a) (nhyp values) with the n x nhyp matrix left on the
+        device -- the contraction the likelihoods make of it (loglik_gauss.cpp:127)."""
+        t = _terms_of(self.om, terms)
+        a, w = _f64(a), _f64(w)
+        if a.shape[0] != t.p or w.shape[0] != self.n_row:
+            raise ValueError("non-conformable arguments")
+        out = np.empty(len(self.om.grad_layout()[0]))
+        call("obhip_basis_mm_gradhyp_dot", self._h, t._h, ptr(a), ptr(w), None, ptr(out))
+        return out
+
     def tmatmul_gradhyp(self, terms, a):
         """p x nhyp (tmm_gradhyp_out, modandbase.cpp:771-776)."""
         t = _terms_of(self.om, terms)
@@ -606,7 +617,7 @@ class _loglik(lpdf):
         r2 = -math.exp(-s) * resid
         self.grad = self.ob.tmatmul(self._t, r2)
         if self.compute_gradhyp:      # loglik_gauss.cpp:114-117,127
-            self.gradhyp = r2 @ self.ob.matmul_gradhyp(self._t, self.coeff)
+            self.gradhyp = self.ob.matmul_gradhyp_dot(self._t, self.coeff, r2)
         if self.compute_gradpara:     # :128
             self.gradpara = np.array([np.sum(resid ** 2) - len(self.y)])
 
@@ -692,7 +703,7 @@ class loglik_gda(_loglik):
         r2 = r2 / self.obssd
         self.grad = self.ob.tmatmul(self._t, r)
         if self.compute_gradhyp:
-            self.gradhyp = r @ self.ob.matmul_gradhyp(self._t, self.coeff)
+            self.gradhyp = self.ob.matmul_gradhyp_dot(self._t, self.coeff, r)
             if self.dodiag:
                 self.gradhyp = self.gradhyp + r2 @ self.obssd_gradhyp \
                     - (1.0 / self.obssd) @ self.obssd_gradhyp

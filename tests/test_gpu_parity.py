@@ -828,6 +828,8 @@ def test_random_shapes_against_oracle(seed):
     assert relerr(bd.sqcolsums(terms), O.ob_sqcolsums(bo, terms)) < tol
     assert relerr(bd.matmul_gradhyp(terms, a), O.ob_mm_gradhyp(bo, terms, a)[1]) < 100 * tol
     assert relerr(bd.tmatmul_gradhyp(terms, v), O.ob_tmm_gradhyp(bo, terms, v)[1]) < 100 * tol
+    # the contraction the likelihoods make of it, reduced on the device
+    assert relerr(bd.matmul_gradhyp_dot(terms, a, v), v @ O.ob_mm_gradhyp(bo, terms, a)[1]) < 100 * tol
     aa = np.abs(a)
     assert relerr(bd.sqmm(terms, aa), O.ob_sqmm(bo, terms, aa)) < tol
     assert relerr(bd.sqtmm(terms, v), O.ob_sqtmm(bo, terms, v)) < tol
