@@ -1063,3 +1063,33 @@ def test_obfit_on_random_smooth_functions(seed):
     assert np.all(pred["var"] > 0)
     rmse = math.sqrt(np.mean((pred["mean"] - y[n:]) ** 2))
     assert rmse < 0.5 * np.std(y[n:])
+
+
+def test_device_memory_pool_recycles_and_trims():
+    """The temporaries of the C-ABI calls come from a size-keyed pool (csrc/core.cpp): results
+    must not depend on whether a block is fresh or recycled, and obhip_trim_pool hands the
+    cached memory back to the driver."""
+    import torch
+    import ob_oracle as O
+    import outerbase_amd as ob
+    from outerbase_amd import _lib
+    rng = np.random.default_rng(77)
+    kinds = ["mat25", "mat25pow", "mat25ang"]
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 12))
+    terms = om_o.selectterms(40)
+    n = 300000                     # 2.4 MB vectors: blocks large enough to see in hipMemGetInfo
+    x = sample_x(rng, n, kinds)
+    bd = ob.outerbase(om_d, x)
+    a, v = rng.standard_normal(40), rng.standard_normal(n)
+    first = (bd.matmul(terms, a), bd.tmatmul(terms, v), bd.matmul_gradhyp(terms, a))
+    _lib.call("obhip_trim_pool")
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):             # same sizes again: recycled blocks, fill patterns of older calls
+        again = (bd.matmul(terms, a), bd.tmatmul(terms, v), bd.matmul_gradhyp(terms, a))
+        for f, g in zip(first, again):
+            assert np.array_equal(f, g)
+    cached = free0 - torch.cuda.mem_get_info()[0]
+    assert cached > 0              # the temporaries stayed with the pool ...
+    _lib.call("obhip_trim_pool")
+    assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)   # ... and went back on request
+    assert relerr(first[0][:2000], O.ob_mm(O.OuterBase(om_o, x[:2000]), terms, a)) < 1e-9
