@@ -321,6 +321,8 @@ int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   if (t.Mu > 280) return fail(OBHIP_ERR_INVALID, "terms touch too many basis columns for the LDS tile");
   ProfScope ps("materialize_B");
+  static const bool lane_row = getenv("OBHIP_MATERIALIZE_LANE_ROW") != nullptr;
+  if (!lane_row && materialize_tl_supports(t)) return launch_materialize_tl(b, t, d_B);
   switch (t.W / 2) {
     case 1: return run_materialize<1>(b, t, d_B);
     case 2: return run_materialize<2>(b, t, d_B);

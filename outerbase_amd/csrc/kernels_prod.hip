@@ -446,6 +446,161 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
     }
 }
 
+// ---- row-major design matrix, term-per-lane ------------------------------------------------------
+// B[row][k] for the materialised-B Gram kernel (kernels_gram_panel.hip).  lane = two adjacent
+// terms, so a wave instruction stores 64 x 16 B = 1 KB of one row of B and no transpose is
+// needed; products exactly as in k_tmm_tl, the row's basescale is the last factor.
+template <int W, int NPAIR>
+struct MtCtx {
+  static constexpr int D = (12 / W) > 0 ? 12 / W : 1;  // units in flight
+  static constexpr int NU = NPAIR * 2;                 // units (terms of this lane) per row
+  static constexpr int TOT = kTlChunk * NU;
+  uint32_t ad[NPAIR][2][W];
+  uint32_t koff[NPAIR];  // first of the lane's two terms in pair-group q
+  double buf[D][W];
+  double sc;             // basescale of row = lane
+  double sr;             // basescale of the current row, wave-uniform
+  double v0;
+  double *rowp;          // B + current row * p_pad (uniform)
+  uint64_t p_pad;
+  int rc;
+};
+
+template <int U, int W, int NPAIR>
+__device__ __forceinline__ void mt_issue(MtCtx<W, NPAIR> &c) {
+  using C = MtCtx<W, NPAIR>;
+  constexpr int rr = U / C::NU, unit = U % C::NU, q = unit / 2, i = unit % 2;
+#pragma unroll
+  for (int j = 0; j < W; ++j) c.buf[U % C::D][j] = tl_rd<rr * 8>(c.ad[q][i][j]);
+}
+
+template <int U, int W, int NPAIR>
+__device__ __forceinline__ void mt_steps(MtCtx<W, NPAIR> &c) {
+  using C = MtCtx<W, NPAIR>;
+  if constexpr (U < C::TOT) {
+    constexpr int rr = U / C::NU, unit = U % C::NU, q = unit / 2, i = unit % 2;
+    if constexpr (U + C::D - 1 < C::TOT) mt_issue<U + C::D - 1>(c);
+    if constexpr (unit == 0) {
+      c.sr = readlane_f64(c.sc, c.rc + rr);
+      if constexpr (rr > 0) c.rowp += c.p_pad;
+    }
+    constexpr int newer = (C::TOT - 1 - U) < (C::D - 1) ? (C::TOT - 1 - U) : (C::D - 1);
+    tl_wait<newer * W>(c.buf[U % C::D]);
+    double v = c.buf[U % C::D][0];
+#pragma unroll
+    for (int j = 1; j < W; ++j) v *= c.buf[U % C::D][j];
+    v *= c.sr;
+    if constexpr (i == 0) {
+      c.v0 = v;
+    } else {
+      double2 o;
+      o.x = c.v0;
+      o.y = v;
+      *(double2 *)(c.rowp + c.koff[q]) = o;
+    }
+    mt_steps<U + 1>(c);
+  }
+}
+
+template <int U, int W, int NPAIR>
+__device__ __forceinline__ void mt_prologue(MtCtx<W, NPAIR> &c) {
+  if constexpr (U < MtCtx<W, NPAIR>::D - 1) {
+    mt_issue<U>(c);
+    mt_prologue<U + 1>(c);
+  }
+}
+
+template <int W2, int NPAIR, bool PREFETCH>
+__global__ void __launch_bounds__(kTlThreads, 4)
+k_materialize_tl(const double *__restrict__ bm, const double *__restrict__ scale,
+                 const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc,
+                 const uint32_t *__restrict__ colsw, uint64_t ntiles, uint64_t tiles_per_split,
+                 uint64_t p_pad, double *__restrict__ out) {
+  extern __shared__ double lds[];
+  constexpr int W = 2 * W2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+
+  // pair-group ((blockIdx.y * NPAIR + q) * 8 + wave) covers 128 terms, lane takes two
+  MtCtx<W, NPAIR> c;
+  c.p_pad = p_pad;
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q) {
+    const uint64_t k = (((uint64_t)blockIdx.y * NPAIR + q) * kTlWaves + wave) * 128 + 2 * lane;
+    c.koff[q] = (uint32_t)min(k, p_pad - 2);
+    any = any || k < p_pad;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int w = 0; w < W2; ++w) {
+        const uint32_t cw = k < p_pad ? colsw[(k + i) * W2 + w] : 0u;
+        c.ad[q][i][2 * w] = (cw & 0xffffu) * (kTlPitch * 8);
+        c.ad[q][i][2 * w + 1] = (cw >> 16) * (kTlPitch * 8);
+      }
+  }
+  // pair-groups beyond p_pad exist only in the last block along p and only for whole waves
+  const bool live = __builtin_amdgcn_readfirstlane((int)any) != 0;
+
+  int lu[PREFETCH ? kTlPre : 1];
+  double pre[PREFETCH ? kTlPre : 1];
+  if (PREFETCH) {
+#pragma unroll
+    for (int q = 0; q < kTlPre; ++q) {
+      const int u = wave + kTlWaves * q;
+      lu[q] = u < Mu ? __builtin_amdgcn_readfirstlane((int)ucol[u] * kTileRows) : 0;
+    }
+  }
+  double scn = 0.0;
+  auto fetch = [&](uint64_t tile) {
+    const double *src = bm + tile * Mc * kTileRows + lane;
+#pragma unroll
+    for (int q = 0; q < kTlPre; ++q) {
+      const int u = wave + kTlWaves * q;
+      pre[q] = u < Mu ? src[lu[q]] : 0.0;
+    }
+    scn = scale[tile * kTileRows + lane];  // 0 in padding rows
+  };
+  if (PREFETCH && t0 < t1) fetch(t0);
+
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    __syncthreads();
+    if (PREFETCH) {
+#pragma unroll
+      for (int q = 0; q < kTlPre; ++q) {
+        const int u = wave + kTlWaves * q;
+        if (u < Mu) lds[u * kTlPitch + lane] = pre[q];
+      }
+      c.sc = scn;
+    } else {
+      const double *src = bm + tile * Mc * kTileRows + lane;
+      for (int u = wave; u < Mu; u += kTlWaves) lds[u * kTlPitch + lane] = src[(size_t)ucol[u] * kTileRows];
+      c.sc = scale[tile * kTileRows + lane];
+    }
+    __syncthreads();
+    if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
+    if (!live) continue;
+#pragma unroll 1
+    for (int rc = 0; rc < kTileRows; rc += kTlChunk) {
+      c.rc = rc;
+      c.rowp = out + (tile * kTileRows + rc) * p_pad;
+      mt_prologue<0>(c);
+      mt_steps<0>(c);
+#pragma unroll
+      for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            c.ad[q][i][j] += (rc + kTlChunk < kTileRows) ? kTlChunk * 8 : -(kTileRows - kTlChunk) * 8;
+            asm volatile("" : "+v"(c.ad[q][i][j]));
+          }
+    }
+  }
+}
+
 // ---- mm, term-per-lane ----------------------------------------------------------------------
 // out = B a with the same lane = term layout: a wave holds NG terms per lane (addresses and
 // coefficient in registers for the whole launch), accumulates a_k * prod over its terms for
@@ -885,6 +1040,51 @@ int dispatch_tmm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, dou
 int tmm_tl_supports(const obhip_terms &t) {
   const int w2 = (int)(t.W / 2);
   return w2 >= 1 && w2 <= kMaxW2 && t.Mu * kTlPitch * sizeof(double) <= 156 * 1024;
+}
+
+template <int W2, int NPAIR>
+int run_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B, dim3 grid, uint64_t ntiles,
+                       uint64_t tps) {
+  const size_t lds = t.Mu * kTlPitch * sizeof(double);
+  const bool pf = t.Mu <= (uint64_t)kTlWaves * kTlPre;
+  if (pf) {
+    OB_TRY(set_lds(k_materialize_tl<W2, NPAIR, true>, lds));
+    hipLaunchKernelGGL((k_materialize_tl<W2, NPAIR, true>), grid, dim3(kTlThreads), lds, cur_stream(),
+                       b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,
+                       ntiles, tps, t.p_pad, d_B);
+  } else {
+    OB_TRY(set_lds(k_materialize_tl<W2, NPAIR, false>, lds));
+    hipLaunchKernelGGL((k_materialize_tl<W2, NPAIR, false>), grid, dim3(kTlThreads), lds, cur_stream(),
+                       b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,
+                       ntiles, tps, t.p_pad, d_B);
+  }
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+bool materialize_tl_supports(const obhip_terms &t) { return tmm_tl_supports(t) != 0; }
+
+// d_B: n_pad x p_pad doubles, row-major; t prepared by the caller
+int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B) {
+  const int npmax = t.W / 2 <= 2 ? 4 : 2;
+  int npair = 1;
+  while (npair < npmax && (uint64_t)kTlWaves * npair * 128 < t.p_pad) npair *= 2;
+  const uint64_t tpb = (uint64_t)kTlWaves * npair * 128;
+  const uint64_t pblocks = (t.p_pad + tpb - 1) / tpb;
+  const uint64_t ntiles = b.n_pad / kTileRows;
+  uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)device_cus(b.device) * 4 / pblocks);
+  nsplit = std::min(nsplit, ntiles);
+  const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  const dim3 grid((unsigned)nsplit, (unsigned)pblocks);
+#define OB_MT(W2_, NP_) return run_materialize_tl<W2_, NP_>(b, t, d_B, grid, ntiles, tps)
+  switch (t.W / 2) {
+    case 1: if (npair == 4) OB_MT(1, 4); if (npair == 2) OB_MT(1, 2); OB_MT(1, 1);
+    case 2: if (npair == 4) OB_MT(2, 4); if (npair == 2) OB_MT(2, 2); OB_MT(2, 1);
+    case 3: if (npair == 2) OB_MT(3, 2); OB_MT(3, 1);
+    default: if (npair == 2) OB_MT(4, 2); OB_MT(4, 1);
+  }
+#undef OB_MT
 }
 
 int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, bool squared) {

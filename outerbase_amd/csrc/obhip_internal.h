@@ -274,6 +274,8 @@ int ensure_gradbasis_sq(obhip_basis &b);
 obhip_terms *grad_view(obhip_terms &t, const obhip_basis &b, uint64_t h);
 // kernels_chol.hip
 uint64_t newton_workspace_bytes(uint64_t p);
+bool materialize_tl_supports(const obhip_terms &t);
+int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B);
 int launch_newton_solve(uint64_t p, double *d_H, const double *d_rhs,
                         double *d_theta, void *d_ws, uint64_t ws_bytes);
 int launch_form_hessian(uint64_t p, double *d_G, const double *d_prec,
