@@ -257,8 +257,14 @@ int obhip_terms::prepare(const std::vector<int64_t> &cap,
   W = std::max<uint64_t>(2, (max_nnz + 1) / 2 * 2);
   p_pad = (p + 255) / 256 * 256;
   std::vector<uint16_t> hc(p_pad * W, 0);
+  // Right-aligned: the ones sit in the leading slots, the factors keep their dimension order
+  // (so every product rounds as before).  In the term-per-lane kernels the 32 lanes of a
+  // bank group read slot j of 32 consecutive terms; right-aligned, those are far more often
+  // the same column (a broadcast) -- 1.05 instead of 1.17 LDS cycles per read at C3.
   for (uint64_t k = 0; k < p; ++k) {
-    uint64_t w = 0;
+    uint64_t nnz = 0;
+    for (uint64_t l = 0; l < d; ++l) nnz += lev[k * d + l] > 0;
+    uint64_t w = W - nnz;
     for (uint64_t l = 0; l < d; ++l) {
       const uint32_t t = lev[k * d + l];
       if (t > 0) hc[k * W + w++] = pos[(uint32_t)(dims[l].ccol0 + t - 1)];
