@@ -96,6 +96,249 @@ k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
   }
 }
 
+// ---- term-per-lane predictor -------------------------------------------------------------------
+// Default.  Persistent blocks of 8 waves; per 64-row tile the waves first evaluate the
+// dimensions (lane = row) into the [column][65] LDS tile, then switch to lane = term for the
+// contraction exactly as k_mm_tl does: theta_k (and coeffvar_k) and the column addresses of
+// NG terms per lane stay in registers, 8 rows of accumulators per chunk, permlane-swap
+// butterfly + DPP for the sum over the lanes.  More than 8 * NG * 64 terms: several passes
+// over the same LDS tile with the tables reloaded.
+template <int W, int NG, bool VAR>
+struct PrCtx {
+  static constexpr int D = (12 / W) > 0 ? 12 / W : 1;
+  static constexpr int TOT = 8 * NG;  // units per 8-row chunk
+  uint32_t ad[NG][W];
+  double th[NG];
+  double cv[VAR ? NG : 1];
+  double buf[D][W];
+  double acc[8];
+  double accv[VAR ? 8 : 1];
+};
+
+template <int U, int W, int NG, bool VAR>
+__device__ __forceinline__ void pr_issue(PrCtx<W, NG, VAR> &c) {
+  using C = PrCtx<W, NG, VAR>;
+  constexpr int rr = U / NG, g = U % NG;
+#pragma unroll
+  for (int j = 0; j < W; ++j) c.buf[U % C::D][j] = tl_rd<rr * 8>(c.ad[g][j]);
+}
+
+template <int U, int W, int NG, bool VAR>
+__device__ __forceinline__ void pr_steps(PrCtx<W, NG, VAR> &c) {
+  using C = PrCtx<W, NG, VAR>;
+  if constexpr (U < C::TOT) {
+    constexpr int rr = U / NG, g = U % NG;
+    if constexpr (U + C::D - 1 < C::TOT) pr_issue<U + C::D - 1>(c);
+    constexpr int newer = (C::TOT - 1 - U) < (C::D - 1) ? (C::TOT - 1 - U) : (C::D - 1);
+    tl_wait<newer * W>(c.buf[U % C::D]);
+    double v = c.buf[U % C::D][0];
+#pragma unroll
+    for (int j = 1; j < W; ++j) v *= c.buf[U % C::D][j];
+    c.acc[rr] = fma(v, c.th[g], c.acc[rr]);
+    if constexpr (VAR) c.accv[rr] = fma(v * v, c.cv[g], c.accv[rr]);
+    pr_steps<U + 1>(c);
+  }
+}
+
+template <int U, int W, int NG, bool VAR>
+__device__ __forceinline__ void pr_prologue(PrCtx<W, NG, VAR> &c) {
+  if constexpr (U < PrCtx<W, NG, VAR>::D - 1 && U < PrCtx<W, NG, VAR>::TOT) {
+    pr_issue<U>(c);
+    pr_prologue<U + 1>(c);
+  }
+}
+
+// 8 accumulators x 64 lanes -> tile rows rc .. rc + 7 of red[wave][.]
+__device__ __forceinline__ void pr_reduce8(const double (&acc)[8], double *__restrict__ redw, int rc,
+                                           int lane) {
+  double s4[4], s2[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s4[i] = swap32_sum(acc[i], acc[i + 4]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) s2[i] = swap16_sum(s4[i], s4[i + 2]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    double v = row16_ror_add<8>(s2[i]);
+    v = row16_ror_add<4>(v);
+    v = row16_ror_add<2>(v);
+    v = row16_ror_add<1>(v);
+    if ((lane & 15) == 0) redw[rc + i + 2 * (lane >> 4)] = v;
+  }
+}
+
+template <int W2, int NG, bool VAR>
+__global__ void __launch_bounds__(kTlThreads, 4)
+k_predict_tl(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
+             const double *__restrict__ kb, const double *__restrict__ kc,
+             const double *__restrict__ rot, const int *__restrict__ cpos, int d, int Mu,
+             const uint32_t *__restrict__ colsw, int p, uint64_t p_pad, int npass,
+             const double *__restrict__ theta, const double *__restrict__ coeffvar, double e2sigma,
+             const double *__restrict__ x, uint64_t n, uint64_t ntiles, uint64_t tiles_per_split,
+             double *__restrict__ mean, double *__restrict__ var) {
+  extern __shared__ double lds[];
+  constexpr int W = 2 * W2;
+  double *red = lds + (size_t)Mu * kTlPitch;    // [8 waves][64 rows] mean partials
+  double *redv = red + kTlWaves * kTileRows;    // [8][64] variance partials
+  double *reds = redv + kTlWaves * kTileRows;   // [8][64] scale partials
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+
+  PrCtx<W, NG, VAR> c;
+  auto load_terms = [&](int pass) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const uint64_t k = (((uint64_t)pass * NG + g) * kTlWaves + wave) * 64 + lane;
+      c.th[g] = k < (uint64_t)p ? theta[k] : 0.0;
+      if constexpr (VAR) c.cv[g] = k < (uint64_t)p ? coeffvar[k] : 0.0;
+#pragma unroll
+      for (int w = 0; w < W2; ++w) {
+        const uint32_t cw = k < p_pad ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+        c.ad[g][2 * w] = (cw & 0xffffu) * (kTlPitch * 8);
+        c.ad[g][2 * w + 1] = (cw >> 16) * (kTlPitch * 8);
+      }
+    }
+  };
+  if (npass == 1) load_terms(0);
+
+  double s_cur = 0.0;  // wave 0: basescale of row = lane of the tile being contracted
+  auto emit = [&](uint64_t tile, double s) {  // wave 0, lane = row
+    const uint64_t row = tile * kTileRows + lane;
+    double tm = 0.0, tv = 0.0;
+#pragma unroll
+    for (int q = 0; q < kTlWaves; ++q) {
+      tm += red[q * kTileRows + lane];
+      if (VAR) tv += redv[q * kTileRows + lane];
+    }
+    if (row < n) {
+      mean[row] = tm * s;
+      if (VAR) var[row] = tv * (s * s) + e2sigma;  // loglik_gauss.cpp:224-225
+    }
+  };
+
+  const StoreLdsPitch store{lds, cpos, lane};
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    __syncthreads();  // the previous tile's partials are complete, its LDS tile is free
+    if (tile > t0 && wave == 0) emit(tile - 1, s_cur);
+    {  // basis at the new rows, lane = row
+      const uint64_t row = tile * kTileRows + lane;
+      const bool valid = row < n;
+      double sc = 1.0;
+      for (int l = wave; l < d; l += kTlWaves) {
+        const DimDesc D = dims[l];
+        const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
+        sc *= build_dim_any(D, ka, kb, kc, rot, xv, store);
+      }
+      if (wave == 0) lds[lane] = 1.0;  // used column 0 = all ones
+      reds[wave * kTileRows + lane] = sc;
+    }
+    __syncthreads();  // tile built; wave 0 has read the previous partials
+    if (wave == 0) {
+      double s = 1.0;
+#pragma unroll
+      for (int q = 0; q < kTlWaves; ++q) s *= reds[q * kTileRows + lane];
+      s_cur = s;
+    }
+#pragma unroll 1
+    for (int rc = 0; rc < kTileRows; rc += 8) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        c.acc[r] = 0.0;
+        if constexpr (VAR) c.accv[r] = 0.0;
+      }
+      for (int pass = 0; pass < npass; ++pass) {
+        if (npass > 1) {
+          load_terms(pass);
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int j = 0; j < W; ++j) c.ad[g][j] += rc * 8;
+        }
+        pr_prologue<0>(c);
+        pr_steps<0>(c);
+      }
+      if (npass == 1) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            c.ad[g][j] += (rc + 8 < kTileRows) ? 8 * 8 : -(kTileRows - 8) * 8;
+            asm volatile("" : "+v"(c.ad[g][j]));
+          }
+      }
+      pr_reduce8(c.acc, red + wave * kTileRows, rc, lane);
+      if constexpr (VAR) pr_reduce8(c.accv, redv + wave * kTileRows, rc, lane);
+    }
+  }
+  __syncthreads();
+  if (t0 < t1 && wave == 0) emit(t1 - 1, s_cur);
+}
+
+template <int W2, int NG, bool VAR>
+int run_predict_tl(const obhip_model &m, obhip_terms &t, const double *d_theta, const double *d_x,
+                   uint64_t n, double *d_mean, const double *d_coeffvar, double e2sigma,
+                   double *d_var, int npass) {
+  const size_t lds = (t.Mu * kTlPitch + 3 * kTlWaves * kTileRows) * sizeof(double);
+  if (lds > 64 * 1024)
+    OB_HIP(hipFuncSetAttribute((const void *)k_predict_tl<W2, NG, VAR>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+      ncu = 256;
+  }
+  const uint64_t ntiles = (n + kTileRows - 1) / kTileRows;
+  uint64_t nsplit = std::min<uint64_t>(ntiles, (uint64_t)ncu * 4);
+  const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  hipLaunchKernelGGL((k_predict_tl<W2, NG, VAR>), dim3((unsigned)nsplit), dim3(kTlThreads), lds,
+                     cur_stream(), t.pred_md.dims.p, t.pred_md.ka.p, t.pred_md.kb.p, t.pred_md.kc.p,
+                     t.pred_md.rot.p, t.cpos.p, (int)m.d, (int)t.Mu, (const uint32_t *)t.cols.p,
+                     (int)t.p, t.p_pad, npass, d_theta, d_coeffvar, e2sigma, d_x, n, ntiles, tps,
+                     d_mean, d_var);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+template <bool VAR>
+int dispatch_predict_tl(const obhip_model &m, obhip_terms &t, const double *d_theta,
+                        const double *d_x, uint64_t n, double *d_mean, const double *d_coeffvar,
+                        double e2sigma, double *d_var) {
+  // the variance form carries twice the accumulators and coefficients: half the terms per lane
+  const int ngmax = (t.W / 2 <= 2 ? 8 : 4) / (VAR ? 2 : 1);
+  int ng = 1;
+  while (ng < ngmax && (uint64_t)kTlWaves * ng * 64 < t.p_pad) ng *= 2;
+  const uint64_t tpb = (uint64_t)kTlWaves * ng * 64;
+  const int npass = (int)((t.p_pad + tpb - 1) / tpb);
+#define OB_PR(W2_, NG_) \
+  return run_predict_tl<W2_, NG_, VAR>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var, npass)
+  // (the larger NG only exist without the variance)
+  switch (t.W / 2) {
+    case 1:
+      if constexpr (!VAR) if (ng == 8) OB_PR(1, 8);
+      if (ng == 4) OB_PR(1, 4);
+      if (ng == 2) OB_PR(1, 2);
+      OB_PR(1, 1);
+    case 2:
+      if constexpr (!VAR) if (ng == 8) OB_PR(2, 8);
+      if (ng == 4) OB_PR(2, 4);
+      if (ng == 2) OB_PR(2, 2);
+      OB_PR(2, 1);
+    case 3:
+      if constexpr (!VAR) if (ng == 4) OB_PR(3, 4);
+      if (ng == 2) OB_PR(3, 2);
+      OB_PR(3, 1);
+    default:
+      if constexpr (!VAR) if (ng == 4) OB_PR(4, 4);
+      if (ng == 2) OB_PR(4, 2);
+      OB_PR(4, 1);
+  }
+#undef OB_PR
+}
+
 template <int W2, bool VAR>
 int run_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, const double *d_x,
                 uint64_t n, double *d_mean, const double *d_coeffvar, double e2sigma, double *d_var) {
@@ -139,6 +382,14 @@ int launch_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, 
     return fail(OBHIP_ERR_INVALID, "terms touch too many basis columns for the LDS tile");
   if (n == 0) return 0;
   ProfScope ps("predict");
+  static const bool lane_row = getenv("OBHIP_PREDICT_LANE_ROW") != nullptr;
+  const int w2 = (int)(t.W / 2);
+  if (!lane_row && w2 >= 1 && w2 <= 4 &&
+      (t.Mu * kTlPitch + 3 * kTlWaves * kTileRows) * sizeof(double) <= 156 * 1024) {
+    if (d_coeffvar != nullptr && d_var != nullptr)
+      return dispatch_predict_tl<true>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
+    return dispatch_predict_tl<false>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
+  }
   if (d_coeffvar != nullptr && d_var != nullptr)
     return dispatch_predict<true>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
   return dispatch_predict<false>(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);

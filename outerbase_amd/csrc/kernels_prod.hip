@@ -259,39 +259,6 @@ k_tmm(const double *__restrict__ bm, const double *__restrict__ scale,
 // in flight per wave (lgkmcnt counts to 15), LDS returns in order, so s_waitcnt
 // lgkmcnt((D-1) W) releases the oldest unit; the "+v" operands tie each wait to the
 // registers it releases.
-constexpr int kTlThreads = 512, kTlWaves = kTlThreads / 64, kTlGP = 2, kTlPitch = 65;
-constexpr int kTlPre = 16;    // prefetch registers per thread => Mu <= 8 * 16
-constexpr int kTlChunk = 16;  // rows per unrolled chunk (code size)
-
-template <int OFF>
-__device__ __forceinline__ double tl_rd(uint32_t addr) {
-  double v;
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
-template <int KEEP, int W>
-__device__ __forceinline__ void tl_wait(double (&b)[W]) {
-  static_assert(W == 2 || W == 4 || W == 6 || W == 8, "");
-  if constexpr (W == 2)
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(KEEP) : "memory");
-  else if constexpr (W == 4)
-    asm volatile("s_waitcnt lgkmcnt(%4)"
-                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-                 : "n"(KEEP)
-                 : "memory");
-  else if constexpr (W == 6)
-    asm volatile("s_waitcnt lgkmcnt(%6)"
-                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5])
-                 : "n"(KEEP)
-                 : "memory");
-  else
-    asm volatile("s_waitcnt lgkmcnt(%8)"
-                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]),
-                   "+v"(b[6]), "+v"(b[7])
-                 : "n"(KEEP)
-                 : "memory");
-}
-
 template <int W, int NPAIR>
 struct TlCtx {
   static constexpr int D = (12 / W) > 0 ? 12 / W : 1;  // units in flight
@@ -651,31 +618,6 @@ __device__ __forceinline__ void ml_prologue(MlCtx<W, NG> &c) {
     ml_issue<U>(c);
     ml_prologue<U + 1>(c);
   }
-}
-
-// a + b where, afterwards, lanes 0-31 hold the sum of a over lanes (l, l + 32) and lanes
-// 32-63 the sum of b over (l - 32, l)
-__device__ __forceinline__ double swap32_sum(double a, double b) {
-  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a),
-                                                   (unsigned)__double2loint(b), false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a),
-                                                   (unsigned)__double2hiint(b), false, false);
-  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-}
-// the same one level down: 16-lane rows 0 and 2 end with the sum of a over rows (0,1) and
-// (2,3), rows 1 and 3 with the sum of b
-__device__ __forceinline__ double swap16_sum(double a, double b) {
-  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a),
-                                                   (unsigned)__double2loint(b), false, false);
-  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a),
-                                                   (unsigned)__double2hiint(b), false, false);
-  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-}
-template <int ROR>
-__device__ __forceinline__ double row16_ror_add(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + ROR, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + ROR, 0xf, 0xf, false);
-  return v + __hiloint2double(hi, lo);
 }
 
 template <int W2, bool SQ, int NG, bool PREFETCH>

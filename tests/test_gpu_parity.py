@@ -963,6 +963,18 @@ def test_term_per_lane_variants(max_nnz, p, maxlev):
         assert relerr(gotsq, (B * B) @ np.abs(a)) < tol
         assert relerr(got, Bd @ a) < 1e-12
         assert relerr(gotsq, (Bd * Bd) @ np.abs(a)) < 1e-12
+        # the fused predictor (k_predict_tl; several passes over the terms when they exceed
+        # one block's registers): mean = B a, var = B^2 cv + e^{2 sigma}
+        from outerbase_amd._lib import call, ptr
+        mean, var = np.empty(n), np.empty(n)
+        cv, sig = np.abs(a) + 0.1, -0.3
+        xf = np.asfortranarray(x)
+        tt = ob.obmod._Terms(om_d, terms)
+        call("obhip_predict", om_d._h, tt._h, ptr(a), ptr(xf), n, n, ptr(mean), ptr(cv), sig, ptr(var))
+        assert relerr(mean, Bd @ a) < 1e-11
+        assert relerr(var, (Bd * Bd) @ cv + math.exp(2 * sig)) < 1e-11
+        call("obhip_predict", om_d._h, tt._h, ptr(a), ptr(xf), n, n, ptr(mean), None, sig, None)
+        assert relerr(mean, Bd @ a) < 1e-11
 
 
 @pytest.mark.parametrize("seed", range(16))
