@@ -358,9 +358,12 @@ def main():
     elif "mm" in prof:
         byts = float(n) * 8 * (hp.ncols + 1)
         ach = byts / (prof["mm"]["avg_ms"] * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_mm", "achieved": ach, "peak": HBM_PEAK_GBS,
+        # the PCG back end's kernels are LDS-bound (80 % LdsUtil, profiles/r01_pmc_products.txt);
+        # the contract's roofline object only knows hbm | mfma, so this is the HBM view of k_mm_tl
+        out["roofline"] = {"bound": "hbm", "kernel": "k_mm_tl", "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "avg_launch_ms": prof["mm"]["avg_ms"]}
+                           "avg_launch_ms": prof["mm"]["avg_ms"],
+                           "note": "LDS-bound kernel, see profiles/r01_pmc_products.txt"}
     if not args.no_cpu_baseline and world == 1:
         # the CPU leg: the oracle as the timed baseline and as the checker of this very run
         # (device predictions and Newton stationarity on a row sample); nothing else in this
