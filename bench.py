@@ -142,6 +142,12 @@ def cpu_baseline(hp, ns, threads=16):
         else:
             O.predict_mean(om, hp.terms, theta, xnew)
         t["predict"] = time.perf_counter() - t0
+        if use_cpp:   # one B a and one B^T r pass: what a PCG iteration is made of (fit.cpp:71-85)
+            r = y - B @ theta
+            t0 = time.perf_counter()
+            ob_cpu.mm(om, hp.terms, bm, bs, theta, threads)
+            ob_cpu.tmm(om, hp.terms, bm, bs, r, threads)
+            t["mm_tmm"] = time.perf_counter() - t0
         return t
 
     if threadpool_limits is not None:
@@ -153,7 +159,16 @@ def cpu_baseline(hp, ns, threads=16):
     full = per_row * hp.n + t["solve"]
     impl = "oracle/ob_cpu.cpp (C++/OpenMP, reference chunk schedule)" if use_cpp \
         else "oracle/ob_oracle.py (NumPy)"
-    return {"value": hp.n / full, "unit": "points/s", "cores": threads, "kind": "port",
+    pcg = None
+    if "mm_tmm" in t:
+        # the matrix-free path obfit itself takes -- build, then per
+        # iteration update() + hessmult() = two B a and two B^T r passes (fit.cpp:71-85), at
+        # the iteration count the device PCG needed, then predict
+        iters = getattr(hp, "cg_iters", None) or 22
+        full_pcg = (t["build"] + t["predict"] + 2 * (iters + 1) * t["mm_tmm"]) / ns * hp.n
+        pcg = {"value": hp.n / full_pcg, "unit": "points/s", "iterations": iters,
+               "mm_plus_tmm_s_on_sample": t["mm_tmm"]}
+    return {"value": hp.n / full, "unit": "points/s", "cores": threads, "kind": "port", "pcg_path": pcg,
             "sample": "%s + NumPy BLAS/LAPACK for B^T B and solve, %d threads, %d rows of the "
                       "same workload: build %.2fs getmat %.2fs gram %.2fs solve %.2fs predict "
                       "%.2fs; row work scaled to n=%d, solve counted once"
@@ -368,6 +383,8 @@ def main():
         # the CPU leg: the oracle as the timed baseline and as the checker of this very run
         # (device predictions and Newton stationarity on a row sample); nothing else in this
         # file touches oracle/
+        if alt and hp.cg_iters is None:
+            hp.cg_iters = alt.get("cg_iterations")
         out["cpu_baseline"] = cpu_baseline(hp, args.cpu_sample)
         out["parity_check"] = check_against_oracle(hp)
     print(json.dumps(out))
