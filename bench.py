@@ -176,6 +176,14 @@ def cpu_baseline(hp, ns, threads=16):
                          t["predict"], hp.n)}
 
 
+def which_config(d, n, p):
+    """Name of the BASELINE.json configuration these sizes are (rows per GPU)."""
+    known = {(10, 100000, 1024): "BASELINE.json configs[1]", (20, 1000000, 1024 * 4): "BASELINE.json configs[2]",
+             (20, 1250000, 4096): "BASELINE.json configs[3] (one of 8 row shards)",
+             (40, 125000, 16384): "BASELINE.json configs[4] (one of 8 row shards)"}
+    return known.get((d, n, p), "custom sizes")
+
+
 def n_rows_all(hp):
     return hp.n * hp.world
 
@@ -333,9 +341,10 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE.json configs[2]: d=%d n=%d rows/GPU p=%d, %s, %d knots/dim, "
-                        "fit (Gram+Cholesky) + predict on n fresh rows"
-                        % (args.d, n, p, "/".join(sorted(set(kinds))), args.knots),
+            "workload": "%s: d=%d n=%d rows/GPU p=%d, %s, %d knots/dim, "
+                        "fit (%s) + predict on n fresh rows"
+                        % (which_config(args.d, n, p), args.d, n, p, "/".join(sorted(set(kinds))),
+                           args.knots, "Gram+Cholesky" if args.backend == "newton" else "PCG"),
             "backend": args.backend,
             "rows_per_gpu": n, "d": args.d, "p": p,
             "terms_nnz": hp.terms_info["nnz_total"], "basis_columns": hp.ncols,
