@@ -4,7 +4,16 @@
 //   tmm    : out = B^T a (and (B^2)^T a)      tprodmm_ src/linalg.cpp:286-355
 // with B[i,k] = basescale[i] * prod_{l: t_kl>0} basemat[i, col(l, t_kl)].
 //
-// All three stage one 64-row tile of the used basemat columns in LDS
+// Two generations live here.
+//
+// Term-per-lane (default for terms of up to 8 factors): k_tmm_tl, k_mm_tl, k_materialize_tl
+// (and k_predict_tl in kernels_predict.hip).  lane = term, the LDS byte addresses of a term's
+// columns are loop-invariant registers, the row is the immediate offset of the ds_read_b64;
+// persistent blocks of 8 waves walk a range of 64-row tiles staged as [column][65].  The LDS
+// pipe is the bound (80 % busy at the benchmark size).  Described at k_tmm_tl.
+//
+// Lane-per-row (first generation; terms of more than 8 factors, getmat): k_mm, k_tmm.  All
+// stage one 64-row tile of the used basemat columns in LDS
 // ([column][row], one 512-byte run per column, straight from the tile-blocked
 // HBM layout) and map lane = row, so every LDS read in the Hadamard product is
 // a conflict-free ds_read_b64 at a wave-uniform column.
@@ -17,8 +26,8 @@
 //
 // tmm keeps a 64-term x 64-row block of partial sums in registers per wave
 // (acc[t], lane = row mod 64) across all its row tiles and reduces across lanes
-// once at the end, so its per-element cost equals mm's; the next tile's global
-// loads are in flight while the current tile is consumed.
+// once at the end; the next tile's global loads are in flight while the current tile
+// is consumed.
 #include "obhip_internal.h"
 #include "device_common.h"
 
