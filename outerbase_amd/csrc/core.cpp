@@ -271,6 +271,18 @@ int obhip_terms::prepare(const std::vector<int64_t> &cap,
     }
   }
   OB_TRY(cols.upload(hc.data(), hc.size()));
+  // Slot order of the term-per-lane kernels: by falling number of factors, so that the 64 x NU
+  // consecutive slots a wave owns hold terms of (nearly) one length and the wave reads only
+  // that many column slots per term; the padding terms p .. p_pad keep their places.
+  {
+    std::vector<uint32_t> nz(p, 0), order(p_pad);
+    for (uint64_t k = 0; k < p; ++k)
+      for (uint64_t l = 0; l < d; ++l) nz[k] += lev[k * d + l] > 0;
+    for (uint64_t k = 0; k < p_pad; ++k) order[k] = (uint32_t)k;
+    std::stable_sort(order.begin(), order.begin() + p,
+                     [&](uint32_t a, uint32_t b) { return nz[a] > nz[b]; });
+    OB_TRY(sperm.upload(order.data(), order.size()));
+  }
   OB_TRY(ucol.upload(used.data(), used.size()));
   uint64_t Mc = 1;
   for (uint64_t l = 0; l < d; ++l) Mc += (uint64_t)cap[l];

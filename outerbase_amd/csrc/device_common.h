@@ -243,6 +243,111 @@ __device__ __forceinline__ void tl_wait(double (&b)[W]) {
                  : "memory");
 }
 
+// ---- the read pipeline of the term-per-lane kernels ---------------------------------------
+// s_waitcnt lgkmcnt(KEEP) tied to the N registers b[S .. S+N) it releases
+template <int KEEP, int N, int S>
+__device__ __forceinline__ void tl_waitn(double (&b)[12]) {
+  static_assert(N >= 1 && N <= 8 && S + N <= 12, "");
+  if constexpr (N == 1)
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(b[S]) : "n"(KEEP) : "memory");
+  else if constexpr (N == 2)
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b[S]), "+v"(b[S + 1]) : "n"(KEEP) : "memory");
+  else if constexpr (N == 3)
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(b[S]), "+v"(b[S + 1]), "+v"(b[S + 2]) : "n"(KEEP) : "memory");
+  else if constexpr (N == 4)
+    asm volatile("s_waitcnt lgkmcnt(%4)"
+                 : "+v"(b[S]), "+v"(b[S + 1]), "+v"(b[S + 2]), "+v"(b[S + 3])
+                 : "n"(KEEP)
+                 : "memory");
+  else if constexpr (N == 5)
+    asm volatile("s_waitcnt lgkmcnt(%5)"
+                 : "+v"(b[S]), "+v"(b[S + 1]), "+v"(b[S + 2]), "+v"(b[S + 3]), "+v"(b[S + 4])
+                 : "n"(KEEP)
+                 : "memory");
+  else if constexpr (N == 6)
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(b[S]), "+v"(b[S + 1]), "+v"(b[S + 2]), "+v"(b[S + 3]), "+v"(b[S + 4]),
+                   "+v"(b[S + 5])
+                 : "n"(KEEP)
+                 : "memory");
+  else if constexpr (N == 7)
+    asm volatile("s_waitcnt lgkmcnt(%7)"
+                 : "+v"(b[S]), "+v"(b[S + 1]), "+v"(b[S + 2]), "+v"(b[S + 3]), "+v"(b[S + 4]),
+                   "+v"(b[S + 5]), "+v"(b[S + 6])
+                 : "n"(KEEP)
+                 : "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(b[S]), "+v"(b[S + 1]), "+v"(b[S + 2]), "+v"(b[S + 3]), "+v"(b[S + 4]),
+                   "+v"(b[S + 5]), "+v"(b[S + 6]), "+v"(b[S + 7])
+                 : "n"(KEEP)
+                 : "memory");
+}
+
+// One chunk of ROWS tile rows for the NU terms ("units") a lane holds.  A unit's product is
+// the last WE of its W column slots (the term tables are right-aligned, so a wave whose terms
+// all have at most WE factors skips the leading ones); D = 12 / WE units are in flight (LDS
+// returns in order, lgkmcnt counts to 15; INFLIGHT caps the reads -- and their registers).
+// The context C provides
+//   uint32_t ad[NU][W]                       LDS byte addresses of row 0 of the chunk
+//   template <int RR> void row()             once per row, before its first unit
+//   template <int RR, int UNIT> void use(v)  the product of unit UNIT at row RR
+template <int WE, int W, int NU, int ROWS, int INFLIGHT = 12>
+struct TlPipe {
+  static_assert(WE >= 1 && WE <= W && W <= 8 && INFLIGHT <= 12, "");
+  static constexpr int D = (INFLIGHT / WE) > 0 ? INFLIGHT / WE : 1;
+  static constexpr int TOT = ROWS * NU;
+
+  template <int U, typename C>
+  static __device__ __forceinline__ void issue(C &c, double (&buf)[12]) {
+    constexpr int rr = U / NU, unit = U % NU, s = (U % D) * WE;
+#pragma unroll
+    for (int j = 0; j < WE; ++j) buf[s + j] = tl_rd<rr * 8>(c.ad[unit][W - WE + j]);
+  }
+  template <int U, typename C>
+  static __device__ __forceinline__ void steps(C &c, double (&buf)[12]) {
+    if constexpr (U < TOT) {
+      constexpr int rr = U / NU, unit = U % NU, s = (U % D) * WE;
+      if constexpr (U + D - 1 < TOT) issue<U + D - 1>(c, buf);
+      if constexpr (unit == 0) c.template row<rr>();
+      constexpr int newer = (TOT - 1 - U) < (D - 1) ? (TOT - 1 - U) : (D - 1);
+      tl_waitn<newer * WE, WE, s>(buf);
+      double v = buf[s];
+#pragma unroll
+      for (int j = 1; j < WE; ++j) v *= buf[s + j];
+      c.template use<rr, unit>(v);
+      steps<U + 1>(c, buf);
+    }
+  }
+  template <int U, typename C>
+  static __device__ __forceinline__ void prologue(C &c, double (&buf)[12]) {
+    if constexpr (U < D - 1 && U < TOT) {
+      issue<U>(c, buf);
+      prologue<U + 1>(c, buf);
+    }
+  }
+  template <typename C>
+  static __device__ __forceinline__ void run(C &c) {
+    double buf[12];
+    prologue<0>(c, buf);
+    steps<0>(c, buf);
+  }
+};
+
+// number of factors of a term from its packed column words (used column 0 = the ones)
+template <int W2>
+__device__ __forceinline__ int tl_nnz(const uint32_t (&cw)[W2]) {
+  int nz = 0;
+#pragma unroll
+  for (int w = 0; w < W2; ++w) nz += ((cw[w] & 0xffffu) != 0) + ((cw[w] >> 16) != 0);
+  return nz;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
 // a + b where, afterwards, lanes 0-31 hold the sum of a over lanes (l, l + 32) and lanes
 // 32-63 the sum of b over (l - 32, l)
 __device__ __forceinline__ double swap32_sum(double a, double b) {

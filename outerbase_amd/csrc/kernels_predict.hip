@@ -105,48 +105,19 @@ k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
 // over the same LDS tile with the tables reloaded.
 template <int W, int NG, bool VAR>
 struct PrCtx {
-  static constexpr int D = (12 / W) > 0 ? 12 / W : 1;
-  static constexpr int TOT = 8 * NG;  // units per 8-row chunk
   uint32_t ad[NG][W];
   double th[NG];
   double cv[VAR ? NG : 1];
-  double buf[D][W];
   double acc[8];
   double accv[VAR ? 8 : 1];
+  template <int RR>
+  __device__ __forceinline__ void row() {}
+  template <int RR, int UNIT>
+  __device__ __forceinline__ void use(double v) {
+    acc[RR] = fma(v, th[UNIT], acc[RR]);
+    if constexpr (VAR) accv[RR] = fma(v * v, cv[UNIT], accv[RR]);
+  }
 };
-
-template <int U, int W, int NG, bool VAR>
-__device__ __forceinline__ void pr_issue(PrCtx<W, NG, VAR> &c) {
-  using C = PrCtx<W, NG, VAR>;
-  constexpr int rr = U / NG, g = U % NG;
-#pragma unroll
-  for (int j = 0; j < W; ++j) c.buf[U % C::D][j] = tl_rd<rr * 8>(c.ad[g][j]);
-}
-
-template <int U, int W, int NG, bool VAR>
-__device__ __forceinline__ void pr_steps(PrCtx<W, NG, VAR> &c) {
-  using C = PrCtx<W, NG, VAR>;
-  if constexpr (U < C::TOT) {
-    constexpr int rr = U / NG, g = U % NG;
-    if constexpr (U + C::D - 1 < C::TOT) pr_issue<U + C::D - 1>(c);
-    constexpr int newer = (C::TOT - 1 - U) < (C::D - 1) ? (C::TOT - 1 - U) : (C::D - 1);
-    tl_wait<newer * W>(c.buf[U % C::D]);
-    double v = c.buf[U % C::D][0];
-#pragma unroll
-    for (int j = 1; j < W; ++j) v *= c.buf[U % C::D][j];
-    c.acc[rr] = fma(v, c.th[g], c.acc[rr]);
-    if constexpr (VAR) c.accv[rr] = fma(v * v, c.cv[g], c.accv[rr]);
-    pr_steps<U + 1>(c);
-  }
-}
-
-template <int U, int W, int NG, bool VAR>
-__device__ __forceinline__ void pr_prologue(PrCtx<W, NG, VAR> &c) {
-  if constexpr (U < PrCtx<W, NG, VAR>::D - 1 && U < PrCtx<W, NG, VAR>::TOT) {
-    pr_issue<U>(c);
-    pr_prologue<U + 1>(c);
-  }
-}
 
 // 8 accumulators x 64 lanes -> tile rows rc .. rc + 7 of red[wave][.]
 __device__ __forceinline__ void pr_reduce8(const double (&acc)[8], double *__restrict__ redw, int rc,
@@ -171,12 +142,14 @@ __global__ void __launch_bounds__(kTlThreads, 4)
 k_predict_tl(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
              const double *__restrict__ kb, const double *__restrict__ kc,
              const double *__restrict__ rot, const int *__restrict__ cpos, int d, int Mu,
-             const uint32_t *__restrict__ colsw, int p, uint64_t p_pad, int npass,
+             const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm, int p,
+             uint64_t p_pad, int npass,
              const double *__restrict__ theta, const double *__restrict__ coeffvar, double e2sigma,
              const double *__restrict__ x, uint64_t n, uint64_t ntiles, uint64_t tiles_per_split,
              double *__restrict__ mean, double *__restrict__ var) {
   extern __shared__ double lds[];
   constexpr int W = 2 * W2;
+  constexpr int kInflight = NG * W >= 32 ? 8 : 12;
   double *red = lds + (size_t)Mu * kTlPitch;    // [8 waves][64 rows] mean partials
   double *redv = red + kTlWaves * kTileRows;    // [8][64] variance partials
   double *reds = redv + kTlWaves * kTileRows;   // [8][64] scale partials
@@ -186,19 +159,28 @@ k_predict_tl(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
   const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
 
   PrCtx<W, NG, VAR> c;
+  int we = W;  // column slots the terms of this wave (and pass) need
+  // slots ((pass * 8 + wave) * NG + g) * 64 + lane of the sorted order
   auto load_terms = [&](int pass) {
+    int nzmax = 1;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const uint64_t k = (((uint64_t)pass * NG + g) * kTlWaves + wave) * 64 + lane;
-      c.th[g] = k < (uint64_t)p ? theta[k] : 0.0;
-      if constexpr (VAR) c.cv[g] = k < (uint64_t)p ? coeffvar[k] : 0.0;
+      const uint64_t slot = (((uint64_t)pass * kTlWaves + wave) * NG + g) * 64 + lane;
+      const bool ok = slot < p_pad;
+      const uint64_t k = ok ? sperm[slot] : 0;
+      const bool real = ok && k < (uint64_t)p;
+      c.th[g] = real ? theta[k] : 0.0;
+      if constexpr (VAR) c.cv[g] = real ? coeffvar[k] : 0.0;
+      uint32_t cw[W2];
 #pragma unroll
       for (int w = 0; w < W2; ++w) {
-        const uint32_t cw = k < p_pad ? colsw[k * W2 + w] : 0u;  // column 0 = ones
-        c.ad[g][2 * w] = (cw & 0xffffu) * (kTlPitch * 8);
-        c.ad[g][2 * w + 1] = (cw >> 16) * (kTlPitch * 8);
+        cw[w] = ok ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+        c.ad[g][2 * w] = (cw[w] & 0xffffu) * (kTlPitch * 8);
+        c.ad[g][2 * w + 1] = (cw[w] >> 16) * (kTlPitch * 8);
       }
+      nzmax = max(nzmax, tl_nnz<W2>(cw));
     }
+    we = max(wave_max_i32(nzmax), max(1, W - 3));
   };
   if (npass == 1) load_terms(0);
 
@@ -255,8 +237,15 @@ k_predict_tl(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
 #pragma unroll
             for (int j = 0; j < W; ++j) c.ad[g][j] += rc * 8;
         }
-        pr_prologue<0>(c);
-        pr_steps<0>(c);
+        if (we == W) {
+          TlPipe<W, W, NG, 8, kInflight>::run(c);
+        } else if (we == W - 1) {
+          TlPipe<W - 1, W, NG, 8, kInflight>::run(c);
+        } else if (W >= 3 && we == W - 2) {
+          TlPipe<(W >= 3 ? W - 2 : 1), W, NG, 8, kInflight>::run(c);
+        } else {
+          TlPipe<(W >= 4 ? W - 3 : 1), W, NG, 8, kInflight>::run(c);
+        }
       }
       if (npass == 1) {
 #pragma unroll
@@ -297,7 +286,7 @@ int run_predict_tl(const obhip_model &m, obhip_terms &t, const double *d_theta, 
   hipLaunchKernelGGL((k_predict_tl<W2, NG, VAR>), dim3((unsigned)nsplit), dim3(kTlThreads), lds,
                      cur_stream(), t.pred_md.dims.p, t.pred_md.ka.p, t.pred_md.kb.p, t.pred_md.kc.p,
                      t.pred_md.rot.p, t.cpos.p, (int)m.d, (int)t.Mu, (const uint32_t *)t.cols.p,
-                     (int)t.p, t.p_pad, npass, d_theta, d_coeffvar, e2sigma, d_x, n, ntiles, tps,
+                     t.sperm.p, (int)t.p, t.p_pad, npass, d_theta, d_coeffvar, e2sigma, d_x, n, ntiles, tps,
                      d_mean, d_var);
   OB_HIP(hipGetLastError());
   return 0;

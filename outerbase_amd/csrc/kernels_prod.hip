@@ -268,49 +268,43 @@ k_tmm(const double *__restrict__ bm, const double *__restrict__ scale,
 // in flight per wave (lgkmcnt counts to 15), LDS returns in order, so s_waitcnt
 // lgkmcnt((D-1) W) releases the oldest unit; the "+v" operands tie each wait to the
 // registers it releases.
-template <int W, int NPAIR>
-struct TlCtx {
-  static constexpr int D = (12 / W) > 0 ? 12 / W : 1;  // units in flight
-  static constexpr int NU = NPAIR * kTlGP;             // units (terms of this lane) per row
-  static constexpr int TOT = kTlChunk * NU;            // units per chunk
-  uint32_t ad[NPAIR][kTlGP][W];
-  double acc[NPAIR][kTlGP];
-  double buf[D][W];
+// Terms are taken in the order of obhip_terms::sperm (falling number of factors): the
+// NPAIR x 2 x 64 consecutive slots of a wave then hold terms of nearly one length, and the wave
+// runs the pipeline instantiated for that length (TlPipe<WE, ...>): at the benchmark size
+// 25 instead of 32 column reads per lane and row.
+template <int W, int NU>
+struct TmmCtx {
+  uint32_t ad[NU][W];
+  double acc[NU];
   double vs;  // weight of row = lane
   double vr;  // weight of the current row, wave-uniform
   int rc;     // first row of the chunk
+  template <int RR>
+  __device__ __forceinline__ void row() {
+    vr = readlane_f64(vs, rc + RR);
+  }
+  template <int RR, int UNIT>
+  __device__ __forceinline__ void use(double v) {
+    acc[UNIT] = fma(v, vr, acc[UNIT]);
+  }
 };
 
-template <int U, int W, int NPAIR>
-__device__ __forceinline__ void tl_issue(TlCtx<W, NPAIR> &c) {
-  using C = TlCtx<W, NPAIR>;
-  constexpr int rr = U / C::NU, unit = U % C::NU, q = unit / kTlGP, i = unit % kTlGP;
+template <int WE, int W, int NU>
+__device__ __forceinline__ void tmm_tile(TmmCtx<W, NU> &c) {
+#pragma unroll 1
+  for (int rc = 0; rc < kTileRows; rc += kTlChunk) {
+    c.rc = rc;
+    // 8 units x W addresses already fill the register budget: 8 reads in flight instead of 12
+    TlPipe<WE, W, NU, kTlChunk, (NU * W >= 32 ? 8 : 12)>::run(c);
 #pragma unroll
-  for (int j = 0; j < W; ++j) c.buf[U % C::D][j] = tl_rd<rr * 8>(c.ad[q][i][j]);
-}
-
-template <int U, int W, int NPAIR>
-__device__ __forceinline__ void tl_steps(TlCtx<W, NPAIR> &c) {
-  using C = TlCtx<W, NPAIR>;
-  if constexpr (U < C::TOT) {
-    constexpr int rr = U / C::NU, unit = U % C::NU, q = unit / kTlGP, i = unit % kTlGP;
-    if constexpr (U + C::D - 1 < C::TOT) tl_issue<U + C::D - 1>(c);
-    if constexpr (unit == 0) c.vr = readlane_f64(c.vs, c.rc + rr);
-    constexpr int newer = (C::TOT - 1 - U) < (C::D - 1) ? (C::TOT - 1 - U) : (C::D - 1);
-    tl_wait<newer * W>(c.buf[U % C::D]);
-    double v = c.buf[U % C::D][0];
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
-    for (int j = 1; j < W; ++j) v *= c.buf[U % C::D][j];
-    c.acc[q][i] = fma(v, c.vr, c.acc[q][i]);
-    tl_steps<U + 1>(c);
-  }
-}
-
-template <int U, int W, int NPAIR>
-__device__ __forceinline__ void tl_prologue(TlCtx<W, NPAIR> &c) {
-  if constexpr (U < TlCtx<W, NPAIR>::D - 1) {
-    tl_issue<U>(c);
-    tl_prologue<U + 1>(c);
+      for (int j = 0; j < W; ++j) {
+        // next chunk, or back to row 0; opaque so that no second copy of the addresses
+        // is kept (and spilled) across the tile loop
+        c.ad[u][j] += (rc + kTlChunk < kTileRows) ? kTlChunk * 8 : -(kTileRows - kTlChunk) * 8;
+        asm volatile("" : "+v"(c.ad[u][j]));
+      }
   }
 }
 
@@ -318,31 +312,37 @@ template <int W2, bool SQ, int NPAIR, bool PREFETCH>
 __global__ void __launch_bounds__(kTlThreads, 4)
 k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
          const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc,
-         const uint32_t *__restrict__ colsw, const double *__restrict__ a, uint64_t n,
-         uint64_t ntiles, uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ part) {
+         const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm,
+         const double *__restrict__ a, uint64_t n, uint64_t ntiles, uint64_t tiles_per_split,
+         uint64_t p_pad, double *__restrict__ part) {
   extern __shared__ double lds[];
-  constexpr int W = 2 * W2;
+  constexpr int W = 2 * W2, NU = NPAIR * kTlGP;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
   const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
 
-  // my terms: group ((blockIdx.y * NPAIR + q) * 8 + wave) * 2 + i, term = group * 64 + lane
-  TlCtx<W, NPAIR> c;
+  // my terms: slots ((blockIdx.y * 8 + wave) * NU + u) * 64 + lane of the sorted order
+  TmmCtx<W, NU> c;
+  int nzmax = 1;
 #pragma unroll
-  for (int q = 0; q < NPAIR; ++q)
+  for (int u = 0; u < NU; ++u) {
+    const uint64_t slot = (((uint64_t)blockIdx.y * kTlWaves + wave) * NU + u) * 64 + lane;
+    const bool ok = slot < p_pad;
+    const uint64_t k = ok ? sperm[slot] : 0;
+    c.acc[u] = 0.0;
+    uint32_t cw[W2];
 #pragma unroll
-    for (int i = 0; i < kTlGP; ++i) {
-      const uint64_t k =
-          ((((uint64_t)blockIdx.y * NPAIR + q) * kTlWaves + wave) * kTlGP + i) * 64 + lane;
-      c.acc[q][i] = 0.0;
-#pragma unroll
-      for (int w = 0; w < W2; ++w) {
-        const uint32_t cw = k < p_pad ? colsw[k * W2 + w] : 0u;  // column 0 = ones
-        c.ad[q][i][2 * w] = (cw & 0xffffu) * (kTlPitch * 8);
-        c.ad[q][i][2 * w + 1] = (cw >> 16) * (kTlPitch * 8);
-      }
+    for (int w = 0; w < W2; ++w) {
+      cw[w] = ok ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+      c.ad[u][2 * w] = (cw[w] & 0xffffu) * (kTlPitch * 8);
+      c.ad[u][2 * w + 1] = (cw[w] >> 16) * (kTlPitch * 8);
     }
+    nzmax = max(nzmax, tl_nnz<W2>(cw));
+  }
+  // pipeline variants exist for W, W-1, W-2, W-3 column reads per term
+  const int we = max(wave_max_i32(nzmax), max(1, W - 3));
+  const bool live = (((uint64_t)blockIdx.y * kTlWaves + wave) * NU) * 64 < p_pad;
 
   // this wave stages columns u = wave + 8 q of every tile: their tile offsets, wave-uniform
   int lu[PREFETCH ? kTlPre : 1];
@@ -359,8 +359,8 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
     const uint64_t row = tile * kTileRows + lane;
     double v = 0.0;
     if (row < n) {
-      const double s = scale[row];
-      v = a[row] * (SQ ? s * s : s);  // b = basescale % a, linalg.cpp:305
+      const double sc = scale[row];
+      v = a[row] * (SQ ? sc * sc : sc);  // b = basescale % a, linalg.cpp:305
     }
     return v;
   };
@@ -394,32 +394,22 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
     }
     __syncthreads();
     if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
-#pragma unroll 1
-    for (int rc = 0; rc < kTileRows; rc += kTlChunk) {
-      c.rc = rc;
-      tl_prologue<0>(c);
-      tl_steps<0>(c);
-#pragma unroll
-      for (int q = 0; q < NPAIR; ++q)
-#pragma unroll
-        for (int i = 0; i < kTlGP; ++i)
-#pragma unroll
-          for (int j = 0; j < W; ++j) {
-            // next chunk, or back to row 0; opaque so that no second copy of the addresses
-            // is kept (and spilled) across the tile loop
-            c.ad[q][i][j] += (rc + kTlChunk < kTileRows) ? kTlChunk * 8 : -(kTileRows - kTlChunk) * 8;
-            asm volatile("" : "+v"(c.ad[q][i][j]));
-          }
+    if (!live) continue;  // (whole waves beyond p_pad in the last block along p)
+    if (we == W) {
+      tmm_tile<W>(c);
+    } else if (we == W - 1) {
+      tmm_tile<W - 1>(c);
+    } else if (W >= 3 && we == W - 2) {
+      tmm_tile<(W >= 3 ? W - 2 : 1)>(c);
+    } else {
+      tmm_tile<(W >= 4 ? W - 3 : 1)>(c);
     }
   }
 #pragma unroll
-  for (int q = 0; q < NPAIR; ++q)
-#pragma unroll
-    for (int i = 0; i < kTlGP; ++i) {
-      const uint64_t k =
-          ((((uint64_t)blockIdx.y * NPAIR + q) * kTlWaves + wave) * kTlGP + i) * 64 + lane;
-      if (k < p_pad) part[(uint64_t)blockIdx.x * p_pad + k] = c.acc[q][i];
-    }
+  for (int u = 0; u < NU; ++u) {
+    const uint64_t slot = (((uint64_t)blockIdx.y * kTlWaves + wave) * NU + u) * 64 + lane;
+    if (slot < p_pad) part[(uint64_t)blockIdx.x * p_pad + sperm[slot]] = c.acc[u];
+  }
 }
 
 // ---- row-major design matrix, term-per-lane ------------------------------------------------------
@@ -588,44 +578,49 @@ k_materialize_tl(const double *__restrict__ bm, const double *__restrict__ scale
 constexpr int kMlChunk = 8;  // rows per chunk: 8 accumulators, the register budget is tight
 
 template <int W, int NG>
-struct MlCtx {
-  static constexpr int D = (12 / W) > 0 ? 12 / W : 1;  // units in flight
-  static constexpr int TOT = kMlChunk * NG;            // units per chunk
+struct MmCtx {
   uint32_t ad[NG][W];
   double av[NG];
-  double buf[D][W];
   double acc[kMlChunk];
+  template <int RR>
+  __device__ __forceinline__ void row() {}
+  template <int RR, int UNIT>
+  __device__ __forceinline__ void use(double v) {
+    acc[RR] = fma(v, av[UNIT], acc[RR]);
+  }
 };
 
-template <int U, int W, int NG>
-__device__ __forceinline__ void ml_issue(MlCtx<W, NG> &c) {
-  using C = MlCtx<W, NG>;
-  constexpr int rr = U / NG, g = U % NG;
+// one tile: 8-row chunks, after each the 8 accumulators x 64 lanes go to red[rc .. rc + 7]
+template <int WE, int W, int NG>
+__device__ __forceinline__ void mm_tile(MmCtx<W, NG> &c, double *__restrict__ redw, int lane) {
+#pragma unroll 1
+  for (int rc = 0; rc < kTileRows; rc += kMlChunk) {
 #pragma unroll
-  for (int j = 0; j < W; ++j) c.buf[U % C::D][j] = tl_rd<rr * 8>(c.ad[g][j]);
-}
-
-template <int U, int W, int NG>
-__device__ __forceinline__ void ml_steps(MlCtx<W, NG> &c) {
-  using C = MlCtx<W, NG>;
-  if constexpr (U < C::TOT) {
-    constexpr int rr = U / NG, g = U % NG;
-    if constexpr (U + C::D - 1 < C::TOT) ml_issue<U + C::D - 1>(c);
-    constexpr int newer = (C::TOT - 1 - U) < (C::D - 1) ? (C::TOT - 1 - U) : (C::D - 1);
-    tl_wait<newer * W>(c.buf[U % C::D]);
-    double v = c.buf[U % C::D][0];
+    for (int r = 0; r < kMlChunk; ++r) c.acc[r] = 0.0;
+    TlPipe<WE, W, NG, kMlChunk, (NG * W >= 32 ? 8 : 12)>::run(c);
 #pragma unroll
-    for (int j = 1; j < W; ++j) v *= c.buf[U % C::D][j];
-    c.acc[rr] = fma(v, c.av[g], c.acc[rr]);
-    ml_steps<U + 1>(c);
-  }
-}
-
-template <int U, int W, int NG>
-__device__ __forceinline__ void ml_prologue(MlCtx<W, NG> &c) {
-  if constexpr (U < MlCtx<W, NG>::D - 1 && U < MlCtx<W, NG>::TOT) {
-    ml_issue<U>(c);
-    ml_prologue<U + 1>(c);
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        c.ad[g][j] += (rc + kMlChunk < kTileRows) ? kMlChunk * 8 : -(kTileRows - kMlChunk) * 8;
+        asm volatile("" : "+v"(c.ad[g][j]));
+      }
+    // 8 accumulators x 64 lanes -> 2 registers whose 16-lane row q holds tile row
+    // rc + i + 2 q, then the sum over the 16 lanes of the row
+    static_assert(kMlChunk == 8, "butterfly below reduces 8 rows");
+    double s4[4], s2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s4[i] = swap32_sum(c.acc[i], c.acc[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) s2[i] = swap16_sum(s4[i], s4[i + 2]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      double v = row16_ror_add<8>(s2[i]);
+      v = row16_ror_add<4>(v);
+      v = row16_ror_add<2>(v);
+      v = row16_ror_add<1>(v);
+      if ((lane & 15) == 0) redw[rc + i + 2 * (lane >> 4)] = v;
+    }
   }
 }
 
@@ -633,7 +628,8 @@ template <int W2, bool SQ, int NG, bool PREFETCH>
 __global__ void __launch_bounds__(kTlThreads, 4)
 k_mm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
         const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc, const uint32_t *__restrict__ colsw,
-        const double *__restrict__ a, int p, uint64_t n, uint64_t n_pad, uint64_t ntiles,
+        const uint32_t *__restrict__ sperm, const double *__restrict__ a, int p, uint64_t n,
+        uint64_t n_pad, uint64_t ntiles,
         uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ out,
         double *__restrict__ part) {
   extern __shared__ double lds[];
@@ -644,19 +640,26 @@ k_mm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
   const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
   const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
 
-  // my terms: group (blockIdx.y * NG + g) * 8 + wave, term = group * 64 + lane
-  MlCtx<W, NG> c;
+  // my terms: slots ((blockIdx.y * 8 + wave) * NG + g) * 64 + lane of the sorted order
+  MmCtx<W, NG> c;
+  int nzmax = 1;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    const uint64_t k = (((uint64_t)blockIdx.y * NG + g) * kTlWaves + wave) * 64 + lane;
-    c.av[g] = k < (uint64_t)p ? a[k] : 0.0;
+    const uint64_t slot = (((uint64_t)blockIdx.y * kTlWaves + wave) * NG + g) * 64 + lane;
+    const bool ok = slot < p_pad;
+    const uint64_t k = ok ? sperm[slot] : 0;
+    c.av[g] = ok && k < (uint64_t)p ? a[k] : 0.0;
+    uint32_t cw[W2];
 #pragma unroll
     for (int w = 0; w < W2; ++w) {
-      const uint32_t cw = k < p_pad ? colsw[k * W2 + w] : 0u;  // column 0 = ones
-      c.ad[g][2 * w] = (cw & 0xffffu) * (kTlPitch * 8);
-      c.ad[g][2 * w + 1] = (cw >> 16) * (kTlPitch * 8);
+      cw[w] = ok ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+      c.ad[g][2 * w] = (cw[w] & 0xffffu) * (kTlPitch * 8);
+      c.ad[g][2 * w + 1] = (cw[w] >> 16) * (kTlPitch * 8);
     }
+    nzmax = max(nzmax, tl_nnz<W2>(cw));
   }
+  const int we = max(wave_max_i32(nzmax), max(1, W - 3));
+  const bool live = (((uint64_t)blockIdx.y * kTlWaves + wave) * NG) * 64 < p_pad;
 
   int lu[PREFETCH ? kTlPre : 1];
   double pre[PREFETCH ? kTlPre : 1];
@@ -708,35 +711,17 @@ k_mm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
     }
     __syncthreads();  // tile staged; wave 0 has read red
     if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
-#pragma unroll 1
-    for (int rc = 0; rc < kTileRows; rc += kMlChunk) {
-#pragma unroll
-      for (int r = 0; r < kMlChunk; ++r) c.acc[r] = 0.0;
-      ml_prologue<0>(c);
-      ml_steps<0>(c);
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          c.ad[g][j] += (rc + kMlChunk < kTileRows) ? kMlChunk * 8 : -(kTileRows - kMlChunk) * 8;
-          asm volatile("" : "+v"(c.ad[g][j]));
-        }
-      // 8 accumulators x 64 lanes -> 2 registers whose 16-lane row q holds tile row
-      // rc + i + 2 q, then the sum over the 16 lanes of the row
-      static_assert(kMlChunk == 8, "butterfly below reduces 8 rows");
-      double s4[4], s2[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) s4[i] = swap32_sum(c.acc[i], c.acc[i + 4]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) s2[i] = swap16_sum(s4[i], s4[i + 2]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        double v = row16_ror_add<8>(s2[i]);
-        v = row16_ror_add<4>(v);
-        v = row16_ror_add<2>(v);
-        v = row16_ror_add<1>(v);
-        if ((lane & 15) == 0) red[wave * kTileRows + rc + i + 2 * (lane >> 4)] = v;
-      }
+    double *redw = red + wave * kTileRows;
+    if (!live) {  // whole waves beyond p_pad in the last block along p
+      redw[lane] = 0.0;
+    } else if (we == W) {
+      mm_tile<W>(c, redw, lane);
+    } else if (we == W - 1) {
+      mm_tile<W - 1>(c, redw, lane);
+    } else if (W >= 3 && we == W - 2) {
+      mm_tile<(W >= 3 ? W - 2 : 1)>(c, redw, lane);
+    } else {
+      mm_tile<(W >= 4 ? W - 3 : 1)>(c, redw, lane);
     }
   }
   __syncthreads();
@@ -879,13 +864,13 @@ int run_mm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d
   if (pf) {
     OB_TRY(set_lds(k_mm_tl<W2, SQ, NG, true>, lds));
     hipLaunchKernelGGL((k_mm_tl<W2, SQ, NG, true>), grid, dim3(kTlThreads), lds, cur_stream(), b.bm.p,
-                       b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, d_a,
-                       (int)t.p, b.n, b.n_pad, ntiles, tps, t.p_pad, d_out, part);
+                       b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, t.sperm.p,
+                       d_a, (int)t.p, b.n, b.n_pad, ntiles, tps, t.p_pad, d_out, part);
   } else {
     OB_TRY(set_lds(k_mm_tl<W2, SQ, NG, false>, lds));
     hipLaunchKernelGGL((k_mm_tl<W2, SQ, NG, false>), grid, dim3(kTlThreads), lds, cur_stream(), b.bm.p,
-                       b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, d_a,
-                       (int)t.p, b.n, b.n_pad, ntiles, tps, t.p_pad, d_out, part);
+                       b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, t.sperm.p,
+                       d_a, (int)t.p, b.n, b.n_pad, ntiles, tps, t.p_pad, d_out, part);
   }
   OB_HIP(hipGetLastError());
   return 0;
@@ -956,17 +941,18 @@ template <int W2, bool SQ, int NPAIR>
 int run_tmm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, double *part, dim3 grid,
                uint64_t ntiles, uint64_t tps) {
   const size_t lds = t.Mu * kTlPitch * sizeof(double);
-  const bool pf = t.Mu <= (uint64_t)kTlWaves * kTlPre;
+  static const bool nopf = getenv("OBHIP_TL_NOPREFETCH") != nullptr;
+  const bool pf = !nopf && t.Mu <= (uint64_t)kTlWaves * kTlPre;
   if (pf) {
     OB_TRY(set_lds(k_tmm_tl<W2, SQ, NPAIR, true>, lds));
     hipLaunchKernelGGL((k_tmm_tl<W2, SQ, NPAIR, true>), grid, dim3(kTlThreads), lds, cur_stream(),
                        b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,
-                       d_a, b.n, ntiles, tps, t.p_pad, part);
+                       t.sperm.p, d_a, b.n, ntiles, tps, t.p_pad, part);
   } else {
     OB_TRY(set_lds(k_tmm_tl<W2, SQ, NPAIR, false>, lds));
     hipLaunchKernelGGL((k_tmm_tl<W2, SQ, NPAIR, false>), grid, dim3(kTlThreads), lds, cur_stream(),
                        b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,
-                       d_a, b.n, ntiles, tps, t.p_pad, part);
+                       t.sperm.p, d_a, b.n, ntiles, tps, t.p_pad, part);
   }
   OB_HIP(hipGetLastError());
   return 0;

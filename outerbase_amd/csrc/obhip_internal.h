@@ -175,6 +175,7 @@ struct obhip_terms {
   uint64_t Mu = 0;                    // used compact columns
   obhip::DevBuf<uint16_t> cols;       // p_pad x W indices into the USED list
   obhip::DevBuf<uint32_t> ucol;       // Mu compact column ids (used list)
+  obhip::DevBuf<uint32_t> sperm;      // p_pad: terms ordered by falling number of factors (stable)
   obhip::DevBuf<int32_t> cpos;        // compact column -> used index or -1 (Mc)
   uint64_t p_pad = 0;
   // per hyper-parameter views for the gradient products (kernels_grad.hip)
