@@ -160,12 +160,12 @@ k_predict_tl(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
 
   PrCtx<W, NG, VAR> c;
   int we = W;  // column slots the terms of this wave (and pass) need
-  // slots ((pass * 8 + wave) * NG + g) * 64 + lane of the sorted order
+  // slots: NG * 64 consecutive ones of the sorted order per wave (tl_slot)
   auto load_terms = [&](int pass) {
     int nzmax = 1;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const uint64_t slot = (((uint64_t)pass * kTlWaves + wave) * NG + g) * 64 + lane;
+      const uint64_t slot = tl_slot<NG>((uint64_t)pass, wave, g, lane);
       const bool ok = slot < p_pad;
       const uint64_t k = ok ? sperm[slot] : 0;
       const bool real = ok && k < (uint64_t)p;
@@ -180,7 +180,7 @@ k_predict_tl(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
       }
       nzmax = max(nzmax, tl_nnz<W2>(cw));
     }
-    we = max(wave_max_i32(nzmax), max(1, W - 3));
+    we = tl_variant<W>(wave_max_i32(nzmax));
   };
   if (npass == 1) load_terms(0);
 
@@ -237,15 +237,7 @@ k_predict_tl(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
 #pragma unroll
             for (int j = 0; j < W; ++j) c.ad[g][j] += rc * 8;
         }
-        if (we == W) {
-          TlPipe<W, W, NG, 8, kInflight>::run(c);
-        } else if (we == W - 1) {
-          TlPipe<W - 1, W, NG, 8, kInflight>::run(c);
-        } else if (W >= 3 && we == W - 2) {
-          TlPipe<(W >= 3 ? W - 2 : 1), W, NG, 8, kInflight>::run(c);
-        } else {
-          TlPipe<(W >= 4 ? W - 3 : 1), W, NG, 8, kInflight>::run(c);
-        }
+        tl_run_half<W, NG, 8, kInflight, 0>(c, we);
       }
       if (npass == 1) {
 #pragma unroll

@@ -289,13 +289,19 @@ struct TmmCtx {
   }
 };
 
-template <int WE, int W, int NU>
-__device__ __forceinline__ void tmm_tile(TmmCtx<W, NU> &c) {
+template <int W, int NU>
+__device__ __forceinline__ void tmm_tile(TmmCtx<W, NU> &c, int wea, int web) {
+  // 8 units x W addresses already fill the register budget: 8 reads in flight instead of 12
+  constexpr int kInflight = NU * W >= 32 ? 8 : 12;
 #pragma unroll 1
   for (int rc = 0; rc < kTileRows; rc += kTlChunk) {
     c.rc = rc;
-    // 8 units x W addresses already fill the register budget: 8 reads in flight instead of 12
-    TlPipe<WE, W, NU, kTlChunk, (NU * W >= 32 ? 8 : 12)>::run(c);
+    if constexpr (NU == 1) {
+      tl_run_half<W, 1, kTlChunk, kInflight, 0>(c, wea);
+    } else {
+      tl_run_half<W, NU / 2, kTlChunk, kInflight, 0>(c, wea);
+      tl_run_half<W, NU / 2, kTlChunk, kInflight, NU / 2>(c, web);
+    }
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -322,13 +328,16 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
   const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
   const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
 
-  // my terms: slots ((blockIdx.y * 8 + wave) * NU + u) * 64 + lane of the sorted order
+  // my terms: NU * 64 consecutive slots of the sorted order (tl_slot); the two halves of the
+  // units get their own pipeline width
   TmmCtx<W, NU> c;
-  int nzmax = 1;
+  int nza = 1, nzb = 1;
+  bool live = false;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const uint64_t slot = (((uint64_t)blockIdx.y * kTlWaves + wave) * NU + u) * 64 + lane;
+    const uint64_t slot = tl_slot<NU>(blockIdx.y, wave, u, lane);
     const bool ok = slot < p_pad;
+    live = live || ok;
     const uint64_t k = ok ? sperm[slot] : 0;
     c.acc[u] = 0.0;
     uint32_t cw[W2];
@@ -338,11 +347,13 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
       c.ad[u][2 * w] = (cw[w] & 0xffffu) * (kTlPitch * 8);
       c.ad[u][2 * w + 1] = (cw[w] >> 16) * (kTlPitch * 8);
     }
-    nzmax = max(nzmax, tl_nnz<W2>(cw));
+    if (NU == 1 || u < NU / 2)
+      nza = max(nza, tl_nnz<W2>(cw));
+    else
+      nzb = max(nzb, tl_nnz<W2>(cw));
   }
-  // pipeline variants exist for W, W-1, W-2, W-3 column reads per term
-  const int we = max(wave_max_i32(nzmax), max(1, W - 3));
-  const bool live = (((uint64_t)blockIdx.y * kTlWaves + wave) * NU) * 64 < p_pad;
+  const int wea = tl_variant<W>(wave_max_i32(nza)), web = tl_variant<W>(wave_max_i32(nzb));
+  live = wave_max_i32(live ? 1 : 0) != 0;
 
   // this wave stages columns u = wave + 8 q of every tile: their tile offsets, wave-uniform
   int lu[PREFETCH ? kTlPre : 1];
@@ -395,19 +406,11 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
     __syncthreads();
     if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
     if (!live) continue;  // (whole waves beyond p_pad in the last block along p)
-    if (we == W) {
-      tmm_tile<W>(c);
-    } else if (we == W - 1) {
-      tmm_tile<W - 1>(c);
-    } else if (W >= 3 && we == W - 2) {
-      tmm_tile<(W >= 3 ? W - 2 : 1)>(c);
-    } else {
-      tmm_tile<(W >= 4 ? W - 3 : 1)>(c);
-    }
+    tmm_tile<W, NU>(c, wea, web);
   }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const uint64_t slot = (((uint64_t)blockIdx.y * kTlWaves + wave) * NU + u) * 64 + lane;
+    const uint64_t slot = tl_slot<NU>(blockIdx.y, wave, u, lane);
     if (slot < p_pad) part[(uint64_t)blockIdx.x * p_pad + sperm[slot]] = c.acc[u];
   }
 }
@@ -591,13 +594,15 @@ struct MmCtx {
 };
 
 // one tile: 8-row chunks, after each the 8 accumulators x 64 lanes go to red[rc .. rc + 7]
-template <int WE, int W, int NG>
-__device__ __forceinline__ void mm_tile(MmCtx<W, NG> &c, double *__restrict__ redw, int lane) {
+template <int W, int NG>
+__device__ __forceinline__ void mm_tile(MmCtx<W, NG> &c, int we, double *__restrict__ redw,
+                                        int lane) {
+  constexpr int kInflight = NG * W >= 32 ? 8 : 12;
 #pragma unroll 1
   for (int rc = 0; rc < kTileRows; rc += kMlChunk) {
 #pragma unroll
     for (int r = 0; r < kMlChunk; ++r) c.acc[r] = 0.0;
-    TlPipe<WE, W, NG, kMlChunk, (NG * W >= 32 ? 8 : 12)>::run(c);
+    tl_run_half<W, NG, kMlChunk, kInflight, 0>(c, we);
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -640,12 +645,12 @@ k_mm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
   const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
   const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
 
-  // my terms: slots ((blockIdx.y * 8 + wave) * NG + g) * 64 + lane of the sorted order
+  // my terms: NG * 64 consecutive slots of the sorted order (tl_slot)
   MmCtx<W, NG> c;
   int nzmax = 1;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    const uint64_t slot = (((uint64_t)blockIdx.y * kTlWaves + wave) * NG + g) * 64 + lane;
+    const uint64_t slot = tl_slot<NG>(blockIdx.y, wave, g, lane);
     const bool ok = slot < p_pad;
     const uint64_t k = ok ? sperm[slot] : 0;
     c.av[g] = ok && k < (uint64_t)p ? a[k] : 0.0;
@@ -658,7 +663,7 @@ k_mm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
     }
     nzmax = max(nzmax, tl_nnz<W2>(cw));
   }
-  const int we = max(wave_max_i32(nzmax), max(1, W - 3));
+  const int we = tl_variant<W>(wave_max_i32(nzmax));
   const bool live = (((uint64_t)blockIdx.y * kTlWaves + wave) * NG) * 64 < p_pad;
 
   int lu[PREFETCH ? kTlPre : 1];
@@ -712,17 +717,10 @@ k_mm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
     __syncthreads();  // tile staged; wave 0 has read red
     if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
     double *redw = red + wave * kTileRows;
-    if (!live) {  // whole waves beyond p_pad in the last block along p
+    if (!live)  // whole waves beyond p_pad in the last block along p
       redw[lane] = 0.0;
-    } else if (we == W) {
-      mm_tile<W>(c, redw, lane);
-    } else if (we == W - 1) {
-      mm_tile<W - 1>(c, redw, lane);
-    } else if (W >= 3 && we == W - 2) {
-      mm_tile<(W >= 3 ? W - 2 : 1)>(c, redw, lane);
-    } else {
-      mm_tile<(W >= 4 ? W - 3 : 1)>(c, redw, lane);
-    }
+    else
+      mm_tile<W, NG>(c, we, redw, lane);
   }
   __syncthreads();
   if (t0 < t1 && wave == 0) emit(t1 - 1);
