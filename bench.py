@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="rows per GPU")
-    ap.add_argument("--d", type=int, default=20)
+    ap.add_argument("--d", "--dims", dest="d", type=int, default=20,
+                    help="(--dims: torch.distributed.run swallows an abbreviated --d)")
     ap.add_argument("--p", type=int, default=4096)
     ap.add_argument("--knots", type=int, default=40)
     ap.add_argument("--backend", choices=["newton", "cg"], default="newton")
