@@ -495,6 +495,27 @@ static void build_sparse_views(obhip_terms &t, const obhip_basis &b) {
       (delta ? t.ge_dviews : t.ge_sviews)[hh] = std::move(v);
     }
   }
+  // the gradient views of all hyper-parameters as one term list
+  t.ge_sall_off.assign(nh + 1, 0);
+  for (uint64_t hh = 0; hh < nh; ++hh)
+    t.ge_sall_off[hh + 1] = t.ge_sall_off[hh] + t.ge_sidx[hh].size();
+  t.ge_sall.reset();
+  if (t.ge_sall_off[nh] > 0) {
+    auto v = std::make_unique<obhip_terms>();
+    v->p = t.ge_sall_off[nh];
+    v->d = de;
+    v->lev.resize(v->p * de);
+    v->maxlev.assign(de, 0);
+    for (uint64_t hh = 0; hh < nh; ++hh) {
+      const obhip_terms *sv = t.ge_sviews[hh].get();
+      if (!sv) continue;
+      std::copy(sv->lev.begin(), sv->lev.end(), v->lev.begin() + t.ge_sall_off[hh] * de);
+      for (uint64_t q = 0; q < de; ++q) v->maxlev[q] = std::max(v->maxlev[q], sv->maxlev[q]);
+      v->nnz_total += sv->nnz_total;
+      v->max_nnz = std::max(v->max_nnz, sv->max_nnz);
+    }
+    t.ge_sall = std::move(v);
+  }
 }
 
 obhip_terms *grad_view_sparse(obhip_terms &t, const obhip_basis &b, uint64_t h,
@@ -781,9 +802,26 @@ static int tmm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const d
   }
   OB_TRY(launch_bt_times_ge0(b, t, squared, d_a, dout.p));
   OB_TRY(d2h(out_gradhyp, dout.p, p * nh * sizeof(double)));
+  // the terms that have the hyper-parameter's dimension: one pass over the concatenated
+  // restricted views when their columns fit one LDS tile, else one pass per hyper-parameter
   std::vector<double> tmp;
+  const std::vector<uint32_t> *idx = nullptr;
+  grad_view_sparse(t, b, 0, &idx);  // builds the views
+  obhip_terms *all = t.ge_sall.get();
+  if (all && all->prepare(src.md.cap, src.md.dims_h) == 0 && all->Mu <= 296) {
+    DevBuf<double> dall;
+    OB_TRY(dall.alloc(all->p));
+    OB_TRY(launch_tmm(src, *all, d_a, dall.p, false));
+    tmp.resize(all->p);
+    OB_TRY(d2h(tmp.data(), dall.p, tmp.size() * sizeof(double)));
+    for (uint64_t h = 0; h < nh; ++h) {
+      const std::vector<uint32_t> &ix = t.ge_sidx[h];
+      const double *src_h = tmp.data() + t.ge_sall_off[h];
+      for (size_t j = 0; j < ix.size(); ++j) out_gradhyp[h * p + ix[j]] = src_h[j];
+    }
+    return 0;
+  }
   for (uint64_t h = 0; h < nh; ++h) {
-    const std::vector<uint32_t> *idx = nullptr;
     obhip_terms *v = grad_view_sparse(t, b, h, &idx);
     if (!v) continue;
     OB_TRY(launch_tmm(src, *v, d_a, dout.p, false));

@@ -186,6 +186,9 @@ struct obhip_terms {
   std::vector<std::vector<uint32_t>> ge_sidx;
   // restricted likewise, the dimension's factor replaced by the delta column (products B a)
   std::vector<std::unique_ptr<obhip_terms>> ge_dviews;
+  // all ge_sviews concatenated (one B^T a pass for every hyper-parameter), offsets per h
+  std::unique_ptr<obhip_terms> ge_sall;
+  std::vector<uint64_t> ge_sall_off;
   // device view of the model capped at maxlev, for the fused predictor
   obhip::ModelDev pred_md;
   const obhip_model *pred_model = nullptr;
