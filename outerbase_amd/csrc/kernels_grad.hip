@@ -25,11 +25,13 @@
 //                             multiplied out (k_mm on a restricted view whose pseudo-dimension
 //                             points at the delta columns): nnz(terms) products instead of
 //                             p x nhyp
-//   tmatmul / sqtmm _gradhyp  k_bt_times_u: one streaming pass over the materialised design
-//                             matrix for the terms without the hyper-parameter's dimension,
-//                             + k_tmm on views restricted to the terms that have it
-//   fallback (design matrix too large for the HBM): k_tmm on the full views, one pass per
-//   hyper-parameter
+//   tmatmul / sqtmm _gradhyp  k_tmm_ge0: the terms without the hyper-parameter's dimension, all
+//                             hyper-parameters at once (products on the fly, MFMA contraction
+//                             with the weight columns), + k_tmm_tl on the concatenated views
+//                             restricted to the terms that have it.  k_bt_times_u (a streaming
+//                             pass over the materialised design matrix) is the older form of
+//                             the dense part, kept for terms of more than 8 factors
+//   fallback: k_tmm on the full views, one pass per hyper-parameter
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "obhip_internal.h"
@@ -400,6 +402,189 @@ k_bt_times_u(const double *__restrict__ Bmat, uint64_t p_pad, const double *__re
       part[((uint64_t)blockIdx.x * kNHB + h) * p_pad + k4 + q] = acc[q][h];
 }
 
+// ---- the same dense part without the design matrix: products on the fly, MFMA contraction ------
+// D[h][k] = sum_i (a_i s_i ge[h, 0]_i) P_k(i) is a (hyper-parameters x rows) x (rows x terms)
+// product whose right factor never exists: with lane = (term t16 = l & 15, row r4 = l >> 4) a
+// lane's term product at rows 4 s + r4 IS the B operand element B[k = r4][j = t16] of
+// v_mfma_f64_16x16x4_f64, and the weight column of hyper-parameter t16 read at the same rows
+// is the A operand element A[i = t16][k = r4].  Column addresses are loop-invariant per lane
+// as in the term-per-lane kernels (the step is the immediate offset), so a (term, row) costs
+// its WE column reads, WE - 1 multiplies and 1/64 of an MFMA per 16 hyper-parameters.  The
+// weights (staged behind the tile's columns, premultiplied by a and the basescale) go through
+// the same in-order LDS queue one step ahead; every s_waitcnt counts the reads behind its
+// target exactly (ge_newer_*).  A wave holds 4 groups of 16 terms, a block 512 terms.
+typedef double ge_d4 __attribute__((ext_vector_type(4)));
+constexpr int kGeNU = 4, kGeSteps = 16, kGeInflight = 8;
+
+template <int WE, int W, int NHB>
+struct GePipe {
+  static constexpr int NU = kGeNU, TOT = kGeSteps * kGeNU;
+  static constexpr int D = (kGeInflight / WE) > 0 ? kGeInflight / WE : 1;
+  // units issued once step U has issued (the prologue issues units 0 .. D-2)
+  static constexpr int issued(int U) { return U + D < TOT ? U + D : TOT; }
+  static constexpr bool wnext(int s) { return s + 1 < kGeSteps; }  // weights of step s+1 exist
+  // LDS reads queued behind the weights of step s when step s waits for them
+  static constexpr int newer_w(int s) {
+    const int units = s == 0 ? issued(0) : issued(s * NU) - issued((s - 1) * NU);
+    const int v = units * WE + (wnext(s) ? NHB : 0);
+    return v < 15 ? v : 15;
+  }
+  // LDS reads queued behind the reads of unit U when step U waits for them
+  static constexpr int newer_u(int U) {
+    const int units = (TOT - 1 - U) < (D - 1) ? (TOT - 1 - U) : (D - 1);
+    int wr = 0;
+    for (int S = (U - D + 1 > 0 ? U - D + 1 : 0); S <= U; ++S)
+      if (S % NU == 0 && wnext(S / NU)) wr += NHB;
+    const int v = units * WE + wr;
+    return v < 15 ? v : 15;
+  }
+
+  template <int U, typename C>
+  static __device__ __forceinline__ void issue(C &c, double (&buf)[12]) {
+    constexpr int st = U / NU, unit = U % NU, s = (U % D) * WE;
+#pragma unroll
+    for (int j = 0; j < WE; ++j) buf[s + j] = tl_rd<st * 32>(c.ad[unit][W - WE + j]);
+  }
+  template <int S, typename C>
+  static __device__ __forceinline__ void issue_w(C &c, double (&w)[12]) {
+#pragma unroll
+    for (int hb = 0; hb < NHB; ++hb) w[(S % 2) * NHB + hb] = tl_rd<S * 32>(c.aw[hb]);
+  }
+  template <int U, typename C>
+  static __device__ __forceinline__ void steps(C &c, double (&buf)[12], double (&w)[12]) {
+    if constexpr (U < TOT) {
+      constexpr int st = U / NU, unit = U % NU, s = (U % D) * WE;
+      if constexpr (U + D - 1 < TOT) issue<U + D - 1>(c, buf);
+      if constexpr (unit == 0) {
+        if constexpr (wnext(st)) issue_w<st + 1>(c, w);
+        tl_waitn<newer_w(st), NHB, (st % 2) * NHB>(w);
+      }
+      tl_waitn<newer_u(U), WE, s>(buf);
+      double v = buf[s];
+#pragma unroll
+      for (int j = 1; j < WE; ++j) v *= buf[s + j];
+#pragma unroll
+      for (int hb = 0; hb < NHB; ++hb)
+        c.acc[unit][hb] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[(st % 2) * NHB + hb], v,
+                                                               c.acc[unit][hb], 0, 0, 0);
+      steps<U + 1>(c, buf, w);
+    }
+  }
+  template <int U, typename C>
+  static __device__ __forceinline__ void prologue(C &c, double (&buf)[12]) {
+    if constexpr (U < D - 1 && U < TOT) {
+      issue<U>(c, buf);
+      prologue<U + 1>(c, buf);
+    }
+  }
+  template <typename C>
+  static __device__ __forceinline__ void run(C &c) {
+    double buf[12], w[12];
+    issue_w<0>(c, w);
+    prologue<0>(c, buf);
+    steps<0>(c, buf, w);
+  }
+};
+
+template <int W, int NHB>
+struct GeCtx {
+  uint32_t ad[kGeNU][W];
+  uint32_t aw[NHB];
+  ge_d4 acc[kGeNU][NHB];
+};
+
+template <int W, int NHB>
+__device__ __forceinline__ void ge_tile(GeCtx<W, NHB> &c, int we) {
+  if (we == W) {
+    GePipe<W, W, NHB>::run(c);
+  } else if (we == W - 1) {
+    GePipe<W - 1, W, NHB>::run(c);
+  } else if (W >= 3 && we == W - 2) {
+    GePipe<(W >= 3 ? W - 2 : 1), W, NHB>::run(c);
+  } else {
+    GePipe<(W >= 4 ? W - 3 : 1), W, NHB>::run(c);
+  }
+}
+
+template <int W2, int NHB>
+__global__ void __launch_bounds__(kTlThreads, 4)
+k_tmm_ge0(const double *__restrict__ bm, const double *__restrict__ scale,
+          const uint32_t *__restrict__ ucol, int Mu, uint64_t Mtot,
+          const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm,
+          const int *__restrict__ ge0abs, int nhyp, int h0, const double *__restrict__ a, uint64_t n,
+          uint64_t ntiles, uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ part) {
+  extern __shared__ double lds[];
+  constexpr int W = 2 * W2, HS = 16 * NHB;
+  const int lane = threadIdx.x & 63, t16 = lane & 15, r4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+
+  // my terms: slots (blockIdx.y * 8 + wave) * 64 + g * 16 + t16 of the sorted order
+  GeCtx<W, NHB> c;
+  int nzmax = 1;
+#pragma unroll
+  for (int g = 0; g < kGeNU; ++g) {
+    const uint64_t slot = ((uint64_t)blockIdx.y * kTlWaves + wave) * 64 + g * 16 + t16;
+    const bool ok = slot < p_pad;
+    const uint64_t k = ok ? sperm[slot] : 0;
+    uint32_t cw[W2];
+#pragma unroll
+    for (int w = 0; w < W2; ++w) {
+      cw[w] = ok ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+      c.ad[g][2 * w] = (cw[w] & 0xffffu) * (kTlPitch * 8) + r4 * 8;
+      c.ad[g][2 * w + 1] = (cw[w] >> 16) * (kTlPitch * 8) + r4 * 8;
+    }
+    nzmax = max(nzmax, tl_nnz<W2>(cw));
+#pragma unroll
+    for (int hb = 0; hb < NHB; ++hb) c.acc[g][hb] = ge_d4{0.0, 0.0, 0.0, 0.0};
+  }
+#pragma unroll
+  for (int hb = 0; hb < NHB; ++hb) c.aw[hb] = (uint32_t)(Mu + hb * 16 + t16) * (kTlPitch * 8) + r4 * 8;
+  const int we = tl_variant<W>(wave_max_i32(nzmax));
+  const bool live = ((uint64_t)blockIdx.y * kTlWaves + wave) * 64 < p_pad;
+
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    __syncthreads();  // every wave is done with the previous tile
+    {
+      const double *src = bm + tile * Mtot * kTileRows + lane;
+      for (int u = wave; u < Mu; u += kTlWaves) lds[u * kTlPitch + lane] = src[(size_t)ucol[u] * kTileRows];
+      const uint64_t row = tile * kTileRows + lane;
+      const double wr = row < n ? a[row] * scale[row] : 0.0;
+      for (int h = wave; h < HS; h += kTlWaves) {
+        const int col = h0 + h < nhyp ? ge0abs[h0 + h] : -1;
+        lds[(Mu + h) * kTlPitch + lane] = col >= 0 ? wr * src[(size_t)col * kTileRows] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (live) ge_tile<W, NHB>(c, we);
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: column (term) = lane & 15, row (hyper-parameter) =
+  // (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int g = 0; g < kGeNU; ++g) {
+    const uint64_t slot = ((uint64_t)blockIdx.y * kTlWaves + wave) * 64 + g * 16 + t16;
+    if (slot >= p_pad) continue;
+    const uint64_t k = sperm[slot];
+#pragma unroll
+    for (int hb = 0; hb < NHB; ++hb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        part[((uint64_t)blockIdx.x * HS + hb * 16 + r4 + 4 * v) * p_pad + k] = c.acc[g][hb][v];
+  }
+}
+
+// D[h0 + h][k] = sum of the row-split partials laid out [split][hs][p_pad]
+__global__ void k_ge0_reduce(const double *__restrict__ part, int nsplit, int hs, uint64_t p_pad,
+                             int p, int nh, double *__restrict__ out /* [nh][p] */) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y;
+  if (k >= (uint64_t)p || h >= nh) return;
+  double s = 0.0;
+  for (int r = 0; r < nsplit; ++r) s += part[((uint64_t)r * hs + h) * p_pad + k];
+  out[(uint64_t)h * p + k] = s;
+}
+
 // D[h0 + h][k] = sum of the row-split partials
 __global__ void k_btu_reduce(const double *__restrict__ part, int nsplit, uint64_t p_pad, int p,
                              int nh, double *__restrict__ out /* [nh][p] */) {
@@ -412,6 +597,70 @@ __global__ void k_btu_reduce(const double *__restrict__ part, int nsplit, uint64
 }
 
 }  // namespace
+
+namespace {
+template <int W2, int NHB>
+int run_tmm_ge0(const obhip_basis &src, obhip_terms &t, const int *d_c0, int nhyp, int h0,
+                const double *d_a, dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
+  const size_t lds = (t.Mu + 16 * NHB) * kTlPitch * sizeof(double);
+  if (lds > 64 * 1024)
+    OB_HIP(hipFuncSetAttribute((const void *)k_tmm_ge0<W2, NHB>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_tmm_ge0<W2, NHB>), grid, dim3(kTlThreads), lds, cur_stream(), src.bm.p,
+                     src.scale.p, t.ucol.p, (int)t.Mu, src.md.Mc, (const uint32_t *)t.cols.p,
+                     t.sperm.p, d_c0, nhyp, h0, d_a, src.n, ntiles, tps, t.p_pad, part);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+// the dense part without the design matrix (k_tmm_ge0); t prepared for b
+bool tmm_ge0_supports(const obhip_terms &t) {
+  const uint64_t w2 = t.W / 2;
+  return w2 >= 1 && w2 <= 4 && (t.Mu + 32) * kTlPitch * sizeof(double) <= 156 * 1024;
+}
+
+// d_out: p x nhyp column-major (device) = sum_i a_i ge[h, 0]_i B_ik (squared: the squared stores)
+int launch_tmm_ge0(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a, double *d_out) {
+  obhip_gradbasis &g = *b.grad;
+  const obhip_basis &src = squared ? *g.gbsq : *g.gb;
+  const int nhyp = (int)b.model->nhyp();
+  std::vector<int> c0(nhyp);
+  for (int h = 0; h < nhyp; ++h) c0[h] = g.hyps_h[h].gecol;  // absolute column in the combined array
+  DevBuf<int> dc0;
+  OB_TRY(dc0.upload(c0.data(), c0.size()));
+  const uint64_t ntiles = b.n_pad / kTileRows;
+  const uint64_t pblocks = (t.p_pad + 511) / 512;
+  int ncu = 256;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b.device) != hipSuccess || ncu <= 0)
+    ncu = 256;
+  uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)ncu * 2 / pblocks);
+  nsplit = std::min(nsplit, ntiles);
+  const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  const dim3 grid((unsigned)nsplit, (unsigned)pblocks);
+  ProfScope ps(squared ? "sqtmm_gradhyp_dense" : "tmm_gradhyp_dense");
+  // 16 hyper-parameters per pass: with two 16-blocks per pass (NHB = 2) the 64 accumulator
+  // registers of a wave no longer fit beside the pipeline and the compiler spills them in the
+  // inner loop (measured 8.4 ms against 2 x 1.7 ms at C3)
+  for (int h0 = 0; h0 < nhyp; h0 += 16) {
+    const int nh = std::min(16, nhyp - h0), hs = 16;
+    double *part = nullptr;
+    OB_TRY(b.workspace(nsplit * hs * t.p_pad * sizeof(double), (void **)&part));
+    switch (t.W / 2) {
+      case 1: OB_TRY((run_tmm_ge0<1, 1>(src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      case 2: OB_TRY((run_tmm_ge0<2, 1>(src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      case 3: OB_TRY((run_tmm_ge0<3, 1>(src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      default: OB_TRY((run_tmm_ge0<4, 1>(src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+    }
+    hipLaunchKernelGGL(k_ge0_reduce, dim3((unsigned)((t.p + 255) / 256), (unsigned)nh), dim3(256), 0,
+                       cur_stream(), part, (int)nsplit, hs, t.p_pad, (int)t.p, nh,
+                       d_out + (uint64_t)h0 * t.p);
+    OB_HIP(hipGetLastError());
+  }
+  OB_HIP(hipStreamSynchronize(cur_stream()));  // dc0 is a local
+  return 0;
+}
 
 // d_out: p x nhyp column-major (device) = sum_i a_i ge[h, 0]_i B_ik (SQ: squared stores)
 int launch_bt_times_ge0(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a,
@@ -793,14 +1042,19 @@ static int tmm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const d
   DevBuf<double> dout;
   OB_TRY(dout.alloc(p * nh));
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
-  if (!gram_panel_supports(b, t)) {
+  static const bool stream_b = getenv("OBHIP_GRAD_STREAM_B") != nullptr;  // the older dense pass
+  const bool onfly = tmm_ge0_supports(t) && !stream_b;
+  if (!onfly && !gram_panel_supports(b, t)) {
     for (uint64_t h = 0; h < nh; ++h) {
       OB_TRY(launch_tmm(src, *grad_view(t, b, h), d_a, dout.p, false));
       OB_TRY(d2h(out_gradhyp + h * p, dout.p, p * sizeof(double)));
     }
     return 0;
   }
-  OB_TRY(launch_bt_times_ge0(b, t, squared, d_a, dout.p));
+  if (onfly)
+    OB_TRY(launch_tmm_ge0(b, t, squared, d_a, dout.p));
+  else
+    OB_TRY(launch_bt_times_ge0(b, t, squared, d_a, dout.p));
   OB_TRY(d2h(out_gradhyp, dout.p, p * nh * sizeof(double)));
   // the terms that have the hyper-parameter's dimension: one pass over the concatenated
   // restricted views when their columns fit one LDS tile, else one pass per hyper-parameter
