@@ -220,29 +220,6 @@ __device__ __forceinline__ double tl_rd(uint32_t addr) {
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
-template <int KEEP, int W>
-__device__ __forceinline__ void tl_wait(double (&b)[W]) {
-  static_assert(W == 2 || W == 4 || W == 6 || W == 8, "");
-  if constexpr (W == 2)
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(KEEP) : "memory");
-  else if constexpr (W == 4)
-    asm volatile("s_waitcnt lgkmcnt(%4)"
-                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-                 : "n"(KEEP)
-                 : "memory");
-  else if constexpr (W == 6)
-    asm volatile("s_waitcnt lgkmcnt(%6)"
-                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5])
-                 : "n"(KEEP)
-                 : "memory");
-  else
-    asm volatile("s_waitcnt lgkmcnt(%8)"
-                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]),
-                   "+v"(b[6]), "+v"(b[7])
-                 : "n"(KEEP)
-                 : "memory");
-}
-
 // ---- the read pipeline of the term-per-lane kernels ---------------------------------------
 // s_waitcnt lgkmcnt(KEEP) tied to the N registers b[S .. S+N) it releases
 template <int KEEP, int N, int S>

@@ -421,63 +421,32 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
 // needed; products exactly as in k_tmm_tl, the row's basescale is the last factor.
 template <int W, int NPAIR>
 struct MtCtx {
-  static constexpr int D = (12 / W) > 0 ? 12 / W : 1;  // units in flight
-  static constexpr int NU = NPAIR * 2;                 // units (terms of this lane) per row
-  static constexpr int TOT = kTlChunk * NU;
-  uint32_t ad[NPAIR][2][W];
-  uint32_t koff[NPAIR];  // first of the lane's two terms in pair-group q
-  double buf[D][W];
-  double sc;             // basescale of row = lane
-  double sr;             // basescale of the current row, wave-uniform
+  uint32_t ad[NPAIR * 2][W];  // unit 2 q + i = term i of the lane's pair in pair-group q
+  uint32_t koff[NPAIR];       // first of the lane's two terms in pair-group q
+  double sc;                  // basescale of row = lane
+  double sr;                  // basescale of the current row, wave-uniform
   double v0;
-  double *rowp;          // B + current row * p_pad (uniform)
+  double *rowp;               // B + current row * p_pad (uniform)
   uint64_t p_pad;
   int rc;
-};
-
-template <int U, int W, int NPAIR>
-__device__ __forceinline__ void mt_issue(MtCtx<W, NPAIR> &c) {
-  using C = MtCtx<W, NPAIR>;
-  constexpr int rr = U / C::NU, unit = U % C::NU, q = unit / 2, i = unit % 2;
-#pragma unroll
-  for (int j = 0; j < W; ++j) c.buf[U % C::D][j] = tl_rd<rr * 8>(c.ad[q][i][j]);
-}
-
-template <int U, int W, int NPAIR>
-__device__ __forceinline__ void mt_steps(MtCtx<W, NPAIR> &c) {
-  using C = MtCtx<W, NPAIR>;
-  if constexpr (U < C::TOT) {
-    constexpr int rr = U / C::NU, unit = U % C::NU, q = unit / 2, i = unit % 2;
-    if constexpr (U + C::D - 1 < C::TOT) mt_issue<U + C::D - 1>(c);
-    if constexpr (unit == 0) {
-      c.sr = readlane_f64(c.sc, c.rc + rr);
-      if constexpr (rr > 0) c.rowp += c.p_pad;
-    }
-    constexpr int newer = (C::TOT - 1 - U) < (C::D - 1) ? (C::TOT - 1 - U) : (C::D - 1);
-    tl_wait<newer * W>(c.buf[U % C::D]);
-    double v = c.buf[U % C::D][0];
-#pragma unroll
-    for (int j = 1; j < W; ++j) v *= c.buf[U % C::D][j];
-    v *= c.sr;
-    if constexpr (i == 0) {
-      c.v0 = v;
+  template <int RR>
+  __device__ __forceinline__ void row() {
+    sr = readlane_f64(sc, rc + RR);
+    if constexpr (RR > 0) rowp += p_pad;
+  }
+  template <int RR, int UNIT>
+  __device__ __forceinline__ void use(double v) {
+    v *= sr;
+    if constexpr (UNIT % 2 == 0) {
+      v0 = v;
     } else {
       double2 o;
-      o.x = c.v0;
+      o.x = v0;
       o.y = v;
-      *(double2 *)(c.rowp + c.koff[q]) = o;
+      *(double2 *)(rowp + koff[UNIT / 2]) = o;
     }
-    mt_steps<U + 1>(c);
   }
-}
-
-template <int U, int W, int NPAIR>
-__device__ __forceinline__ void mt_prologue(MtCtx<W, NPAIR> &c) {
-  if constexpr (U < MtCtx<W, NPAIR>::D - 1) {
-    mt_issue<U>(c);
-    mt_prologue<U + 1>(c);
-  }
-}
+};
 
 template <int W2, int NPAIR, bool PREFETCH>
 __global__ void __launch_bounds__(kTlThreads, 4)
@@ -506,8 +475,8 @@ k_materialize_tl(const double *__restrict__ bm, const double *__restrict__ scale
 #pragma unroll
       for (int w = 0; w < W2; ++w) {
         const uint32_t cw = k < p_pad ? colsw[(k + i) * W2 + w] : 0u;
-        c.ad[q][i][2 * w] = (cw & 0xffffu) * (kTlPitch * 8);
-        c.ad[q][i][2 * w + 1] = (cw >> 16) * (kTlPitch * 8);
+        c.ad[2 * q + i][2 * w] = (cw & 0xffffu) * (kTlPitch * 8);
+        c.ad[2 * q + i][2 * w + 1] = (cw >> 16) * (kTlPitch * 8);
       }
   }
   // pair-groups beyond p_pad exist only in the last block along p and only for whole waves
@@ -555,17 +524,14 @@ k_materialize_tl(const double *__restrict__ bm, const double *__restrict__ scale
     for (int rc = 0; rc < kTileRows; rc += kTlChunk) {
       c.rc = rc;
       c.rowp = out + (tile * kTileRows + rc) * p_pad;
-      mt_prologue<0>(c);
-      mt_steps<0>(c);
+      TlPipe<W, W, NPAIR * 2, kTlChunk>::run(c);
 #pragma unroll
-      for (int q = 0; q < NPAIR; ++q)
+      for (int u = 0; u < NPAIR * 2; ++u)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < W; ++j) {
-            c.ad[q][i][j] += (rc + kTlChunk < kTileRows) ? kTlChunk * 8 : -(kTileRows - kTlChunk) * 8;
-            asm volatile("" : "+v"(c.ad[q][i][j]));
-          }
+        for (int j = 0; j < W; ++j) {
+          c.ad[u][j] += (rc + kTlChunk < kTileRows) ? kTlChunk * 8 : -(kTileRows - kTlChunk) * 8;
+          asm volatile("" : "+v"(c.ad[u][j]));
+        }
     }
   }
 }
