@@ -68,6 +68,9 @@ __device__ __forceinline__ void dim_chunk(const DimDesc &D, const double *__rest
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = 0.0;
   const double *rp = rot + D.rotoff + c0;
+  // unrolled so that the scalar loads of several knots are in flight together: one knot is
+  // only ~17 VALU instructions, far less than a scalar-load round trip
+#pragma unroll 4
   for (int j = 0; j < D.m; ++j) {
     double kv = kernel_value<KIND>(ka[D.koff + j], kb[D.koff + j], kc[D.koff + j], a0, a1, a2);
     const double *r = rp + (size_t)j * D.ncolp;
