@@ -383,9 +383,15 @@ k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__rest
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     double zk = lane < jb ? z[j0 + lane] : 0.0;
-    // L_jj^T theta = z, from the last unknown to the first
+    // L_jj^T theta = z, from the last unknown to the first.  The 64 divisions happen up
+    // front in parallel (one Newton-corrected reciprocal per lane), so that the serial chain
+    // per unknown is readlane - multiply - fma.
+    const double dl = Ld[lane * LDP + lane];
+    double rinv = 1.0 / dl;
+    rinv = fma(fma(-dl, rinv, 1.0), rinv, rinv);
+#pragma unroll 8
     for (int c = NB - 1; c >= 0; --c) {
-      const double tc = readlane_d(zk, c) / Ld[c * LDP + c];
+      const double tc = readlane_d(zk, c) * readlane_d(rinv, c);
       if (lane == c) zk = tc;
       if (lane < c) zk = fma(-Ld[c * LDP + lane], tc, zk);
     }
@@ -396,6 +402,7 @@ k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__rest
   const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (c < j0) {
     double s = z[c];
+#pragma unroll 8
     for (int k = 0; k < jb; ++k) s = fma(-L[(size_t)(j0 + k) * p + c], th[k], s);
     z[c] = s;
   }
