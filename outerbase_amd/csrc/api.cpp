@@ -201,8 +201,15 @@ int obhip_basis_sqtmm(const obhip_basis *b, const obhip_terms *t, const double *
 
 int obhip_basis_sqcolsums(const obhip_basis *b, const obhip_terms *t, double *out) {
   if (!b || !t || !out) return fail(OBHIP_ERR_INVALID, "sqcolsums: null argument");
-  std::vector<double> ones(b->n, 1.0);  // modandbase.cpp:864-866
-  return mm_host(b, t, ones.data(), 1, out, true, true);
+  OB_TRY(check_compat(b->model, t));
+  // tmm of the squared store with the all-ones vector (modandbase.cpp:864-866), the ones
+  // filled on the device
+  DevBuf<double> dones, dout;
+  OB_TRY(dones.alloc(b->n));
+  OB_TRY(dout.alloc(t->p));
+  OB_TRY(launch_fill(dones.p, b->n, 1.0));
+  OB_TRY(launch_tmm(*b, *const_cast<obhip_terms *>(t), dones.p, dout.p, true));
+  return d2h(out, dout.p, t->p * sizeof(double));
 }
 
 int obhip_basis_residvar(const obhip_basis *b, const obhip_terms *t, const obhip_model *m,

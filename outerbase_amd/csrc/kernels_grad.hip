@@ -977,16 +977,23 @@ static int tmm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const d
 
 // products on the squared stores: ob$sqmm_gradhyp / ob$sqtmm_gradhyp
 // (modandbase.cpp:798-809, 845-856)
+// a == nullptr with transposed: the all-ones vector, filled on the device (sqcolsums_gradhyp)
 static int sq_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const double *a,
                       double *out_gradhyp, bool transposed) {
   OB_TRY(check_grad_args(bc, tc));
-  if (!a || !out_gradhyp) return fail(OBHIP_ERR_INVALID, "sq*_gradhyp: null argument");
+  if ((!a && !transposed) || !out_gradhyp)
+    return fail(OBHIP_ERR_INVALID, "sq*_gradhyp: null argument");
   obhip_basis &b = *const_cast<obhip_basis *>(bc);
   obhip_terms &t = *const_cast<obhip_terms *>(tc);
   OB_TRY(ensure_gradbasis_sq(b));
   const uint64_t nin = transposed ? b.n : t.p, nout = transposed ? t.p : b.n;
   DevBuf<double> da, dout;
-  OB_TRY(da.upload(a, nin));
+  if (a) {
+    OB_TRY(da.upload(a, nin));
+  } else {
+    OB_TRY(da.alloc(nin));
+    OB_TRY(launch_fill(da.p, nin, 1.0));
+  }
   OB_TRY(dout.alloc(nout));
   if (transposed) return tmm_gradhyp_all(b, t, true, da.p, out_gradhyp);
   return mm_gradhyp_all(b, t, true, a, da.p, dout.p, out_gradhyp);
@@ -1004,8 +1011,7 @@ int obhip_basis_sqtmm_gradhyp(const obhip_basis *b, const obhip_terms *t, const 
 
 int obhip_basis_sqcolsums_gradhyp(const obhip_basis *b, const obhip_terms *t, double *out_gradhyp) {
   if (!b) return fail(OBHIP_ERR_INVALID, "sqcolsums_gradhyp: null argument");
-  std::vector<double> ones(b->n, 1.0);  // modandbase.cpp:875-879
-  return sq_gradhyp(b, t, ones.data(), out_gradhyp, true);
+  return sq_gradhyp(b, t, nullptr, out_gradhyp, true);  // ones: modandbase.cpp:875-879
 }
 
 int obhip_basis_residvar_gradhyp(const obhip_basis *b, const obhip_terms *t, const obhip_model *m,
