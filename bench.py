@@ -4,21 +4,30 @@
 One "step" = one full pass of the hot path over one synthetic batch that is
 already resident in HBM (BASELINE.md sections 2-3):
 
-  fit      standardise y (R/fitting.R:55-57) -> basis build (outerbase::build)
-           -> Gram B^T B on the FP64 matrix cores + B^T y -> [all-reduce over
-           ranks] -> H = e^{-2 sigma} G + prior, Cholesky, two triangular solves
+  fit      basis build (outerbase::build) -> Gram B^T B on the FP64 matrix cores,
+           B^T y, B^T 1, (sum y, sum y^2) -> [ONE exchange buffer summed over ranks:
+           packed upper triangle of G + the two p-vectors + 3 scalars] -> right-hand side
+           of the problem with y standardised over all rows (R/fitting.R:55-57) ->
+           H = e^{-2 sigma} G + prior, Cholesky, two triangular solves
            (lpdf::optnewton, "back end A")
-  predict  fused basis build at n fresh rows + B theta (predictor$update/$mean)
+  predict  fused basis build at the rank's n fresh rows + B theta (predictor$update/$mean)
 
-Default workload: BASELINE.json configs[2] = d=20, n=1e6, p=4096, Matern-5/2 in
-every dimension, 40 knots per dimension, rows sharded over ranks (weak
-scaling: every rank owns n rows).  Prints ONE JSON line on rank 0.
+Default workload: BASELINE.json configs[2] = d=20, n=1e6, p=4096, Matern-5/2 in every
+dimension, 40 knots per dimension.  With --gpus N the SAME n = 1e6 rows are sharded over
+the N ranks ("scaling": "strong", what the metric "d=20 n=1e6 p=4096 at 1/2/4/8 MI355X"
+says); the line also carries `config3`, BASELINE.json configs[3]'s shape (1.25e6 rows per
+GPU, weak).  `python bench.py --gpus N` launches its own N ranks (one process per GPU,
+torch.distributed.run) when it is not already running under a launcher.  Prints ONE JSON
+line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
 import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,14 +36,17 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix (dense); see DESIGN.md
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW"
+LDS_PEAK_GBS = 256 * 256 * 2.4  # 256 B/clk/CU (ds_read_b64) x 256 CUs x 2.4 GHz = 157 TB/s
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="rows per GPU")
+    ap.add_argument("--rows", dest="n", type=int, default=1_000_000,
+                    help="rows of the whole job (sharded over the ranks); with --weak: rows per GPU")
+    ap.add_argument("--weak", action="store_true", help="--rows is per GPU (weak scaling)")
     ap.add_argument("--d", "--dims", dest="d", type=int, default=20,
                     help="(--dims: torch.distributed.run swallows an abbreviated --d)")
     ap.add_argument("--p", type=int, default=4096)
@@ -42,11 +54,28 @@ def parse():
     ap.add_argument("--backend", choices=["newton", "cg"], default="newton")
     ap.add_argument("--kinds", default="mat25", help="comma list cycled over dimensions")
     ap.add_argument("--gram-backend", type=int, default=0,
-                    help="0 auto, 1 MFMA 16x16x4, 2 vector pipe, 3 fused MFMA 4x4x4, 4 materialised-B MFMA 4x4x4")
+                    help="0 auto, 1 MFMA 16x16x4, 3 fused MFMA 4x4x4, 4 materialised-B MFMA 4x4x4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-backend", action="store_true")
+    ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=200000)
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: start N fresh ranks (one process per
+    GPU) BEFORE this process makes any GPU call, relay their output, return their exit code.
+    Nothing is exec'ed: the ranks are children of this process."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def check_against_oracle(hp, rows=2000):
@@ -55,7 +84,6 @@ def check_against_oracle(hp, rows=2000):
     oracle's basis build + B theta with the device's theta; (b) Newton
     stationarity of the device theta, H theta = e^{-2 sigma} B^T y, evaluated with
     the matrix-free device kernels (independent of the Gram/Cholesky kernels)."""
-    import ctypes as C
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -73,6 +101,10 @@ def check_against_oracle(hp, rows=2000):
     got = hp.mean[:rows].cpu().numpy()
     out = {"rows": rows,
            "predict_max_rel_err": float(np.max(np.abs(got - want)) / np.max(np.abs(want)))}
+    # the synthetic rows themselves (first rows of the shard) against the oracle's generator
+    xo, yo = O.synth_xy(hp.seed_train, hp.row0, min(rows, 256), hp.kinds)
+    out["synthetic_rows_max_abs_diff"] = float(
+        np.max(np.abs(hp.x[:, :len(yo)].cpu().numpy().T - xo)))
     if hp.backend == "newton" and hp.world == 1:
         e2 = math.exp(-2 * hp.sigma)
         tmp = torch.empty(hp.n, dtype=torch.float64, device="cuda")
@@ -87,13 +119,16 @@ def check_against_oracle(hp, rows=2000):
     return out
 
 
-def cpu_baseline(hp, ns, threads=16):
-    """CPU restatement of the reference path timed on the host cores on a bounded row
-    sample of the same workload (test infrastructure, oracle/): the reference's own
-    loops (outerbase::build, getm_, prodmm_) in C++/OpenMP with the reference's chunk
-    schedule (oracle/ob_cpu.cpp), BLAS/LAPACK (NumPy) for basismat.t()*basismat and
-    solve() exactly where the reference hands over to Armadillo.  Row-proportional
-    work is scaled to n, the p x p solve is counted once."""
+def cpu_baseline(hp, ns):
+    """CPU restatement of the reference path timed on the host cores (test infrastructure,
+    oracle/): the reference's own loops (outerbase::build, getm_, prodmm_, tprodmm_) in
+    C++/OpenMP with the reference's chunk schedule and thread count rule
+    (omp_get_num_procs(), src/modandbase.cpp:464) in oracle/ob_cpu.cpp; BLAS/LAPACK (NumPy)
+    for basismat.t()*basismat and solve() exactly where the reference hands over to
+    Armadillo.  Gram path: a bounded row sample (the reference's loglik_std would need the
+    32.8 GB design matrix at n = 1e6), row-proportional work scaled to n, the p x p solve
+    counted once.  PCG path (what obfit runs): basis build and one B a + one B^T r pass
+    timed at the FULL n, times the passes lpdf::optcg makes."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ob_oracle as O
@@ -102,14 +137,15 @@ def cpu_baseline(hp, ns, threads=16):
         from threadpoolctl import threadpool_limits
     except Exception:
         threadpool_limits = None
-    threads = min(threads, os.cpu_count() or 1)
+    threads = os.cpu_count() or 1
     ns = min(ns, hp.n)
     use_cpp = ob_cpu.available()
 
+    om = O.OuterMod()
+    om.setcovfs(hp.kinds)
+    om.setknot(O.bench_knots(hp.kinds, hp.m))
+
     def run():
-        om = O.OuterMod()
-        om.setcovfs(hp.kinds)
-        om.setknot(O.bench_knots(hp.kinds, hp.m))
         x, y = O.synth_xy(42, 0, ns, hp.kinds)
         xnew, _ = O.synth_xy(43, 0, ns, hp.kinds)
         y = (y - y.mean()) / y.std(ddof=1)
@@ -143,54 +179,143 @@ def cpu_baseline(hp, ns, threads=16):
         else:
             O.predict_mean(om, hp.terms, theta, xnew)
         t["predict"] = time.perf_counter() - t0
-        if use_cpp:   # one B a and one B^T r pass: what a PCG iteration is made of (fit.cpp:71-85)
-            r = y - B @ theta
-            t0 = time.perf_counter()
-            ob_cpu.mm(om, hp.terms, bm, bs, theta, threads)
-            ob_cpu.tmm(om, hp.terms, bm, bs, r, threads)
-            t["mm_tmm"] = time.perf_counter() - t0
-        return t
+        return t, theta
 
     if threadpool_limits is not None:
         with threadpool_limits(limits=threads):
-            t = run()
+            t, theta = run()
     else:
-        t = run()
+        t, theta = run()
     per_row = (t["build"] + t["getmat"] + t["gram"] + t["predict"]) / ns
     full = per_row * hp.n + t["solve"]
     impl = "oracle/ob_cpu.cpp (C++/OpenMP, reference chunk schedule)" if use_cpp \
         else "oracle/ob_oracle.py (NumPy)"
     pcg = None
-    if "mm_tmm" in t:
-        # the matrix-free path obfit itself takes -- build, then per
-        # iteration update() + hessmult() = two B a and two B^T r passes (fit.cpp:71-85), at
-        # the iteration count the device PCG needed, then predict
+    if use_cpp:
+        # the matrix-free path obfit itself takes, at the full n (basemat
+        # 6.4 GB): build, then per iteration update() + hessmult() = two B a and two B^T r
+        # passes (fit.cpp:71-85), at the iteration count the device PCG needed, then predict
+        nfull = hp.n
+        x, _ = O.synth_xy(42, 0, nfull, hp.kinds)
+        t0 = time.perf_counter()
+        bm, bs = ob_cpu.build(om, x, threads)
+        tb = time.perf_counter() - t0
+        r = np.ones(nfull)
+        t0 = time.perf_counter()
+        ob_cpu.mm(om, hp.terms, bm, bs, theta, threads)
+        ob_cpu.tmm(om, hp.terms, bm, bs, r, threads)
+        tp = time.perf_counter() - t0
+        del bm, bs, x
         iters = getattr(hp, "cg_iters", None) or 22
-        full_pcg = (t["build"] + t["predict"] + 2 * (iters + 1) * t["mm_tmm"]) / ns * hp.n
-        pcg = {"value": hp.n / full_pcg, "unit": "points/s", "iterations": iters,
-               "mm_plus_tmm_s_on_sample": t["mm_tmm"]}
-    return {"value": hp.n / full, "unit": "points/s", "cores": threads, "kind": "port", "pcg_path": pcg,
-            "sample": "%s + NumPy BLAS/LAPACK for B^T B and solve, %d threads, %d rows of the "
-                      "same workload: build %.2fs getmat %.2fs gram %.2fs solve %.2fs predict "
-                      "%.2fs; row work scaled to n=%d, solve counted once"
+        full_pcg = 2 * tb + (2 * (iters + 1) + 1) * tp   # fit build + predict build; +1 pass: predict
+        pcg = {"value": nfull / full_pcg, "unit": "points/s", "iterations": iters, "rows": nfull,
+               "build_s": tb, "mm_plus_tmm_s": tp,
+               "what": "build and one B a + B^T r pass timed at the full n on %d threads; "
+                       "2 (iters + 1) such passes per fit as lpdf::optcg makes them" % threads}
+    return {"value": hp.n / full, "unit": "points/s", "cores": threads, "kind": "port",
+            "host_cpu_count": os.cpu_count(), "pcg_path": pcg,
+            "sample": "%s + NumPy BLAS/LAPACK for B^T B and solve, %d threads (= os.cpu_count()), "
+                      "%d rows of the same workload: build %.2fs getmat %.2fs gram %.2fs solve %.2fs "
+                      "predict %.2fs; row work scaled to n=%d, solve counted once"
                       % (impl, threads, ns, t["build"], t["getmat"], t["gram"], t["solve"],
                          t["predict"], hp.n)}
 
 
-def which_config(d, n, p):
-    """Name of the BASELINE.json configuration these sizes are (rows per GPU)."""
-    known = {(10, 100000, 1024): "BASELINE.json configs[1]", (20, 1000000, 1024 * 4): "BASELINE.json configs[2]",
-             (20, 1250000, 4096): "BASELINE.json configs[3] (one of 8 row shards)",
-             (40, 125000, 16384): "BASELINE.json configs[4] (one of 8 row shards)"}
-    return known.get((d, n, p), "custom sizes")
+def which_config(d, n_total, rows_per_gpu, p):
+    """Name of the BASELINE.json configuration these sizes are."""
+    if (d, n_total, p) == (10, 100000, 1024):
+        return "BASELINE.json configs[1]"
+    if (d, n_total, p) == (20, 1000000, 4096):
+        return "BASELINE.json configs[2]"
+    if (d, rows_per_gpu, p) == (20, 1250000, 4096):
+        return "BASELINE.json configs[3] (1.25e6 rows per GPU)"
+    if (d, p) == (40, 16384):
+        return "BASELINE.json configs[4] shape (d=40, p=16384, mixed covariances)"
+    return "custom sizes"
 
 
-def n_rows_all(hp):
-    return hp.n * hp.world
+def timed_steps(hp, steps, warmup, sync, torch, dist, world):
+    """W untimed steps, then K timed steps between barrier + synchronize; -> (elapsed of the
+    K steps, max over ranks; per-step times from events on the launch stream)."""
+    for _ in range(warmup):
+        hp.step()
+    sync()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(steps):
+        hp.step()
+        evs[i + 1].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    return elapsed, per_step
+
+
+def kernel_profile(hp, _lib, torch, nprof=2):
+    """per-kernel hipEvent timing on the launch stream (obhip_profile_*), untimed region"""
+    _lib.call("obhip_profile_reset")
+    _lib.call("obhip_profile_enable", 1)
+    for _ in range(nprof):
+        hp.step()
+    torch.cuda.synchronize()
+    prof = {}
+    for name in ["build_basis", "materialize_B", "gram", "gram_reduce", "tmm", "mm", "sqtmm",
+                 "exchange", "form_hessian", "cholesky", "backsolve", "predict"]:
+        cnt, ms = C.c_uint64(0), C.c_double(0)
+        _lib.call("obhip_profile_get", name.encode(), C.byref(cnt), C.byref(ms))
+        if cnt.value:
+            prof[name] = dict(launches=cnt.value, avg_ms=ms.value / cnt.value,
+                              ms_per_step=ms.value / nprof)
+    _lib.call("obhip_profile_enable", 0)
+    return prof
+
+
+def secondary_rooflines(hp, prof):
+    """Achieved fractions of the kernels beside the Gram, from the live hipEvent averages and
+    the algorithmic bytes / flops of DESIGN.md section 4 (per point: build reads 8 d and
+    writes 8 (Mc + 1); a product pass reads 8 (Mc + 1) + 8; the design-matrix copy writes 8 p;
+    a term-per-lane pass makes nnz_total 8-byte LDS reads per row)."""
+    n, p, d, Mc = float(hp.n), float(hp.p), float(hp.d), float(hp.ncols)
+    nnz = float(hp.terms_info["nnz_total"])
+    out = {}
+
+    def hbm(name, kernel, byts, extra=None):
+        if name not in prof:
+            return
+        ms = prof[name]["avg_ms"]
+        e = {"kernel": kernel, "avg_launch_ms": ms, "hbm_GBs": byts / ms / 1e6,
+             "hbm_frac": byts / ms / 1e6 / HBM_PEAK_GBS}
+        if extra:
+            e.update(extra(ms))
+        out[name] = e
+
+    def lds(ms):
+        b = 8.0 * n * nnz
+        return {"lds_GBs": b / ms / 1e6, "lds_frac": b / ms / 1e6 / LDS_PEAK_GBS,
+                "bound": "lds (term-per-lane column reads)"}
+    hbm("build_basis", "k_build_basis", n * 8 * (d + Mc + 1), lambda ms: {"bound": "fp64 valu issue"})
+    hbm("materialize_B", "k_materialize_tl", n * 8 * (Mc + 1 + p), lambda ms: {"bound": "hbm write"})
+    hbm("tmm", "k_tmm_tl", n * 8 * (Mc + 2), lds)
+    hbm("mm", "k_mm_tl", n * 8 * (Mc + 2), lds)
+    hbm("predict", "k_predict_tl", n * 8 * (d + 1), lds)
+    if "cholesky" in prof:
+        ms = prof["cholesky"]["avg_ms"]
+        fl = p ** 3 / 3.0
+        out["cholesky"] = {"kernel": "k_chol_panel2 + k_chol_update", "avg_launch_ms": ms,
+                           "tflops": fl / ms / 1e9, "mfma_frac": fl / ms / 1e9 / FP64_MFMA_PEAK_TFLOPS,
+                           "bound": "latency (p / 64 dependent panel steps)"}
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -199,12 +324,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0 and world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run for --gpus > 1")
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (libobhip has no CPU fallback)")
     # one rank per GPU; OBHIP_DIST_BACKEND=gloo lets several ranks rehearse the N > 1 path
-    # on a single GPU (gloo stages CUDA tensors through the host)
+    # on a single GPU (libobhip's host transport stages the exchange buffer through gloo)
     backend = os.environ.get("OBHIP_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     dev = local if backend == "nccl" else local % max(1, ndev)
@@ -216,14 +340,16 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import outerbase_amd as ob
+    import outerbase_amd as ob  # noqa: F401
     from outerbase_amd import _lib
-    from outerbase_amd.driver import HotPath
+    from outerbase_amd.driver import HotPath, shard_rows
 
     kinds = [k.strip() for k in args.kinds.split(",")]
     kinds = [kinds[i % len(kinds)] for i in range(args.d)]
-    hp = HotPath(kinds, args.knots, args.p, args.n, rank=rank, world=world,
-                 backend=args.backend)
+    n_total = args.n * world if args.weak else args.n
+    row0, n_local = shard_rows(rank, world, n_total)
+    hp = HotPath(kinds, args.knots, args.p, n_local, rank=rank, world=world, backend=args.backend,
+                 row0=row0, n_total=n_total)
     hp.setup()
     _lib.call("obhip_set_gram_backend", args.gram_backend)
 
@@ -232,35 +358,8 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        hp.step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hp.step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-kernel timing (hipEvents on the launch stream), outside the timed region
-    _lib.call("obhip_profile_reset")
-    _lib.call("obhip_profile_enable", 1)
-    nprof = 2
-    for _ in range(nprof):
-        hp.step()
-    torch.cuda.synchronize()
-    prof = {}
-    for name in ["build_basis", "materialize_B", "gram", "gram_reduce", "tmm", "mm", "sqtmm", "form_hessian",
-                 "cholesky", "backsolve", "predict"]:
-        cnt, ms = C.c_uint64(0), C.c_double(0)
-        _lib.call("obhip_profile_get", name.encode(), C.byref(cnt), C.byref(ms))
-        if cnt.value:
-            prof[name] = dict(launches=cnt.value, avg_ms=ms.value / cnt.value,
-                              ms_per_step=ms.value / nprof)
-    _lib.call("obhip_profile_enable", 0)
+    elapsed, per_step = timed_steps(hp, args.steps, args.warmup, sync, torch, dist, world)
+    prof = kernel_profile(hp, _lib, torch)
 
     # fit-only and predict-only wall times, outside the timed region
     split = {}
@@ -276,7 +375,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         split[name + "_ms"] = dt * 1e3
-        split[name + "_only_points_per_s"] = float(n_rows_all(hp)) / dt
+        split[name + "_only_points_per_s"] = float(n_total) / dt
 
     # what a host-buffer caller pays on top: x, y, xnew in, mean out over PCIe
     # (pinned buffers); reported beside `value`, never part of it
@@ -284,25 +383,23 @@ def main():
     if rank == 0:
         hx = torch.empty(hp.x.shape, dtype=torch.float64).pin_memory()
         hy = torch.empty(hp.n, dtype=torch.float64).pin_memory()
-        sync_local = torch.cuda.synchronize
-        sync_local()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         hp.x.copy_(hx, non_blocking=True)
         hp.xnew.copy_(hx, non_blocking=True)
         hp.y_raw.copy_(hy, non_blocking=True)
         hy.copy_(hp.mean, non_blocking=True)
-        sync_local()
+        torch.cuda.synchronize()
         pcie = (time.perf_counter() - t0) * 1e3
-        # restore the synthetic inputs the copies overwrote
-        hp.setup_inputs()
-        sync_local()
-
+        hp.setup_inputs()          # restore the synthetic inputs the copies overwrote
+        hp.step()
+        torch.cuda.synchronize()
+        del hx, hy
 
     # the other back end on the same inputs, for the record (untimed region; every rank
-    # takes part because the fit all-reduces): B = matrix-free PCG, what obfit() runs
+    # takes part because the fit sums over ranks): B = matrix-free PCG, what obfit() runs
     alt = None
     if args.backend == "newton" and not args.no_alt_backend:
-        import numpy as np
         theta_newton = hp.theta.clone()
         mean_newton = hp.mean.clone()
         hp.backend = "cg"
@@ -314,90 +411,144 @@ def main():
         dt = time.perf_counter() - t0
         rel = float((hp.mean - mean_newton).abs().max() / mean_newton.abs().max())
         alt = {"backend": "cg (lpdf::optcg, tol 1e-10, cap .getsteps)", "ms_per_step": dt * 1e3,
-               "points_per_s": float(n_rows_all(hp)) / dt, "cg_iterations": hp.cg_iters,
+               "points_per_s": float(n_total) / dt, "cg_iterations": hp.cg_iters,
                "max_rel_diff_of_predictions_vs_newton": rel}
         hp.backend = "newton"
         hp.theta.copy_(theta_newton)
         hp.mean.copy_(mean_newton)
+
+    comm_info = hp.comm_info()
+
+    # BASELINE.json configs[3]'s shape: 1.25e6 rows per GPU (weak), same d / p / knots.  Every
+    # rank takes part.  Measured after the headline so that it cannot disturb it.
+    config3 = None
+    if not args.no_config3 and args.backend == "newton" and (args.d, args.p) == (20, 4096):
+        rows3 = 1_250_000
+        keep = dict(theta=hp.theta.clone(), mean=hp.mean[:4096].clone(), g=hp.g.clone(),
+                    y_cent=hp.y_cent, y_sca=hp.y_sca)
+        hp.close()
+        for name in ("x", "xnew", "y_raw", "y", "ones", "mean", "G"):
+            setattr(hp, name, None)
+        torch.cuda.empty_cache()
+        _lib.call("obhip_trim_pool")
+        h3 = HotPath(kinds, args.knots, args.p, rows3, rank=rank, world=world, backend="newton",
+                     row0=rank * rows3, n_total=rows3 * world)
+        h3.setup()
+        e3, ps3 = timed_steps(h3, 3, 1, sync, torch, dist, world)
+        config3 = {"workload": "BASELINE.json configs[3]: d=20 n=%d (1.25e6 rows per GPU x %d) p=4096"
+                               % (rows3 * world, world),
+                   "scaling": "weak", "value": rows3 * world * 3 / e3, "unit": "points/s",
+                   "ms_per_step": e3 / 3 * 1e3, "median_step_ms": statistics.median(ps3),
+                   "steps": 3, "warmup": 1}
+        h3.close()
+        del h3
+        torch.cuda.empty_cache()
+    else:
+        keep = None
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    n, p = args.n, args.p
-    pts = float(n) * world * args.steps
+    p = args.p
+    pts = float(n_total) * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     out = {
-        "metric": "fit+predict points/sec, d=%d n=%g p=%d" % (args.d, n, p),
+        "metric": "fit+predict points/sec, d=%d n=%g p=%d" % (args.d, n_total, p),
         "value": pts / elapsed,
         "unit": "points/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "median_step_ms": statistics.median(per_step),
+        "value_at_median_step": float(n_total) / (statistics.median(per_step) * 1e-3),
+        "step_ms": per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if args.weak else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "%s: d=%d n=%d rows/GPU p=%d, %s, %d knots/dim, "
+            "workload": "%s: d=%d n=%d (%d rows on each of %d GPU(s)) p=%d, %s, %d knots/dim, "
                         "fit (%s) + predict on n fresh rows"
-                        % (which_config(args.d, n, p), args.d, n, p, "/".join(sorted(set(kinds))),
-                           args.knots, "Gram+Cholesky" if args.backend == "newton" else "PCG"),
+                        % (which_config(args.d, n_total, n_local, p), args.d, n_total, n_local,
+                           world, p, "/".join(sorted(set(kinds))), args.knots,
+                           "Gram+Cholesky" if args.backend == "newton" else "PCG"),
             "backend": args.backend,
-            "rows_per_gpu": n, "d": args.d, "p": p,
+            "rows_total": n_total, "rows_per_gpu": n_local, "d": args.d, "p": p,
             "terms_nnz": hp.terms_info["nnz_total"], "basis_columns": hp.ncols,
-            "parallelism": "rows sharded over %d rank(s); all-reduce of G and g" % world,
+            "parallelism": "rows sharded over %d rank(s); one exchange buffer per fit "
+                           "(packed triangle of G, B^T y, B^T 1, 3 scalars)" % world,
         },
+        "exchange": dict(comm_info, allreduce_ms=prof.get("exchange", {}).get("avg_ms")),
         "fit_predict_split": split,
         "host_buffer_overhead": None if pcie is None else {
             "pcie_ms_per_step": pcie,
-            "what": "x, xnew, y host->device and mean device->host, pinned, one GPU",
-            "points_per_s_including_copies": float(n) * world / (ms_per_step * 1e-3 + pcie * 1e-3)},
+            "what": "x, xnew, y host->device and mean device->host, pinned, rank 0's shard",
+            "points_per_s_including_copies": float(n_total) / (ms_per_step * 1e-3 + pcie * 1e-3)},
         "kernels_ms": prof,
         "parity_check": None,
         "alt_backend": alt,
+        "config3": config3,
     }
     if "gram" in prof and args.backend == "newton":
-        flops = float(n) * p * (p + 1)  # p(p+1) flop per point
+        flops = float(n_local) * p * (p + 1)  # p(p+1) flop per point
         ach = flops / (prof["gram"]["avg_ms"] * 1e-3) / 1e12
-        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE,
-        # WRITE_SIZE) on this exact workload; see the file for the command and caveats
-        traffic = None
-        kernel = {0: "k_gram_dma2", 1: "k_gram", 2: "k_gram_valu", 3: "k_gram_mfma4",
-                  4: "k_gram_dma2"}[args.gram_backend]
-        tf = os.path.join(ROOT, "profiles", "r01_gram_traffic.json")
-        if os.path.exists(tf):
-            tj = json.load(open(tf))
-            c = tj["config"]
-            if tj["kernel"] == kernel and \
-                    (c["d"], c["rows"], c["p"], c["knots"]) == (args.d, n, p, args.knots):
-                traffic = tj["traffic_bytes_per_launch"]
+        # HBM-side bytes per launch and the matrix-pipe utilisation come from separate
+        # rocprofv3 --pmc passes on this exact workload (profiles/); see the files for the
+        # commands and the gfx950 corrections
+        traffic = mfma_util = None
+        kernel = {0: "k_gram_dma2", 1: "k_gram", 3: "k_gram_mfma4", 4: "k_gram_dma2"}.get(
+            args.gram_backend, "k_gram_dma2")
+        for fn in ("r02_gram_traffic.json", "r01_gram_traffic.json"):
+            tf = os.path.join(ROOT, "profiles", fn)
+            if os.path.exists(tf):
+                tj = json.load(open(tf))
+                c = tj["config"]
+                if tj["kernel"] == kernel and \
+                        (c["d"], c["rows"], c["p"], c["knots"]) == (args.d, n_local, p, args.knots):
+                    traffic = tj["traffic_bytes_per_launch"]
+                    mfma_util = tj.get("mfma_util")
+                    break
+        mf = os.path.join(ROOT, "profiles", "r02_pmc_gram_mfma.json")
+        if mfma_util is None and os.path.exists(mf):
+            mj = json.load(open(mf))
+            c = mj["config"]
+            if mj["kernel"] == kernel and (c["d"], c["rows"], c["p"]) == (args.d, n_local, p):
+                mfma_util = mj["mfma_util"]
         out["roofline"] = {"bound": "mfma", "kernel": kernel, "achieved": ach,
                            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                            "traffic_unit": "bytes per launch (PMC, separate pass)",
+                           "mfma_util": mfma_util,
                            "avg_launch_ms": prof["gram"]["avg_ms"]}
     elif "mm" in prof:
-        byts = float(n) * 8 * (hp.ncols + 1)
+        byts = float(n_local) * 8 * (hp.ncols + 1)
         ach = byts / (prof["mm"]["avg_ms"] * 1e-3) / 1e9
-        # the PCG back end's kernels are LDS-bound (80 % LdsUtil, profiles/r01_pmc_products.txt);
-        # the contract's roofline object only knows hbm | mfma, so this is the HBM view of k_mm_tl
+        # the PCG back end's kernels are LDS-bound (profiles/r01_pmc_products.txt); the
+        # contract's roofline object only knows hbm | mfma, so this is the HBM view of k_mm_tl
         out["roofline"] = {"bound": "hbm", "kernel": "k_mm_tl", "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                            "avg_launch_ms": prof["mm"]["avg_ms"],
-                           "note": "LDS-bound kernel, see profiles/r01_pmc_products.txt"}
+                           "note": "LDS-bound kernel, see roofline_secondary"}
+    out["roofline_secondary"] = secondary_rooflines(hp, prof)
     if not args.no_cpu_baseline and world == 1:
         # the CPU leg: the oracle as the timed baseline and as the checker of this very run
         # (device predictions and Newton stationarity on a row sample); nothing else in this
         # file touches oracle/
         if alt and hp.cg_iters is None:
             hp.cg_iters = alt.get("cg_iterations")
+        if keep is not None:
+            # config3 released the headline run's buffers; re-run one step for the check
+            hp.setup()
+            hp.step()
+            torch.cuda.synchronize()
         out["cpu_baseline"] = cpu_baseline(hp, args.cpu_sample)
         out["parity_check"] = check_against_oracle(hp)
     print(json.dumps(out))
+    sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -51,6 +51,9 @@ extern "C" {
 typedef struct obhip_model obhip_model; /* class outermod, modandbase.h:9-54 */
 typedef struct obhip_basis obhip_basis; /* class outerbase, modandbase.h:57-125 */
 typedef struct obhip_terms obhip_terms; /* a umat `terms` resident on device */
+typedef struct obhip_comm obhip_comm;   /* the ranks of a row-sharded job (no reference
+                                           counterpart: the reference is one process,
+                                           modandbase.cpp:464) */
 
 /* ---- library ----------------------------------------------------------- */
 int obhip_abi_version(void);
@@ -280,15 +283,57 @@ int obhip_fit_cg(const obhip_basis *b, const obhip_terms *t,
                  const obhip_model *m, const double *y, double sigma,
                  double rho, double tol, uint64_t maxit, double *theta,
                  uint64_t *iters_out, double *diagH, double *val_out);
-/* same with y / theta / diagH in HBM; all_reduce (may be NULL) is called on
- * (device pointer, count) whenever a p-vector or a scalar block must be
- * summed over ranks (multi-GPU row sharding). */
-typedef int (*obhip_allreduce_fn)(void *user, double *d_buf, uint64_t count);
+/* same with y / theta / diagH in HBM.  comm (may be NULL = one rank): the rows are sharded
+ * over comm's ranks and every B^T a pass sums one p-vector (+ 2 scalars) over them
+ * (SURVEY.md section 8e); all ranks return the same theta. */
 int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *t,
                      const obhip_model *m, const double *d_y, double sigma,
                      double rho, double tol, uint64_t maxit, double *d_theta,
                      uint64_t *iters_out, double *d_diagH, double *val_out,
-                     obhip_allreduce_fn all_reduce, void *user);
+                     obhip_comm *comm);
+
+/* ---- multi-GPU: rows sharded over ranks, one process per GPU ------------
+ * No reference counterpart (one process, OpenMP threads: modandbase.cpp:464,480); this is
+ * the partitioning BASELINE.json's north_star prescribes.  Every rank holds a contiguous row
+ * block of x / y and its own outerbase; outermod and terms are replicated.  Back end A
+ * exchanges ONE buffer per fit, back end B one p-vector per B^T a pass; prediction needs no
+ * communication. */
+#define OBHIP_UNIQUE_ID_BYTES 128
+#define OBHIP_TRANSPORT_NONE 0
+#define OBHIP_TRANSPORT_RCCL 1 /* ncclReduceScatter + ncclAllGather over xGMI */
+#define OBHIP_TRANSPORT_HOST 2 /* caller-supplied sum of a host buffer (MPI, gloo) */
+/* rank 0 draws the communicator id (ncclGetUniqueId); the launcher hands the 128 bytes to
+ * every rank */
+int obhip_comm_unique_id(void *id);
+/* RCCL communicator over the current device of each of the nranks processes
+ * (ncclCommInitRank; collective: every rank must call it).  librccl is loaded at run time. */
+int obhip_comm_init(obhip_comm **out, int nranks, int rank, const void *id);
+/* the same ranks with a caller-supplied transport: fn(user, host_buf, count) sums count
+ * doubles in place over all ranks (MPI_Allreduce under R, gloo in the one-GPU rehearsals);
+ * the library stages device buffers through pinned memory */
+typedef int (*obhip_host_allreduce_fn)(void *user, double *host_buf, uint64_t count);
+int obhip_comm_init_host(obhip_comm **out, int nranks, int rank, obhip_host_allreduce_fn fn,
+                         void *user);
+int obhip_comm_destroy(obhip_comm *c);
+/* rccl_ranks: what ncclCommCount reports (0 for the host transport); rccl_version:
+ * ncclGetVersion; any pointer may be NULL */
+int obhip_comm_info(const obhip_comm *c, int *nranks, int *rank, int *transport, int *rccl_ranks,
+                    int *rccl_version);
+/* in-place sum of count doubles in HBM over the ranks, on the library's stream */
+int obhip_comm_allreduce_dev(obhip_comm *c, double *d_buf, uint64_t count);
+/* The one exchange of back end A.  Buffer layout (count doubles, obhip_normal_eq_count):
+ * [upper triangle of G_r = B_r^T B_r, row-major packed, p (p + 1) / 2][B_r^T y_r : p]
+ * [B_r^T 1 : p][sum y_r, sum y_r^2, n_r][zero padding to 2 nranks].  Pack -> sum over ranks ->
+ * unpack: d_G becomes the global Gram (full symmetric storage), d_g the right-hand side of
+ * the problem with y standardised over ALL rows like obfit does (R/fitting.R:55-57):
+ * B^T ((y - cent) / sca) = (B^T y - cent B^T 1) / sca; d_meansd receives cent, sca, n
+ * (device, 3 doubles).  comm may be NULL (one rank: only the standardisation happens and the
+ * triangle part of the buffer is never touched, so d_buf may point count - tail doubles
+ * before a tail-sized allocation). */
+int obhip_normal_eq_count(uint64_t p, int nranks, uint64_t *count);
+int obhip_normal_eq_exchange_dev(obhip_comm *comm, uint64_t p, uint64_t n_local, double *d_G,
+                                 double *d_g, const double *d_b1, const double *d_sum2,
+                                 double *d_buf, uint64_t buf_count, double *d_meansd);
 
 /* ---- predictor ---------------------------------------------------------- */
 /* predictor$update(x) + $mean() (+ $var() of pred_gauss):

@@ -919,7 +919,8 @@ def genknotlist(bassize, x):
 def getsteps(numb, sampsize, sigtonoiseratio=1e-3, tol=0.001):
     """.getsteps (R/fitting.R:188-195)."""
     r = math.sqrt(numb / sampsize)
-    kapp = (1 + r) ** 2 / (1 - r) ** 2
+    # R evaluates (1 + r)^2 / 0 to Inf and min(1000, Inf) = 1000
+    kapp = math.inf if r == 1.0 else (1 + r) ** 2 / (1 - r) ** 2
     kapp = min(1000, kapp)
     iterest = 0.5 * math.sqrt(kapp) * math.log(2 * sampsize *
                                                 sigtonoiseratio / tol)
@@ -962,11 +963,12 @@ def splitmix64(z):
 
 
 def synth_u(seed, row0, nrows, d):
-    """u(i,j) = (splitmix64(seed + i*d + j) >> 11) * 2^-53."""
+    """u(i,j) = (splitmix64(splitmix64(seed) ^ (i*d + j)) >> 11) * 2^-53: the hashed seed
+    masks the counter, so that the streams of two seeds do not overlap."""
     i = np.arange(row0, row0 + nrows, dtype=np.uint64)[:, None]
     j = np.arange(d, dtype=np.uint64)[None, :]
     with np.errstate(over="ignore"):
-        ctr = np.uint64(seed) + i * np.uint64(d) + j
+        ctr = splitmix64(np.uint64(seed)) ^ (i * np.uint64(d) + j)
     return (splitmix64(ctr) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
 
 

@@ -22,21 +22,23 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "obhip.h")
 LIB_PATH = os.path.join(_HERE, "libobhip.so")
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
+# obhip_host_allreduce_fn: sum count doubles of a HOST buffer in place over all ranks
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 
 _BASE = {
     "int": C.c_int, "double": C.c_double, "uint64_t": C.c_uint64,
     "int64_t": C.c_int64, "void": None, "char": C.c_char, "size_t": C.c_size_t,
 }
-_HANDLES = ("obhip_model", "obhip_basis", "obhip_terms")
+_HANDLES = ("obhip_model", "obhip_basis", "obhip_terms", "obhip_comm", "obhip_lpdf",
+            "obhip_predictor")
 
 
 def _ctype(decl):
     decl = decl.replace("const", " ").strip()
     stars = decl.count("*")
     base = decl.replace("*", " ").split()[0]
-    if base == "obhip_allreduce_fn":
-        return C.c_void_p  # pass ctypes.cast(ALLREDUCE_FN(f), c_void_p) or None
+    if base == "obhip_host_allreduce_fn":
+        return C.c_void_p  # pass ctypes.cast(HOST_ALLREDUCE_FN(f), c_void_p) or None
     if base in _HANDLES:
         return C.c_void_p if stars == 1 else C.POINTER(C.c_void_p)
     if base == "char" and stars == 1:

@@ -323,7 +323,7 @@ int obhip_fit_newton(const obhip_basis *b, const obhip_terms *t, const obhip_mod
 int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_model *m,
                      const double *d_y, double sigma, double rho, double tol, uint64_t maxit,
                      double *d_theta, uint64_t *iters_out, double *d_diagH, double *val_out,
-                     obhip_allreduce_fn all_reduce, void *user) {
+                     obhip_comm *comm) {
   if (!b || !tc || !m || !d_y || !d_theta) return fail(OBHIP_ERR_INVALID, "fit_cg_dev: null argument");
   OB_TRY(check_compat(m, tc));
   obhip_terms &t = *const_cast<obhip_terms *>(tc);
@@ -344,18 +344,17 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_mo
   OB_TRY(scratch(&red));
   hipStream_t st = cur_stream();
 
+  const bool many = comm != nullptr;
   auto reduce_pull = [&](double *d_buf, uint64_t count, double *host) -> int {
-    if (all_reduce) {
-      OB_HIP(hipStreamSynchronize(st));
-      if (all_reduce(user, d_buf, count) != 0) return fail(OBHIP_ERR_HIP, "all_reduce callback failed");
-    }
+    if (many) OB_TRY(comm_allreduce(comm, d_buf, count));  // stream-ordered (RCCL) or staged
     return d2h(host, d_buf, count * sizeof(double));
   };
 
   // total number of rows over all ranks
   double ntot = (double)n;
-  if (all_reduce) {
+  if (many) {
     OB_HIP(hipMemcpyAsync(dpv.p, &ntot, sizeof(double), hipMemcpyHostToDevice, st));
+    OB_HIP(hipStreamSynchronize(st));  // ntot is about to be overwritten
     OB_TRY(reduce_pull(dpv.p, 1, &ntot));
   }
 
@@ -481,7 +480,7 @@ int obhip_fit_cg(const obhip_basis *b, const obhip_terms *t, const obhip_model *
   OB_TRY(dth.upload(theta, t->p));
   OB_TRY(ddiag.alloc(t->p));
   OB_TRY(obhip_fit_cg_dev(b, t, m, dy.p, sigma, rho, tol, maxit, dth.p, iters_out, ddiag.p, val_out,
-                          nullptr, nullptr));
+                          nullptr));
   OB_TRY(d2h(theta, dth.p, t->p * sizeof(double)));
   if (diagH) OB_TRY(d2h(diagH, ddiag.p, t->p * sizeof(double)));
   return 0;

@@ -1,0 +1,295 @@
+// Multi-GPU exchange of libobhip: rows are sharded over ranks, one
+// process per GPU, and the only data that ever crosses ranks is
+//   back end A: ONE buffer per fit -- the packed upper triangle of G_r = B_r^T B_r, the two
+//               p-vectors B_r^T y_r and B_r^T 1 and the three scalars (sum y, sum y^2, n_r);
+//   back end B: one p-vector (+ 2 scalars) per B^T a pass of the PCG.
+// The reference is a single process (nthreads = omp_get_num_procs(), src/modandbase.cpp:464);
+// this is north_star's own requirement and has no reference counterpart.
+//
+// Transports behind one obhip_comm:
+//   RCCL  (obhip_comm_init): ncclReduceScatter + ncclAllGather, in place, on the library's
+//         stream.  On a fully connected xGMI node the two halves drive all links at once; the
+//         ring a single all-reduce may pick is bound by one link.  librccl is loaded at run
+//         time (the copy already in the process wins), so the library neither links nor
+//         needs it on one GPU.
+//   host  (obhip_comm_init_host): the caller supplies "sum this HOST buffer over ranks"
+//         (gloo in the one-GPU rehearsals of the tests, MPI_Allreduce under R); the library
+//         stages through a pinned buffer.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "obhip_internal.h"
+
+using namespace obhip;
+
+namespace {
+
+// the few RCCL entry points, by their documented C signatures (rccl/rccl.h)
+struct RcclId {
+  char internal[OBHIP_UNIQUE_ID_BYTES];
+};
+typedef void *rccl_comm_t;
+constexpr int kNcclSum = 0, kNcclDouble = 8;  // ncclRedOp_t / ncclDataType_t
+typedef int (*nccl_get_unique_id_t)(RcclId *);
+typedef int (*nccl_comm_init_rank_t)(rccl_comm_t *, int, RcclId, int);
+typedef int (*nccl_comm_destroy_t)(rccl_comm_t);
+typedef int (*nccl_comm_count_t)(const rccl_comm_t, int *);
+typedef const char *(*nccl_get_error_string_t)(int);
+typedef int (*nccl_get_version_t)(int *);
+typedef int (*nccl_reduce_scatter_t)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t);
+typedef int (*nccl_all_gather_t)(const void *, void *, size_t, int, rccl_comm_t, hipStream_t);
+typedef int (*nccl_all_reduce_t)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t);
+typedef int (*nccl_group_t)(void);
+
+struct Rccl {
+  void *lib = nullptr;
+  nccl_get_unique_id_t get_unique_id = nullptr;
+  nccl_comm_init_rank_t comm_init_rank = nullptr;
+  nccl_comm_destroy_t comm_destroy = nullptr;
+  nccl_comm_count_t comm_count = nullptr;
+  nccl_get_error_string_t error_string = nullptr;
+  nccl_get_version_t get_version = nullptr;
+  nccl_reduce_scatter_t reduce_scatter = nullptr;
+  nccl_all_gather_t all_gather = nullptr;
+  nccl_all_reduce_t all_reduce = nullptr;
+  nccl_group_t group_start = nullptr, group_end = nullptr;
+};
+
+int rccl(Rccl **out) {
+  static Rccl r;
+  if (!r.lib) {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names)
+      if ((r.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!r.lib)
+      for (const char *nm : names)
+        if ((r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!r.lib) return fail(OBHIP_ERR_STATE, "RCCL (librccl.so.1) not found: multi-GPU needs it");
+    r.get_unique_id = (nccl_get_unique_id_t)dlsym(r.lib, "ncclGetUniqueId");
+    r.comm_init_rank = (nccl_comm_init_rank_t)dlsym(r.lib, "ncclCommInitRank");
+    r.comm_destroy = (nccl_comm_destroy_t)dlsym(r.lib, "ncclCommDestroy");
+    r.comm_count = (nccl_comm_count_t)dlsym(r.lib, "ncclCommCount");
+    r.error_string = (nccl_get_error_string_t)dlsym(r.lib, "ncclGetErrorString");
+    r.get_version = (nccl_get_version_t)dlsym(r.lib, "ncclGetVersion");
+    r.reduce_scatter = (nccl_reduce_scatter_t)dlsym(r.lib, "ncclReduceScatter");
+    r.all_gather = (nccl_all_gather_t)dlsym(r.lib, "ncclAllGather");
+    r.all_reduce = (nccl_all_reduce_t)dlsym(r.lib, "ncclAllReduce");
+    r.group_start = (nccl_group_t)dlsym(r.lib, "ncclGroupStart");
+    r.group_end = (nccl_group_t)dlsym(r.lib, "ncclGroupEnd");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.comm_count ||
+        !r.reduce_scatter || !r.all_gather || !r.all_reduce) {
+      r.lib = nullptr;
+      return fail(OBHIP_ERR_STATE, "librccl lacks an expected entry point");
+    }
+  }
+  *out = &r;
+  return 0;
+}
+
+int rccl_fail(Rccl *r, int rc, const char *what) {
+  return fail(OBHIP_ERR_HIP, std::string("RCCL: ") + what + " failed: " +
+                                 (r->error_string ? r->error_string(rc) : std::to_string(rc)));
+}
+
+}  // namespace
+
+struct obhip_comm {
+  int nranks = 1, rank = 0;
+  int transport = OBHIP_TRANSPORT_NONE;
+  int device = 0;
+  // RCCL
+  Rccl *r = nullptr;
+  rccl_comm_t nccl = nullptr;
+  int rccl_ranks = 0;
+  // host transport
+  obhip_host_allreduce_fn fn = nullptr;
+  void *user = nullptr;
+  double *pinned = nullptr;
+  size_t pinned_n = 0;
+  // statistics of the last exchange
+  uint64_t last_bytes = 0, calls = 0;
+};
+
+namespace obhip {
+
+// in-place sum of count doubles over the ranks of c, enqueued on (RCCL) or synchronised
+// with (host transport) the library's stream
+int comm_allreduce(obhip_comm *c, double *d_buf, uint64_t count) {
+  if (!c || count == 0) return 0;
+  // (a one-rank communicator still goes through its transport: the sums are copies, and
+  // the whole exchange can be rehearsed on one GPU)
+  hipStream_t st = cur_stream();
+  c->last_bytes = count * sizeof(double);
+  c->calls += 1;
+  if (c->transport == OBHIP_TRANSPORT_RCCL) {
+    Rccl *r = c->r;
+    const uint64_t nr = (uint64_t)c->nranks;
+    // reduce-scatter + all-gather need nranks equal blocks (16-byte multiples); small or
+    // ragged buffers take the plain all-reduce (latency-bound anyway)
+    if (count >= 4096 * nr && count % (2 * nr) == 0) {
+      const uint64_t blk = count / nr;
+      double *mine = d_buf + (uint64_t)c->rank * blk;
+      int rc = r->reduce_scatter(d_buf, mine, blk, kNcclDouble, kNcclSum, c->nccl, st);
+      if (rc) return rccl_fail(r, rc, "ncclReduceScatter");
+      rc = r->all_gather(mine, d_buf, blk, kNcclDouble, c->nccl, st);
+      if (rc) return rccl_fail(r, rc, "ncclAllGather");
+    } else {
+      const int rc = r->all_reduce(d_buf, d_buf, count, kNcclDouble, kNcclSum, c->nccl, st);
+      if (rc) return rccl_fail(r, rc, "ncclAllReduce");
+    }
+    return 0;
+  }
+  if (c->transport == OBHIP_TRANSPORT_HOST) {
+    if (c->pinned_n < count) {
+      if (c->pinned) (void)hipHostFree(c->pinned);
+      c->pinned = nullptr;
+      c->pinned_n = 0;
+      OB_HIP(hipHostMalloc((void **)&c->pinned, count * sizeof(double), hipHostMallocDefault));
+      c->pinned_n = count;
+    }
+    OB_HIP(hipMemcpyAsync(c->pinned, d_buf, count * sizeof(double), hipMemcpyDeviceToHost, st));
+    OB_HIP(hipStreamSynchronize(st));
+    if (c->fn(c->user, c->pinned, count) != 0)
+      return fail(OBHIP_ERR_HIP, "host all-reduce callback failed");
+    OB_HIP(hipMemcpyAsync(d_buf, c->pinned, count * sizeof(double), hipMemcpyHostToDevice, st));
+    return 0;
+  }
+  return fail(OBHIP_ERR_STATE, "communicator has no transport");
+}
+
+int comm_nranks(const obhip_comm *c) { return c ? c->nranks : 1; }
+
+}  // namespace obhip
+
+extern "C" {
+
+int obhip_comm_unique_id(void *id) {
+  if (!id) return fail(OBHIP_ERR_INVALID, "comm_unique_id: null argument");
+  Rccl *r = nullptr;
+  OB_TRY(rccl(&r));
+  RcclId u;
+  std::memset(&u, 0, sizeof u);
+  const int rc = r->get_unique_id(&u);
+  if (rc) return rccl_fail(r, rc, "ncclGetUniqueId");
+  std::memcpy(id, &u, sizeof u);
+  return 0;
+}
+
+int obhip_comm_init(obhip_comm **out, int nranks, int rank, const void *id) {
+  if (!out || nranks < 1 || rank < 0 || rank >= nranks || !id)
+    return fail(OBHIP_ERR_INVALID, "comm_init: bad argument");
+  OB_TRY(require_device());
+  Rccl *r = nullptr;
+  OB_TRY(rccl(&r));
+  obhip_comm *c = new obhip_comm();
+  c->nranks = nranks;
+  c->rank = rank;
+  c->transport = OBHIP_TRANSPORT_RCCL;
+  c->r = r;
+  (void)hipGetDevice(&c->device);
+  RcclId u;
+  std::memcpy(&u, id, sizeof u);
+  int rc = r->comm_init_rank(&c->nccl, nranks, u, rank);
+  if (rc) {
+    delete c;
+    return rccl_fail(r, rc, "ncclCommInitRank");
+  }
+  rc = r->comm_count(c->nccl, &c->rccl_ranks);
+  if (rc || c->rccl_ranks != nranks) {
+    (void)r->comm_destroy(c->nccl);
+    delete c;
+    return fail(OBHIP_ERR_STATE, "RCCL communicator reports a different rank count");
+  }
+  *out = c;
+  return 0;
+}
+
+int obhip_comm_init_host(obhip_comm **out, int nranks, int rank, obhip_host_allreduce_fn fn,
+                         void *user) {
+  if (!out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn))
+    return fail(OBHIP_ERR_INVALID, "comm_init_host: bad argument");
+  obhip_comm *c = new obhip_comm();
+  c->nranks = nranks;
+  c->rank = rank;
+  c->transport = OBHIP_TRANSPORT_HOST;
+  c->fn = fn;
+  c->user = user;
+  *out = c;
+  return 0;
+}
+
+int obhip_comm_destroy(obhip_comm *c) {
+  if (!c) return 0;
+  if (c->transport == OBHIP_TRANSPORT_RCCL && c->nccl) {
+    (void)hipStreamSynchronize(cur_stream());
+    (void)c->r->comm_destroy(c->nccl);
+  }
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  delete c;
+  return 0;
+}
+
+int obhip_comm_info(const obhip_comm *c, int *nranks, int *rank, int *transport, int *rccl_ranks,
+                    int *rccl_version) {
+  if (!c) return fail(OBHIP_ERR_INVALID, "comm_info: null communicator");
+  if (nranks) *nranks = c->nranks;
+  if (rank) *rank = c->rank;
+  if (transport) *transport = c->transport;
+  if (rccl_ranks) *rccl_ranks = c->rccl_ranks;
+  if (rccl_version) {
+    *rccl_version = 0;
+    if (c->r && c->r->get_version) (void)c->r->get_version(rccl_version);
+  }
+  return 0;
+}
+
+int obhip_comm_allreduce_dev(obhip_comm *c, double *d_buf, uint64_t count) {
+  if (!c || (!d_buf && count)) return fail(OBHIP_ERR_INVALID, "comm_allreduce_dev: null argument");
+  ProfScope ps("exchange");
+  return comm_allreduce(c, d_buf, count);
+}
+
+}  // extern "C"
+
+// ---- the one-buffer exchange of back end A -------------------------------------------------
+namespace obhip {
+uint64_t normal_eq_tail(uint64_t p);
+int launch_pack_normal_eq(uint64_t p, bool with_tri, const double *d_G, const double *d_g,
+                          const double *d_b1, const double *d_sum2, double nlocal, double *d_buf,
+                          uint64_t count);
+int launch_unpack_normal_eq(uint64_t p, bool with_tri, const double *d_buf, double *d_G, double *d_g,
+                            double *d_meansd);
+}  // namespace obhip
+
+extern "C" {
+
+int obhip_normal_eq_count(uint64_t p, int nranks, uint64_t *count) {
+  if (!count || nranks < 1 || p == 0) return fail(OBHIP_ERR_INVALID, "normal_eq_count: bad argument");
+  const uint64_t raw = p * (p + 1) / 2 + normal_eq_tail(p);
+  const uint64_t q = 2 * (uint64_t)nranks;  // equal 16-byte blocks for reduce-scatter
+  *count = (raw + q - 1) / q * q;
+  return 0;
+}
+
+int obhip_normal_eq_exchange_dev(obhip_comm *comm, uint64_t p, uint64_t n_local, double *d_G,
+                                 double *d_g, const double *d_b1, const double *d_sum2,
+                                 double *d_buf, uint64_t buf_count, double *d_meansd) {
+  if (!d_G || !d_g || !d_b1 || !d_sum2 || !d_buf || !d_meansd || p == 0)
+    return fail(OBHIP_ERR_INVALID, "normal_eq_exchange_dev: null argument");
+  const int nr = comm_nranks(comm);
+  uint64_t need = 0;
+  OB_TRY(obhip_normal_eq_count(p, nr, &need));
+  if (buf_count < need) return fail(OBHIP_ERR_INVALID, "normal_eq_exchange_dev: buffer too small");
+  const bool many = comm != nullptr;
+  // no communicator: G stays where it is, only the tail (g, b1, scalars) goes through the
+  // buffer, whose triangle part is never touched
+  OB_TRY(launch_pack_normal_eq(p, many, d_G, d_g, d_b1, d_sum2, (double)n_local, d_buf, need));
+  if (many) {
+    ProfScope ps("exchange");
+    OB_TRY(comm_allreduce(comm, d_buf, need));
+  }
+  return launch_unpack_normal_eq(p, many, d_buf, d_G, d_g, d_meansd);
+}
+
+}  // extern "C"

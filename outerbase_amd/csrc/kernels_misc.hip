@@ -16,8 +16,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
+// u(i, j) = (splitmix64(splitmix64(seed) ^ (i d + j)) >> 11) 2^-53: the seed is hashed into a
+// mask of the counter, so streams of different seeds do not overlap (with seed + counter the
+// prediction rows of seed 43 were the training rows of seed 42 shifted by one coordinate)
 __device__ __forceinline__ double synth_u(uint64_t seed, uint64_t i, uint64_t d, uint64_t j) {
-  return (double)(splitmix64(seed + i * d + j) >> 11) * 0x1.0p-53;
+  return (double)(splitmix64(splitmix64(seed) ^ (i * d + j)) >> 11) * 0x1.0p-53;
 }
 
 // x = 0.02 + 0.96 u (x 6.283185 on mat25ang dims);

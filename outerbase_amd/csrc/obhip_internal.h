@@ -298,5 +298,8 @@ int launch_resid(const double *d_yhat, const double *d_y, uint64_t n, double e2,
                  double *d_r, double *d_diff);
 int launch_scale(double *d_v, uint64_t n, double c);
 int launch_fill(double *d_v, uint64_t n, double c);
+// comm.cpp: in-place sum over the ranks of c (no-op for c == nullptr or one rank)
+int comm_allreduce(obhip_comm *c, double *d_buf, uint64_t count);
+int comm_nranks(const obhip_comm *c);
 
 }  // namespace obhip

@@ -34,45 +34,72 @@ def bench_knots(kinds, m=40):
     return out
 
 
-def shard_rows(rank, rows_per_rank):
-    """Row block of the counter-based synthetic stream owned by `rank`
-    (contiguous row blocks, no data exchange)."""
-    return rank * rows_per_rank, rows_per_rank
+def shard_rows(rank, world, n_total):
+    """(row0, nrows) of the contiguous row block of the counter-based synthetic stream
+    owned by `rank` when n_total rows are split over `world` ranks (SURVEY.md section 8e:
+    contiguous row blocks, no data exchange)."""
+    lo = rank * n_total // world
+    hi = (rank + 1) * n_total // world
+    return lo, hi - lo
 
 
-def global_standardise(local_sum, centre_and_sumsq, n_total, reduce_floats):
-    """Mean and sd (n-1 denominator, R/fitting.R:55-57) of a vector sharded over
-    ranks, two-pass for accuracy.  local_sum() -> sum of the local shard;
-    centre_and_sumsq(cent) subtracts cent from the local shard and returns its sum
-    of squares; reduce_floats(list) -> element-wise sums over all ranks."""
-    cent = reduce_floats([local_sum()])[0] / n_total
-    ss = reduce_floats([centre_and_sumsq(cent)])[0]
-    return cent, math.sqrt(ss / (n_total - 1.0))
+def make_comm(rank, world, transport=None):
+    """obhip_comm of this process.  transport "rccl": an RCCL communicator of libobhip's own
+    (the id drawn by rank 0 travels over torch.distributed, which is the launcher's control
+    plane only); "host": sums go through torch.distributed on host memory (gloo) -- the
+    one-GPU rehearsal of the tests.  Default: rccl when torch.distributed runs on nccl."""
+    if world == 1:
+        return None, None
+    import torch
+    import torch.distributed as dist
+    if transport is None:
+        transport = "rccl" if dist.get_backend() == "nccl" else "host"
+    h = C.c_void_p()
+    if transport == "rccl":
+        uid = np.zeros(128, dtype=np.uint8)
+        if rank == 0:
+            call("obhip_comm_unique_id", uid.ctypes.data)
+        box = [uid.tobytes()]
+        dist.broadcast_object_list(box, src=0)
+        uid = np.frombuffer(box[0], dtype=np.uint8).copy()
+        call("obhip_comm_init", C.byref(h), world, rank, uid.ctypes.data)
+        return h, None
 
-
-def merge_normal_equations(G, g, all_reduce):
-    """Back end A's only exchange: sum the per-rank Gram and right-hand side
-    (SURVEY.md section 8e).  all_reduce(tensor) sums in place over ranks."""
-    all_reduce(G)
-    all_reduce(g)
-    return G, g
+    def _sum(user, host_ptr, count):
+        try:
+            buf = np.ctypeslib.as_array(C.cast(host_ptr, C.POINTER(C.c_double)), shape=(count,))
+            dist.all_reduce(torch.from_numpy(buf))
+            return 0
+        except Exception:
+            return 1
+    cb = _lib.HOST_ALLREDUCE_FN(_sum)
+    call("obhip_comm_init_host", C.byref(h), world, rank, C.cast(cb, C.c_void_p), None)
+    return h, cb   # the caller keeps cb alive as long as the communicator
 
 
 class HotPath:
+    """One rank of the row-sharded fit + predict job.  n = rows of THIS rank, row0 = its first
+    row in the synthetic stream, n_total = rows of all ranks."""
+
     def __init__(self, kinds, knots_per_dim, p, n, rank=0, world=1, backend="newton",
-                 seed_train=42, seed_pred=43, rho=DEFAULT_RHO, cg_tol=1e-10, cg_maxit=None):
+                 seed_train=42, seed_pred=43, rho=DEFAULT_RHO, cg_tol=1e-10, cg_maxit=None,
+                 row0=None, n_total=None, transport=None):
         self.kinds = list(kinds)
         self.d = len(kinds)
         self.m = knots_per_dim
         self.p = p
         self.n = n
         self.rank, self.world = rank, world
+        self.row0 = rank * n if row0 is None else row0
+        self.n_total = n * world if n_total is None else n_total
         self.backend = backend
         self.seed_train, self.seed_pred = seed_train, seed_pred
         self.rho = rho
         self.cg_tol = cg_tol
         self.cg_maxit = cg_maxit
+        self.transport = transport
         self.basis = None
+        self.comm = None
         self.cg_iters = None
 
     # -- one-time setup (not timed): model, terms, synthetic inputs in HBM ----------
@@ -97,85 +124,85 @@ class HotPath:
         self.xnew = torch.empty((d, n), dtype=f64, device=dev)
         self.y_raw = torch.empty(n, dtype=f64, device=dev)
         self.y = torch.empty(n, dtype=f64, device=dev)
+        self.ones = torch.ones(n, dtype=f64, device=dev)
         self.mean = torch.empty(n, dtype=f64, device=dev)
         self.G = torch.empty((p, p), dtype=f64, device=dev)
         self.g = torch.empty(p, dtype=f64, device=dev)
+        self.b1 = torch.empty(p, dtype=f64, device=dev)
         self.theta = torch.zeros(p, dtype=f64, device=dev)
         self.diagH = torch.empty(p, dtype=f64, device=dev)
-        self.stats = torch.zeros(2, dtype=f64, device=dev)
+        self.stats = torch.zeros(4, dtype=f64, device=dev)
+        self.meansd = torch.zeros(3, dtype=f64, device=dev)
         wsb = C.c_uint64(0)
         call("obhip_newton_workspace_bytes", p, C.byref(wsb))
         self.ws = torch.empty(wsb.value, dtype=torch.uint8, device=dev)
         self.wsb = wsb.value
-        self.setup_inputs()
+        cnt = C.c_uint64(0)
+        call("obhip_normal_eq_count", p, self.world, C.byref(cnt))
+        self.ex_count = cnt.value
+        # the exchange buffer [packed triangle | g | b1 | 3 scalars | padding].  With one rank
+        # the triangle part is never touched (G stays where it is), so only the tail gets
+        # memory and the buffer address is offset accordingly.
+        tri = p * (p + 1) // 2
         if self.world > 1:
-            self._cgbuf = torch.empty(p + 2, dtype=f64, device=dev)
-
-            def _cb(user, d_buf, count):
-                import torch.distributed as dist
-                try:
-                    buf = self._cgbuf[:count]
-                    call("obhip_memcpy_d2d", buf.data_ptr(), d_buf, 8 * count)
-                    dist.all_reduce(buf)
-                    call("obhip_memcpy_d2d", d_buf, buf.data_ptr(), 8 * count)
-                    torch.cuda.synchronize()
-                    return 0
-                except Exception:
-                    return 1
-            self._cb = _lib.ALLREDUCE_FN(_cb)
+            self.exbuf = torch.zeros(self.ex_count, dtype=f64, device=dev)
+            self.exbuf_ptr = self.exbuf.data_ptr()
         else:
-            self._cb = None
+            self.exbuf = torch.zeros(self.ex_count - tri, dtype=f64, device=dev)
+            self.exbuf_ptr = self.exbuf.data_ptr() - 8 * tri
+        self.setup_inputs()
+        self.comm, self._comm_cb = make_comm(self.rank, self.world, self.transport)
+
+    def comm_info(self):
+        if self.comm is None:
+            return {"transport": "none", "ranks": 1}
+        nr, rk, tr, rr, rv = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        call("obhip_comm_info", self.comm, C.byref(nr), C.byref(rk), C.byref(tr), C.byref(rr),
+             C.byref(rv))
+        return {"transport": {1: "rccl (reduce-scatter + all-gather)", 2: "host"}[tr.value],
+                "ranks": nr.value, "rccl_ranks": rr.value, "rccl_version": rv.value,
+                "bytes_per_fit": 8 * self.ex_count}
 
     def setup_inputs(self):
         """(Re)generate this rank's rows of the synthetic stream in HBM."""
         torch = self.torch
         n, d = self.n, self.d
         kid = (C.c_int * d)(*[KIND_ID[k] for k in self.kinds])
-        row0, _ = shard_rows(self.rank, n)
         scratch = torch.empty(n, dtype=torch.float64, device=self.x.device)
-        call("obhip_synth_xy_dev", self.seed_train, row0, n, d, C.cast(kid, C.c_void_p),
+        call("obhip_synth_xy_dev", self.seed_train, self.row0, n, d, C.cast(kid, C.c_void_p),
              self.x.data_ptr(), self.y_raw.data_ptr())
-        call("obhip_synth_xy_dev", self.seed_pred, row0, n, d, C.cast(kid, C.c_void_p),
+        call("obhip_synth_xy_dev", self.seed_pred, self.row0, n, d, C.cast(kid, C.c_void_p),
              self.xnew.data_ptr(), scratch.data_ptr())
         torch.cuda.synchronize()
         del scratch
 
-    def _allreduce(self, t):
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(t)
-
-    # -- y = (y - mean) / sd over ALL ranks (R/fitting.R:55-57) ------------------------
-    def standardise(self):
-        n_tot = float(self.n * self.world)
-        self.y.copy_(self.y_raw)
-
-        def local_sum():
-            call("obhip_sum_sumsq_dev", self.y.data_ptr(), self.n, self.stats.data_ptr())
-            return float(self.stats[0].item())
-
-        def centre_and_sumsq(cent):
-            call("obhip_affine_dev", self.y.data_ptr(), self.n, cent, 1.0)
-            call("obhip_sum_sumsq_dev", self.y.data_ptr(), self.n, self.stats.data_ptr())
-            return float(self.stats[1].item())
-
-        def reduce_floats(vals):
-            if self.world == 1:
-                return vals
-            t = self.torch.tensor(vals, dtype=self.torch.float64, device=self.stats.device)
-            self._allreduce(t)
-            return [float(v) for v in t.tolist()]
-
-        cent, sd = global_standardise(local_sum, centre_and_sumsq, n_tot, reduce_floats)
-        call("obhip_affine_dev", self.y.data_ptr(), self.n, 0.0, sd)
-        self.y_cent, self.y_sca = cent, sd
+    def _pull_standardisation(self):
+        cent, sca, ntot = self.meansd.tolist()     # one small D2H (synchronises)
+        self.y_cent, self.y_sca = cent, sca
+        if int(round(ntot)) != self.n_total:
+            raise RuntimeError("ranks disagree on the row count: %r vs %r" % (ntot, self.n_total))
         # loglik_std.cpp:51: para0 = log(0.01 * var(y)); var of the standardised y is 1
         self.sigma = math.log(0.01)
+
+    # -- y = (y - mean) / sd over ALL ranks (R/fitting.R:55-57), PCG back end -----------
+    def standardise(self):
+        """One 3-scalar exchange: (sum y, sum y^2, n) summed over ranks; the Gram back end
+        carries the same three numbers inside its one buffer instead."""
+        call("obhip_sum_sumsq_dev", self.y_raw.data_ptr(), self.n, self.stats.data_ptr())
+        self.stats[2] = float(self.n)
+        if self.comm is not None:
+            call("obhip_comm_allreduce_dev", self.comm, self.stats.data_ptr(), 3)
+        s1, s2, nt = self.stats[:3].tolist()
+        cent = s1 / nt
+        sca = math.sqrt(max(s2 - nt * cent * cent, 0.0) / (nt - 1.0))
+        self.meansd.copy_(self.torch.tensor([cent, sca, nt], dtype=self.torch.float64))
+        self.y.copy_(self.y_raw)
+        call("obhip_affine_dev", self.y.data_ptr(), self.n, cent, sca)
+        self._pull_standardisation()
 
     def fit(self):
         torch = self.torch
         call("obhip_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        self.standardise()
         if self.basis is None:
             h = C.c_void_p()
             call("obhip_basis_create_dev", C.byref(h), self.om._h, self.x.data_ptr(), self.n,
@@ -184,23 +211,38 @@ class HotPath:
         else:
             call("obhip_basis_rebuild", self.basis)
         if self.backend == "newton":
-            call("obhip_gram_dev", self.basis, self.t._h, self.y.data_ptr(), self.G.data_ptr(),
+            # local pieces: G_r, B_r^T y_r (raw y), B_r^T 1, (sum y, sum y^2)
+            call("obhip_sum_sumsq_dev", self.y_raw.data_ptr(), self.n, self.stats.data_ptr())
+            call("obhip_gram_dev", self.basis, self.t._h, self.y_raw.data_ptr(), self.G.data_ptr(),
                  self.g.data_ptr())
-            merge_normal_equations(self.G, self.g, self._allreduce)
+            call("obhip_basis_tmm_dev", self.basis, self.t._h, self.ones.data_ptr(),
+                 self.b1.data_ptr(), 0)
+            # the one exchange (no sum with one rank) + standardisation of the right-hand side
+            call("obhip_normal_eq_exchange_dev", self.comm, self.p, self.n, self.G.data_ptr(),
+                 self.g.data_ptr(), self.b1.data_ptr(), self.stats.data_ptr(), self.exbuf_ptr,
+                 self.ex_count, self.meansd.data_ptr())
+            self.sigma = math.log(0.01)
             call("obhip_newton_solve_dev", self.om._h, self.t._h, self.G.data_ptr(),
                  self.g.data_ptr(), self.sigma, self.rho, self.theta.data_ptr(),
                  self.diagH.data_ptr(), self.ws.data_ptr(), self.wsb)
+            self._pull_standardisation()
         else:
+            self.standardise()
             self.theta.zero_()
             iters, val = C.c_uint64(0), C.c_double(0)
             maxit = self.cg_maxit
             if maxit is None:
-                maxit = getsteps(self.p, self.n * self.world, 1.0 / math.exp(2 * self.sigma))
+                maxit = getsteps(self.p, self.n_total, 1.0 / math.exp(2 * self.sigma))
             call("obhip_fit_cg_dev", self.basis, self.t._h, self.om._h, self.y.data_ptr(),
                  self.sigma, self.rho, self.cg_tol, int(maxit), self.theta.data_ptr(),
-                 C.byref(iters), self.diagH.data_ptr(), C.byref(val),
-                 C.cast(self._cb, C.c_void_p) if self._cb is not None else None, None)
+                 C.byref(iters), self.diagH.data_ptr(), C.byref(val), self.comm)
             self.cg_iters = iters.value
+
+    def standardised_targets(self):
+        """(y - cent) / sca of this rank's rows (tests, parity checks)."""
+        y = self.y_raw.clone()
+        call("obhip_affine_dev", y.data_ptr(), self.n, self.y_cent, self.y_sca)
+        return y
 
     def predict(self):
         call("obhip_predict_dev", self.om._h, self.t._h, self.theta.data_ptr(),
@@ -217,11 +259,15 @@ class HotPath:
         if self.basis is not None:
             _lib.lib.obhip_basis_destroy(self.basis)
             self.basis = None
+        if self.comm is not None:
+            _lib.lib.obhip_comm_destroy(self.comm)
+            self.comm = None
 
 
 def getsteps(numb, sampsize, sigtonoiseratio=1e-3, tol=0.001):
     """.getsteps (R/fitting.R:188-195): CG iteration cap used by obfit."""
     r = math.sqrt(numb / sampsize)
-    kapp = min(1000.0, (1 + r) ** 2 / (1 - r) ** 2)
+    # R: (1 + r)^2 / (1 - r)^2 is Inf at r = 1 and min(1000, Inf) = 1000
+    kapp = 1000.0 if r == 1.0 else min(1000.0, (1 + r) ** 2 / (1 - r) ** 2)
     iterest = 0.5 * math.sqrt(kapp) * math.log(2 * sampsize * sigtonoiseratio / tol)
     return int(math.ceil(2 * iterest))

@@ -194,7 +194,8 @@ def _genknotlist(bassize, x):
 
 def _getsteps(numb, sampsize, sigtonoiseratio=1e-3, tol=0.001):
     r = math.sqrt(numb / sampsize)
-    kapp = min(1000.0, (1 + r) ** 2 / (1 - r) ** 2)
+    # R: (1 + r)^2 / (1 - r)^2 is Inf at r = 1 (numb == sampsize) and min(1000, Inf) = 1000
+    kapp = 1000.0 if r == 1.0 else min(1000.0, (1 + r) ** 2 / (1 - r) ** 2)
     return int(math.ceil(2 * 0.5 * math.sqrt(kapp) * math.log(2 * sampsize * sigtonoiseratio / tol)))
 
 

@@ -14,9 +14,12 @@ def pytest_configure(config):
 
 
 def _have_gpu():
+    # device_count() does not initialise the HIP runtime in this process (is_available()
+    # does): tests that start their own rank processes must be able to do so from a parent
+    # that has not touched the GPU yet
     try:
         import torch
-        return torch.cuda.is_available()
+        return torch.cuda.device_count() > 0
     except Exception:
         return False
 

@@ -1,0 +1,110 @@
+"""The N > 1 DEVICE path on the one GPU of the test box: two rank
+processes share the GPU, each runs the device HotPath on its own contiguous row block, and
+the one exchange buffer (packed triangle of G, B^T y, B^T 1, 3 scalars) is summed through
+libobhip's host transport over gloo.  Compared with (a) the single-process device run on
+all the rows and (b) the CPU oracle, both to 1e-6 relative as north_star asks.
+
+This file sorts first and starts its rank processes before the pytest process itself has
+touched the GPU; every GPU-using process here is a child with a fresh HIP runtime.
+"""
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "rank_worker.py")
+KINDS = ["mat25", "mat25pow", "mat25", "mat25ang", "mat25", "mat25pow"]
+KNOTS = 24
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_ranks(out_dir, world, backend, n_total, p):
+    os.makedirs(out_dir, exist_ok=True)
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(
+            [sys.executable, WORKER, str(out_dir), backend, str(n_total), str(p), str(KNOTS),
+             ",".join(KINDS)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    for rank, pr in enumerate(procs):
+        assert pr.returncode == 0, "rank %d failed:\n%s" % (rank, outs[rank][-3000:])
+    return [np.load(os.path.join(out_dir, "rank%d.npz" % r)) for r in range(world)]
+
+
+def _oracle(n_total, p, rows_pred):
+    """CPU oracle on all rows in one piece.  It takes the eigen-rotation of the library's
+    own host-side model (no GPU involved), as every parity test does: trailing eigenpairs
+    are not determined by either eigensolver."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    om = O.OuterMod()
+    om.setcovfs(KINDS)
+    om.setknot(O.bench_knots(KINDS, KNOTS))
+    om_d = ob.outermod()
+    ob.setcovfs(om_d, KINDS)
+    ob.setknot(om_d, O.bench_knots(KINDS, KNOTS))
+    om.rotmat, om.basisvar, om.maxlevel = om_d.rotation()
+    terms = om.selectterms(p)
+    assert np.array_equal(terms, om_d.selectterms(p))
+    x, y = O.synth_xy(42, 0, n_total, KINDS)
+    cent, sd = y.mean(), y.std(ddof=1)
+    theta, _ = O.fit_newton(O.OuterBase(om, x), terms, (y - cent) / sd, sigma=math.log(0.01))
+    xnew, _ = O.synth_xy(43, 0, rows_pred, KINDS)
+    return cent, sd, theta, cent + sd * O.predict_mean(om, terms, theta, xnew)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("backend", ["newton", "cg"])
+def test_two_rank_device_path_equals_single_process_and_oracle(tmp_path, backend):
+    n_total, p = 6001, 300       # ragged split: 3000 + 3001 rows
+    two = _run_ranks(tmp_path / "w2", 2, backend, n_total, p)
+    one = _run_ranks(tmp_path / "w1", 1, backend, n_total, p)[0]
+    assert [int(r["n"]) for r in two] == [3000, 3001] and int(two[1]["row0"]) == 3000
+    assert all(int(r["ranks"]) == 2 for r in two)
+    # replicated solve: the same theta on both ranks, bit for bit (Newton: same summed
+    # buffer, same arithmetic)
+    if backend == "newton":
+        assert np.array_equal(two[0]["theta"], two[1]["theta"])
+        assert np.array_equal(two[0]["G00"], two[1]["G00"])
+    scale = np.max(np.abs(one["theta"]))
+    for r in two:
+        assert abs(r["cent"] - one["cent"]) < 1e-12 * max(1.0, abs(one["cent"]))
+        assert abs(r["sd"] - one["sd"]) < 1e-12 * one["sd"]
+        assert np.max(np.abs(r["theta"] - one["theta"])) < 1e-6 * scale
+    # predictions of the two shards side by side == the single-process predictions
+    mean2 = np.concatenate([two[0]["mean"], two[1]["mean"]])
+    assert mean2.shape == one["mean"].shape
+    assert np.max(np.abs(mean2 - one["mean"])) < 1e-6 * np.max(np.abs(one["mean"]))
+    # and the CPU oracle on all rows in one piece
+    cent, sd, theta_o, want = _oracle(n_total, p, 500)
+    assert abs(one["cent"] - cent) < 1e-10 * max(1.0, abs(cent)) and abs(one["sd"] - sd) < 1e-10 * sd
+    assert np.max(np.abs(mean2[:500] - want)) < 1e-6 * np.max(np.abs(want))
+    if backend == "newton":
+        assert np.max(np.abs(two[0]["theta"] - theta_o)) < 1e-6 * np.max(np.abs(theta_o))
+    else:
+        assert int(two[0]["iters"]) == int(one["iters"]) > 0

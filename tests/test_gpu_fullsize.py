@@ -28,9 +28,11 @@ def _vec(torch, n):
 
 
 def test_standardised_targets(hot):
-    y = hot.y.cpu().numpy()
+    # standardised over all rows with the one-pass sums the exchange buffer carries
+    # (sum y, sum y^2, n): exact up to eps (1 + mean^2 / var) and the summation order
+    y = hot.standardised_targets().cpu().numpy()
     assert abs(y.mean()) < 1e-12
-    assert abs(y.var(ddof=1) - 1.0) < 1e-12
+    assert abs(y.var(ddof=1) - 1.0) < 1e-11
 
 
 def test_gram_is_consistent_with_matrix_free_kernels(hot):
@@ -39,7 +41,8 @@ def test_gram_is_consistent_with_matrix_free_kernels(hot):
     p, n = hot.p, hot.n
     G = torch.empty((p, p), dtype=torch.float64, device="cuda")
     g = _vec(torch, p)
-    call("obhip_gram_dev", hot.basis, hot.t._h, hot.y.data_ptr(), G.data_ptr(), g.data_ptr())
+    y = hot.standardised_targets()
+    call("obhip_gram_dev", hot.basis, hot.t._h, y.data_ptr(), G.data_ptr(), g.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(G, G.T)
     # diag(B^T B) == column sums of B^2 (modandbase.cpp:863-867)
@@ -59,9 +62,11 @@ def test_gram_is_consistent_with_matrix_free_kernels(hot):
     assert float((Ga - BtBa).abs().max() / Ga.abs().max()) < 1e-11
     # g == B^T y through an independent launch
     g2 = _vec(torch, p)
-    call("obhip_basis_tmm_dev", hot.basis, hot.t._h, hot.y.data_ptr(), g2.data_ptr(), 0)
+    call("obhip_basis_tmm_dev", hot.basis, hot.t._h, y.data_ptr(), g2.data_ptr(), 0)
     torch.cuda.synchronize()
     assert torch.equal(g, g2)
+    # the right-hand side the fit used, (B^T y_raw - cent B^T 1) / sca, is the same vector
+    assert float((hot.g - g).abs().max() / g.abs().max()) < 1e-11
 
 
 def test_mm_is_linear(hot):
@@ -108,7 +113,7 @@ def test_fused_predictor_equals_stored_basis_path(hot):
     torch.cuda.synchronize()
     assert float((via_mm - via_pred).abs().max() / via_mm.abs().max()) < 1e-12
     # and the fit explains the data: residual variance well below the prior noise guess
-    resid = via_mm - hot.y
+    resid = via_mm - hot.standardised_targets()
     assert float(resid.var()) < 0.5
 
 
@@ -162,6 +167,28 @@ def test_config1_d10_n1e5_p1024():
     torch.cuda.synchronize()
     try:
         _fit_is_stationary(hp, 1e-10)
+    finally:
+        hp.close()
+
+
+def test_config3_one_rank_shard_d20_1p25e6_rows_p4096():
+    """BASELINE.json configs[3] (d=20, n=1e7, p=4096, rows sharded over 8 GPUs): one rank's
+    1.25e6-row shard (rank 3's rows of the stream) through the same path as the headline --
+    41 GB design matrix, Gram, Cholesky, fused predictor -- checked by the properties that
+    hold at any size.  The 8-rank sum itself is what tests/test_00_two_rank_device.py
+    exercises on the device path."""
+    import torch
+    from outerbase_amd.driver import HotPath, shard_rows
+    row0, n = shard_rows(3, 8, 10_000_000)
+    assert (row0, n) == (3_750_000, 1_250_000)
+    hp = HotPath(["mat25"] * 20, 40, 4096, n, row0=row0, n_total=n)
+    hp.setup()
+    hp.step()
+    torch.cuda.synchronize()
+    try:
+        _fit_is_stationary(hp, 1e-10)
+        y = hp.standardised_targets()
+        assert abs(float(y.mean())) < 1e-12 and abs(float(y.var()) - 1.0) < 1e-11
     finally:
         hp.close()
 
