@@ -119,6 +119,21 @@ def check_against_oracle(hp, rows=2000):
     return out
 
 
+def host_threads():
+    """Threads the CPU leg runs on: the reference takes omp_get_num_procs()
+    (src/modandbase.cpp:464); inside a container that is the cores this process may use --
+    its affinity mask, cut by the cgroup's CPU quota where one is set (a GPU box hands each
+    lease a share of the host, not the whole host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(float(quota) / float(period)))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(hp, ns):
     """CPU restatement of the reference path timed on the host cores (test infrastructure,
     oracle/): the reference's own loops (outerbase::build, getm_, prodmm_, tprodmm_) in
@@ -137,7 +152,7 @@ def cpu_baseline(hp, ns):
         from threadpoolctl import threadpool_limits
     except Exception:
         threadpool_limits = None
-    threads = os.cpu_count() or 1
+    threads = host_threads()
     ns = min(ns, hp.n)
     use_cpp = ob_cpu.available()
 
@@ -214,7 +229,7 @@ def cpu_baseline(hp, ns):
                        "2 (iters + 1) such passes per fit as lpdf::optcg makes them" % threads}
     return {"value": hp.n / full, "unit": "points/s", "cores": threads, "kind": "port",
             "host_cpu_count": os.cpu_count(), "pcg_path": pcg,
-            "sample": "%s + NumPy BLAS/LAPACK for B^T B and solve, %d threads (= os.cpu_count()), "
+            "sample": "%s + NumPy BLAS/LAPACK for B^T B and solve, %d threads (affinity / cgroup share of the host), "
                       "%d rows of the same workload: build %.2fs getmat %.2fs gram %.2fs solve %.2fs "
                       "predict %.2fs; row work scaled to n=%d, solve counted once"
                       % (impl, threads, ns, t["build"], t["getmat"], t["gram"], t["solve"],
@@ -392,9 +407,9 @@ def main():
         torch.cuda.synchronize()
         pcie = (time.perf_counter() - t0) * 1e3
         hp.setup_inputs()          # restore the synthetic inputs the copies overwrote
-        hp.step()
-        torch.cuda.synchronize()
         del hx, hy
+    hp.step()                      # every rank: the fit sums over ranks
+    sync()
 
     # the other back end on the same inputs, for the record (untimed region; every rank
     # takes part because the fit sums over ranks): B = matrix-free PCG, what obfit() runs

@@ -5,6 +5,7 @@ transport carries the exchange buffer.  Writes theta / predictions / standardisa
 this rank to <out>/rank<r>.npz.
 
 usage: rank_worker.py <out_dir> <backend: newton|cg> <n_total> <p> <knots> <kinds,comma>
+                      [cg_tol cg_maxit]
        (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT from the environment)
 """
 import os
@@ -20,6 +21,8 @@ def main():
     out_dir, backend, n_total, p, knots, kinds = sys.argv[1:7]
     n_total, p, knots = int(n_total), int(p), int(knots)
     kinds = kinds.split(",")
+    cg_tol = float(sys.argv[7]) if len(sys.argv) > 7 else 1e-10
+    cg_maxit = int(sys.argv[8]) if len(sys.argv) > 8 else None
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
@@ -30,7 +33,8 @@ def main():
     from outerbase_amd.driver import HotPath, shard_rows
     row0, n = shard_rows(rank, world, n_total)
     hp = HotPath(kinds, knots, p, n, rank=rank, world=world, backend=backend, row0=row0,
-                 n_total=n_total, transport="host" if world > 1 else None)
+                 n_total=n_total, transport="host" if world > 1 else None, cg_tol=cg_tol,
+                 cg_maxit=cg_maxit)
     hp.setup()
     hp.step()
     hp.step()          # a second step: the exchange buffer and the basis are reused

@@ -32,7 +32,7 @@ def _free_port():
     return port
 
 
-def _run_ranks(out_dir, world, backend, n_total, p):
+def _run_ranks(out_dir, world, backend, n_total, p, extra=()):
     os.makedirs(out_dir, exist_ok=True)
     port = _free_port()
     procs = []
@@ -41,7 +41,7 @@ def _run_ranks(out_dir, world, backend, n_total, p):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen(
             [sys.executable, WORKER, str(out_dir), backend, str(n_total), str(p), str(KNOTS),
-             ",".join(KINDS)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+             ",".join(KINDS)] + [str(e) for e in extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for pr in procs:
         try:
@@ -82,8 +82,12 @@ def _oracle(n_total, p, rows_pred):
 @pytest.mark.parametrize("backend", ["newton", "cg"])
 def test_two_rank_device_path_equals_single_process_and_oracle(tmp_path, backend):
     n_total, p = 6001, 300       # ragged split: 3000 + 3001 rows
-    two = _run_ranks(tmp_path / "w2", 2, backend, n_total, p)
-    one = _run_ranks(tmp_path / "w1", 1, backend, n_total, p)[0]
+    # PCG: run to convergence (tol 1e-13) -- stopped at obfit's iteration cap this small,
+    # badly conditioned problem is far from converged, and unconverged CG iterates are not
+    # reproducible to rounding across summation orders
+    extra = (1e-13, 5000) if backend == "cg" else ()
+    two = _run_ranks(tmp_path / "w2", 2, backend, n_total, p, extra)
+    one = _run_ranks(tmp_path / "w1", 1, backend, n_total, p, extra)[0]
     assert [int(r["n"]) for r in two] == [3000, 3001] and int(two[1]["row0"]) == 3000
     assert all(int(r["ranks"]) == 2 for r in two)
     # replicated solve: the same theta on both ranks, bit for bit (Newton: same summed
@@ -95,7 +99,8 @@ def test_two_rank_device_path_equals_single_process_and_oracle(tmp_path, backend
     for r in two:
         assert abs(r["cent"] - one["cent"]) < 1e-12 * max(1.0, abs(one["cent"]))
         assert abs(r["sd"] - one["sd"]) < 1e-12 * one["sd"]
-        assert np.max(np.abs(r["theta"] - one["theta"])) < 1e-6 * scale
+        if backend == "newton":
+            assert np.max(np.abs(r["theta"] - one["theta"])) < 1e-6 * scale
     # predictions of the two shards side by side == the single-process predictions
     mean2 = np.concatenate([two[0]["mean"], two[1]["mean"]])
     assert mean2.shape == one["mean"].shape
@@ -107,4 +112,7 @@ def test_two_rank_device_path_equals_single_process_and_oracle(tmp_path, backend
     if backend == "newton":
         assert np.max(np.abs(two[0]["theta"] - theta_o)) < 1e-6 * np.max(np.abs(theta_o))
     else:
-        assert int(two[0]["iters"]) == int(one["iters"]) > 0
+        # same iterates on both ranks (every reduction is a sum over ranks); theta itself is
+        # not pinned in the flat directions of the posterior, the predictions are
+        assert np.array_equal(two[0]["theta"], two[1]["theta"])
+        assert 0 < int(two[0]["iters"]) == int(two[1]["iters"]) < 5000
