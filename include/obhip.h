@@ -51,6 +51,8 @@ extern "C" {
 typedef struct obhip_model obhip_model; /* class outermod, modandbase.h:9-54 */
 typedef struct obhip_basis obhip_basis; /* class outerbase, modandbase.h:57-125 */
 typedef struct obhip_terms obhip_terms; /* a umat `terms` resident on device */
+typedef struct obhip_lpdf obhip_lpdf;   /* class lpdf and descendants, fit.h:23-361 */
+typedef struct obhip_predictor obhip_predictor; /* class predictor, fit.h:352-361 */
 typedef struct obhip_comm obhip_comm;   /* the ranks of a row-sharded job (no reference
                                            counterpart: the reference is one process,
                                            modandbase.cpp:464) */
@@ -366,6 +368,107 @@ int obhip_predict_std(const obhip_model *m, const obhip_terms *t, const double *
 int obhip_margadj_full(const obhip_basis *b, const obhip_terms *t, const obhip_model *m,
                        const double *H, double sigma, double rho, double *val, double *gradhyp,
                        double *gradpara);
+
+/* ---- the model layer: lpdf, loglik_*, logpr_gauss, lpdfvec, predictor ------------------
+ * Module rows src/interfaceR.cpp:696-762; classes src/fit.h:23-361; arithmetic
+ * src/fit.cpp:37-612 and src/lpdfs/{loglik_std,loglik_gauss,loglik_gda,logpr_gauss}.cpp.
+ * One handle type for every descendant of class lpdf; y, yhat, the residuals and the
+ * observation standard deviations of an object stay in HBM between calls, so a call moves
+ * p-, nhyp- and npara-sized vectors only.  Objects reference each other like the C++
+ * objects of the reference do (fit.h:133,153): the caller keeps the outermod alive as long
+ * as a likelihood or prior built on it, and the two members as long as their lpdfvec. */
+#define OBHIP_LPDF_LOGLIK_STD 0   /* class loglik_std,   src/lpdfs/loglik_std.cpp:41-203 */
+#define OBHIP_LPDF_LOGLIK_GAUSS 1 /* class loglik_gauss, src/lpdfs/loglik_gauss.cpp:41-172 */
+#define OBHIP_LPDF_LOGLIK_GDA 2   /* class loglik_gda,   src/lpdfs/loglik_gda.cpp:48-235 */
+#define OBHIP_LPDF_LOGPR_GAUSS 3  /* class logpr_gauss,  src/lpdfs/logpr_gauss.cpp:41-186 */
+#define OBHIP_LPDF_VEC 4          /* class lpdfvec,      src/fit.cpp:174-612 */
+/* new(loglik_std | loglik_gauss | loglik_gda, om, terms, y, x): interfaceR.cpp:733-750.
+ * terms p x d column-major, y n, x n x d column-major with leading dimension ldx (host). */
+int obhip_loglik_create(obhip_lpdf **out, int kind, const obhip_model *om, const uint64_t *terms,
+                        uint64_t p, const double *y, const double *x, uint64_t n, uint64_t ldx);
+/* new(logpr_gauss, om, terms): interfaceR.cpp:752-756 */
+int obhip_logpr_gauss_create(obhip_lpdf **out, const obhip_model *om, const uint64_t *terms,
+                             uint64_t p);
+/* new(lpdfvec, a, b): interfaceR.cpp:758-762, fit.cpp:174-200; para = [a.para, b.para] */
+int obhip_lpdfvec_create(obhip_lpdf **out, obhip_lpdf *a, obhip_lpdf *b);
+int obhip_lpdf_destroy(obhip_lpdf *l);
+/* kind, nterms (field, interfaceR.cpp:709), npara, number of hyper-parameters of the model,
+ * rows of the likelihood's data (0 for the prior); any pointer may be NULL */
+int obhip_lpdf_dims(const obhip_lpdf *l, int *kind, uint64_t *nterms, uint64_t *npara,
+                    uint64_t *nhyp, uint64_t *n);
+/* boolean fields: compute_* (interfaceR.cpp:698-701; this ABI names them by what they do --
+ * the reference module binds R's compute_gradpara to C++ compute_gradhyp and vice versa),
+ * fullhess (read-only, :702), lpdfvec's domarg (:761), loglik_gda's dodiag (:748) */
+#define OBHIP_FLAG_COMPUTE_VAL 0
+#define OBHIP_FLAG_COMPUTE_GRAD 1
+#define OBHIP_FLAG_COMPUTE_GRADHYP 2
+#define OBHIP_FLAG_COMPUTE_GRADPARA 3
+#define OBHIP_FLAG_FULLHESS 4
+#define OBHIP_FLAG_DOMARG 5
+#define OBHIP_FLAG_DODIAG 6
+int obhip_lpdf_get_flag(const obhip_lpdf *l, int flag, int *value);
+int obhip_lpdf_set_flag(obhip_lpdf *l, int flag, int value);
+/* field val (interfaceR.cpp:703) */
+int obhip_lpdf_get_val(const obhip_lpdf *l, double *val);
+/* vector fields (interfaceR.cpp:704-708,737,743,749,755; para0 / paravar fit.h:59-60;
+ * totdiaghess fit.h:33): out may be NULL to query the length */
+#define OBHIP_VEC_COEFF 0
+#define OBHIP_VEC_GRAD 1
+#define OBHIP_VEC_GRADHYP 2
+#define OBHIP_VEC_GRADPARA 3
+#define OBHIP_VEC_PARA 4
+#define OBHIP_VEC_PARA0 5
+#define OBHIP_VEC_PARAVAR 6
+#define OBHIP_VEC_TOTDIAGHESS 7
+#define OBHIP_VEC_COEFFSD 8 /* logpr_gauss only */
+#define OBHIP_VEC_YHAT 9    /* likelihoods only; copied from HBM */
+int obhip_lpdf_get_vec(const obhip_lpdf *l, int which, double *out, uint64_t cap, uint64_t *len);
+/* names of the parameters, getpara(lpdf): interfaceR.cpp:193-199 */
+int obhip_lpdf_paraname(const obhip_lpdf *l, uint64_t i, const char **name);
+/* the umat `terms` of the object (fit.h:31), p x d column-major */
+int obhip_lpdf_terms(const obhip_lpdf *l, uint64_t *terms_out);
+/* the outerbase a likelihood owns (member `ob`, fit.h:185,237,273) and the device form of
+ * its terms; borrowed handles, valid until the next updateterms / destroy */
+int obhip_lpdf_basis(obhip_lpdf *l, obhip_basis **b, obhip_terms **t);
+/* lpdf$setnthreads (interfaceR.cpp:710): accepted and ignored on the device */
+int obhip_lpdf_setnthreads(obhip_lpdf *l, int nthreads);
+/* lpdf$update(coeff): loglik_gauss.cpp:110-130, loglik_std.cpp:100-120, loglik_gda.cpp:117-153,
+ * logpr_gauss.cpp:113-121, lpdfvec fit.cpp:323-380 (marginal adjustment included) */
+int obhip_lpdf_update(obhip_lpdf *l, const double *coeff, uint64_t ncoeff);
+/* lpdf$updateom() / updatepara(para) / updateterms(terms): interfaceR.cpp:714-716 */
+int obhip_lpdf_updateom(obhip_lpdf *l);
+int obhip_lpdf_updatepara(obhip_lpdf *l, const double *para, uint64_t npara);
+int obhip_lpdf_updateterms(obhip_lpdf *l, const uint64_t *terms, uint64_t p);
+/* lpdf$hessmult(g) -> p; diaghess() -> p; diaghessgradhyp() -> p x nhyp;
+ * diaghessgradpara() -> p x npara (column-major): interfaceR.cpp:717-720 */
+int obhip_lpdf_hessmult(obhip_lpdf *l, const double *g, double *out);
+int obhip_lpdf_diaghess(obhip_lpdf *l, double *out);
+int obhip_lpdf_diaghessgradhyp(obhip_lpdf *l, double *out);
+int obhip_lpdf_diaghessgradpara(obhip_lpdf *l, double *out);
+/* hess() (fit.h:81; loglik_std.cpp:170-173, logpr_gauss.cpp:167-172, lpdfvec::hess_
+ * fit.cpp:503-512): p x p, formed on the device by the Gram kernels */
+int obhip_lpdf_hess(obhip_lpdf *l, double *out);
+/* lpdf$optcg(tol, maxepch) (fit.cpp:37-96; iters may be NULL) and lpdf$optnewton()
+ * (fit.cpp:98-131) */
+int obhip_lpdf_optcg(obhip_lpdf *l, double tol, uint64_t maxepch, uint64_t *iters);
+int obhip_lpdf_optnewton(obhip_lpdf *l);
+/* lpdf$paralpdf(para) / paralpdf_grad(para): fit.cpp:133-157, lpdfvec fit.cpp:470-496 */
+int obhip_lpdf_paralpdf(const obhip_lpdf *l, const double *parap, uint64_t n, double *out);
+int obhip_lpdf_paralpdf_grad(const obhip_lpdf *l, const double *parap, uint64_t n, double *out);
+
+/* new(predictor, lpdf) (interfaceR.cpp:725-731, lpdf::pred fit.h:51-55): the predictor of the
+ * likelihood -- predr_std (loglik_std.cpp:218-256), pred_gauss (loglik_gauss.cpp:196-227),
+ * pred_gda (loglik_gda.cpp:247-281); an lpdfvec stands for its likelihood.  Starts at the
+ * training inputs like the reference. */
+int obhip_predictor_create(obhip_predictor **out, const obhip_lpdf *l);
+int obhip_predictor_destroy(obhip_predictor *p);
+int obhip_predictor_setnthreads(obhip_predictor *p, int nthreads);
+/* predictor$update(x): x n x d column-major, leading dimension ldx (host) */
+int obhip_predictor_update(obhip_predictor *p, const double *x, uint64_t n, uint64_t ldx);
+int obhip_predictor_n(const obhip_predictor *p, uint64_t *n);
+/* predictor$mean() / $var(): n values */
+int obhip_predictor_mean(obhip_predictor *p, double *out);
+int obhip_predictor_var(obhip_predictor *p, double *out);
 
 /* ---- synthetic workload of BASELINE.md section 3 (benchmark input) ------ */
 /* rows [row0, row0+n) of the counter-based SplitMix64 stream; d_x is n x d

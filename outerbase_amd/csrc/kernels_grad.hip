@@ -1110,3 +1110,39 @@ int obhip_basis_tmm_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const 
 }
 
 }  // extern "C"
+
+// ---- device-level forms for the likelihood classes (lpdf.cpp): inputs and the n-sized
+// results stay in HBM, only p- and nhyp-sized results go to the host -----------------------
+namespace obhip {
+
+// dge (n x nhyp, device) = d(B a)/dhyp (squared: d(B^2 a)/dhyp), d_M = B a (B^2 a);
+// a_host / d_a: the same p coefficients on the host and on the device
+int grad_mm_dev(obhip_basis &b, obhip_terms &t, bool squared, const double *a_host, const double *d_a,
+                double *d_M, DevBuf<double> &dge) {
+  OB_TRY(check_grad_args(&b, &t));
+  OB_TRY(squared ? ensure_gradbasis_sq(b) : ensure_gradbasis(b));
+  return mm_gradhyp_dev(b, t, squared, a_host, d_a, d_M, dge);
+}
+
+// out_host[c] = sum_i w_i G[i + c n], c < ncol (G: n x ncol column-major, device)
+int grad_wdot_dev(const double *d_G, const double *d_w, uint64_t n, uint64_t ncol, double *out_host) {
+  if (ncol == 0) return 0;
+  constexpr int nblk = 256;
+  DevBuf<double> dpart, dres;
+  OB_TRY(dpart.alloc(ncol * nblk));
+  OB_TRY(dres.alloc(ncol));
+  hipLaunchKernelGGL(k_wdot1, dim3(nblk, (unsigned)ncol), dim3(256), 0, cur_stream(), d_G, d_w, n,
+                     dpart.p);
+  hipLaunchKernelGGL(k_wdot2, dim3((unsigned)ncol), dim3(64), 0, cur_stream(), dpart.p, nblk, dres.p);
+  OB_HIP(hipGetLastError());
+  return d2h(out_host, dres.p, ncol * sizeof(double));
+}
+
+// out_host (p x nhyp column-major) = sum_i a_i dB_ik/dhyp_h (squared: of B^2)
+int grad_tmm_host(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a, double *out_host) {
+  OB_TRY(check_grad_args(&b, &t));
+  OB_TRY(squared ? ensure_gradbasis_sq(b) : ensure_gradbasis(b));
+  return tmm_gradhyp_all(b, t, squared, d_a, out_host);
+}
+
+}  // namespace obhip

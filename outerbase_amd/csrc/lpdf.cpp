@@ -1,0 +1,1330 @@
+// The statistical-model layer of the reference behind the C ABI: class lpdf and its
+// descendants (src/fit.h:23-361, src/fit.cpp:37-612, src/lpdfs/*.cpp; module rows
+// src/interfaceR.cpp:696-762) as handles of libobhip.  Every n-vector (y, yhat, residuals,
+// observation standard deviations and their gradients) lives in HBM for the life of the
+// object; what crosses the ABI per call are p-, nhyp- and npara-sized vectors.  Every pass
+// over the n rows is one of the HIP kernels of kernels_*.hip; the element-wise algebra the
+// reference writes as Armadillo expressions is a device lambda here (vec_ops.h).
+//
+//   obhip_lpdf       lpdf (fit.h:23-90): loglik_std | loglik_gauss | loglik_gda | logpr_gauss
+//                    | lpdfvec, one struct per class with the reference's member names
+//   obhip_predictor  predictor / predf (fit.h:9-20,352-361): predr_std | pred_gauss | pred_gda
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "obhip_internal.h"
+#include "vec_ops.h"
+
+using namespace obhip;
+
+namespace obhip {
+int launch_colnorm2(const double *d_Z, uint64_t ld, uint64_t p, uint64_t n, double add,
+                    double *d_out);
+}
+
+namespace {
+
+int d2h(void *dst, const void *src, size_t bytes) {
+  OB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cur_stream()));
+  OB_HIP(hipStreamSynchronize(cur_stream()));
+  return 0;
+}
+
+int h2d(void *dst, const void *src, size_t bytes) {  // src may be a temporary: synchronous
+  OB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cur_stream()));
+  OB_HIP(hipStreamSynchronize(cur_stream()));
+  return 0;
+}
+
+// var(y) with the n - 1 denominator (arma::var, loglik_std.cpp:51)
+double sample_var(const double *y, uint64_t n) {
+  double m = 0;
+  for (uint64_t i = 0; i < n; ++i) m += y[i];
+  m /= (double)n;
+  double s = 0;
+  for (uint64_t i = 0; i < n; ++i) s += (y[i] - m) * (y[i] - m);
+  return n > 1 ? s / (double)(n - 1) : 0.0;
+}
+
+}  // namespace
+
+// ---- lpdf (fit.h:23-90) -----------------------------------------------------------------
+struct obhip_lpdf {
+  int kind = -1;
+  const obhip_model *om = nullptr;
+  double val = 0;
+  std::vector<double> grad, gradhyp, gradpara, para, para0, paravar, coeff, totdiaghess;
+  DevBuf<double> tothess;  // p x p, full symmetric storage (settothess)
+  bool didfulltothess = false, didnotothess = true, fullhess = false;
+  std::vector<std::string> paranames;
+  bool compute_val = true, compute_grad = true, compute_gradhyp = false, compute_gradpara = false;
+  uint64_t npara = 0, nterms = 0;
+  std::vector<uint64_t> terms;  // p x d column-major levels (umat)
+  uint64_t cgiters = 0;
+
+  virtual ~obhip_lpdf() {}
+  uint64_t nhyp() const { return om ? om->nhyp() : 0; }
+
+  virtual int updateom() { return 0; }
+  virtual int updatepara(const double *, uint64_t) { return 0; }
+  virtual int updateterms(const uint64_t *, uint64_t) { return 0; }
+  virtual int update(const double *) { return 0; }
+  virtual int hessmult(const double *, double *) { return fail(OBHIP_ERR_STATE, "lpdf: no hessmult"); }
+  virtual int diaghess(double *) { return fail(OBHIP_ERR_STATE, "lpdf: no diaghess"); }
+  virtual int diaghessgradhyp(double *) { return fail(OBHIP_ERR_STATE, "lpdf: no diaghessgradhyp"); }
+  virtual int diaghessgradpara(double *) { return fail(OBHIP_ERR_STATE, "lpdf: no diaghessgradpara"); }
+  // d_H (p x p, device) = [d_H +] hess(); the reference's base returns an empty matrix
+  virtual int hess_dev(double *, bool) { return fail(OBHIP_ERR_STATE, "this lpdf has no hess()"); }
+  virtual void settotdiaghess(const std::vector<double> &d) {  // fit.h:71-75
+    totdiaghess = d;
+    didfulltothess = false;
+    didnotothess = false;
+  }
+  virtual int settothess(const double *d_H) {  // fit.h:76-80
+    OB_TRY(tothess.alloc(nterms * nterms));
+    OB_HIP(hipMemcpyAsync(tothess.p, d_H, nterms * nterms * sizeof(double), hipMemcpyDeviceToDevice,
+                          cur_stream()));
+    didfulltothess = true;
+    didnotothess = false;
+    return 0;
+  }
+  virtual double paralpdf(const double *parap, uint64_t n) const {  // fit.cpp:133-139
+    if (n != npara) return -std::numeric_limits<double>::infinity();
+    double out = 0;
+    for (uint64_t k = 0; k < n; ++k) out -= 0.5 * (parap[k] - para0[k]) * (parap[k] - para0[k]) / paravar[k];
+    return out;
+  }
+  virtual void paralpdf_grad(const double *parap, uint64_t n, double *out) const {  // fit.cpp:146-157
+    for (uint64_t k = 0; k < para.size(); ++k) out[k] = 0.0;
+    if (n != npara) return;
+    for (uint64_t k = 0; k < n; ++k) out[k] = -(parap[k] - para0[k]) / paravar[k];
+  }
+  virtual int optcg(double tol, uint64_t maxepch);
+  virtual int optnewton();
+  virtual obhip_basis *basis() { return nullptr; }
+};
+
+// lpdf::optcg (fit.cpp:37-96): diagonally preconditioned CG on update / diaghess / hessmult
+int obhip_lpdf::optcg(double tol, uint64_t maxepch) {
+  fullhess = false;
+  compute_val = compute_grad = true;
+  compute_gradhyp = compute_gradpara = false;
+  const uint64_t p = nterms;
+  if (coeff.size() != p) coeff.assign(p, 0.0);
+  std::vector<double> c = coeff;
+  OB_TRY(update(c.data()));
+  std::vector<double> m(p);
+  OB_TRY(diaghess(m.data()));
+  bool mfin = true, gfin = true;
+  for (uint64_t k = 0; k < p; ++k) {
+    mfin = mfin && std::isfinite(m[k]);
+    gfin = gfin && std::isfinite(grad[k]);
+  }
+  cgiters = 0;
+  if (!mfin && !gfin) {  // fit.cpp:53-56
+    val = -std::numeric_limits<double>::infinity();
+    return 0;
+  }
+  std::vector<double> rm(p), pv(p), q(p);
+  for (uint64_t k = 0; k < p; ++k) pv[k] = rm[k] = grad[k] / m[k];
+  OB_TRY(hessmult(pv.data(), q.data()));
+  double valdiff = 10, num0 = -1;
+  uint64_t k = 0;
+  for (k = 0; k < maxepch; ++k) {  // fit.cpp:71-85
+    double num = 0;
+    for (uint64_t i = 0; i < p; ++i) num += grad[i] * rm[i];
+    if (num < tol && valdiff < tol) break;
+    // the three guards of obhip_fit_cg_dev (api.cpp): rounding floor, vanished gradient,
+    // direction without curvature -- the reference divides 0 / 0 there
+    if (num0 < 0) num0 = num;
+    if (num <= 1e-28 * num0 || !(num > 0.0)) break;
+    double denom = 0;
+    for (uint64_t i = 0; i < p; ++i) denom += q[i] * pv[i];
+    if (!(denom > 0.0)) break;
+    const double alpha = num / denom;
+    for (uint64_t i = 0; i < p; ++i) c[i] += alpha * pv[i];
+    const double valo = val;
+    OB_TRY(update(c.data()));
+    valdiff = val - valo;
+    double num2 = 0;
+    for (uint64_t i = 0; i < p; ++i) {
+      rm[i] = grad[i] / m[i];
+      num2 -= (alpha * q[i]) * rm[i];
+    }
+    const double beta = num2 / num;
+    for (uint64_t i = 0; i < p; ++i) pv[i] = rm[i] + beta * pv[i];
+    OB_TRY(hessmult(pv.data(), q.data()));
+  }
+  cgiters = k;
+  compute_gradhyp = compute_gradpara = true;  // fit.cpp:87-93
+  OB_TRY(update(c.data()));
+  compute_gradhyp = compute_gradpara = false;
+  return 0;
+}
+
+// lpdf::optnewton (fit.cpp:98-131): coeff += solve(hess(), grad), Cholesky + two triangular
+// solves on the device (H is positive definite by construction)
+int obhip_lpdf::optnewton() {
+  fullhess = true;
+  compute_val = compute_grad = true;
+  compute_gradhyp = compute_gradpara = false;
+  const uint64_t p = nterms;
+  if (coeff.size() != p) coeff.assign(p, 0.0);
+  std::vector<double> c = coeff;
+  OB_TRY(update(c.data()));
+  DevBuf<double> dH, dr, dstep;
+  DevBuf<char> ws;
+  OB_TRY(dH.alloc(p * p));
+  OB_TRY(hess_dev(dH.p, false));
+  bool gfin = true;
+  for (uint64_t k = 0; k < p; ++k) gfin = gfin && std::isfinite(grad[k]);
+  if (!gfin) {  // fit.cpp:115-118 (h non-finite and r non-finite)
+    val = -std::numeric_limits<double>::infinity();
+    return 0;
+  }
+  OB_TRY(dr.upload(grad.data(), p));
+  OB_TRY(dstep.alloc(p));
+  const uint64_t wsb = newton_workspace_bytes(p);
+  OB_TRY(ws.alloc(wsb));
+  OB_TRY(launch_newton_solve(p, dH.p, dr.p, dstep.p, ws.p, wsb));
+  std::vector<double> step(p);
+  OB_TRY(d2h(step.data(), dstep.p, p * sizeof(double)));
+  for (uint64_t k = 0; k < p; ++k) c[k] += step[k];
+  compute_gradhyp = compute_gradpara = true;  // fit.cpp:122-128
+  OB_TRY(update(c.data()));
+  compute_gradhyp = compute_gradpara = false;
+  return 0;
+}
+
+namespace {
+
+// om.getvar(terms) / om.getlvar_gradhyp(terms) from column-major u64 terms
+// (modandbase.cpp:350-356, 364-379)
+void term_var_lvarge(const obhip_model &m, const std::vector<uint64_t> &terms, uint64_t p,
+                     std::vector<double> &var, std::vector<double> &lvarge /* p x nhyp */) {
+  const uint64_t d = m.d, nh = m.nhyp();
+  var.assign(p, 0.0);
+  lvarge.assign(p * nh, 0.0);
+  for (uint64_t k = 0; k < p; ++k) {
+    double s = 0;
+    for (uint64_t l = 0; l < d; ++l) s += m.basisvar[m.knotptst[l] + terms[l * p + k]];
+    var[k] = std::exp(s);
+  }
+  for (uint64_t h = 0; h < nh; ++h) {
+    const uint64_t l = m.hypmatch[h];
+    for (uint64_t k = 0; k < p; ++k)
+      lvarge[h * p + k] = m.logbasisvar_gradhyp[m.gest[h] + terms[l * p + k]];
+  }
+}
+
+int check_terms(const obhip_model *om, const uint64_t *terms, uint64_t p) {
+  if (!om || !terms || p == 0) return fail(OBHIP_ERR_INVALID, "lpdf: bad model / terms");
+  if (!om->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  for (uint64_t l = 0; l < om->d; ++l)
+    for (uint64_t k = 0; k < p; ++k)
+      if (terms[l * p + k] >= om->m_of(l)) return fail(OBHIP_ERR_INVALID, "terms: level out of range");
+  return 0;
+}
+
+// ---- logpr_gauss (src/lpdfs/logpr_gauss.cpp:41-186) --------------------------------------
+struct LogprGauss : obhip_lpdf {
+  std::vector<double> coeffsd, coefflvarge;  // p, p x nhyp
+  double sca = 1;
+
+  int init(const obhip_model *m, const uint64_t *t, uint64_t p) {
+    OB_TRY(check_terms(m, t, p));
+    kind = OBHIP_LPDF_LOGPR_GAUSS;
+    om = m;
+    npara = 1;
+    terms.assign(t, t + p * m->d);
+    para0 = {6.0};
+    paravar = {4.0};
+    paranames = {"coeffscale"};
+    nterms = p;
+    para = para0;
+    sca = std::exp(para[0]);
+    return updateom();
+  }
+  int updateom() override {  // :80-83
+    std::vector<double> v;
+    term_var_lvarge(*om, terms, nterms, v, coefflvarge);
+    coeffsd.resize(nterms);
+    for (uint64_t k = 0; k < nterms; ++k) coeffsd[k] = std::sqrt(v[k]);
+    return 0;
+  }
+  int updatepara(const double *pp, uint64_t n) override {  // :90-93
+    if (n != 1) return fail(OBHIP_ERR_INVALID, "logpr_gauss has one parameter");
+    para = {pp[0]};
+    sca = std::exp(para[0]);
+    return 0;
+  }
+  int updateterms(const uint64_t *t, uint64_t p) override {  // :100-105
+    OB_TRY(check_terms(om, t, p));
+    terms.assign(t, t + p * om->d);
+    nterms = p;
+    return updateom();
+  }
+  int update(const double *c) override {  // :113-121
+    const uint64_t p = nterms, nh = nhyp();
+    coeff.assign(c, c + p);
+    std::vector<double> sr(p);
+    double ss = 0, sl = 0;
+    for (uint64_t k = 0; k < p; ++k) {
+      sr[k] = c[k] / (coeffsd[k] * sca);
+      ss += sr[k] * sr[k];
+      sl += std::log(coeffsd[k] * sca);
+    }
+    if (compute_val) val = -0.5 * ss - sl;
+    if (compute_gradhyp) {
+      gradhyp.assign(nh, 0.0);
+      for (uint64_t h = 0; h < nh; ++h) {
+        double s = 0;
+        for (uint64_t k = 0; k < p; ++k) s += 0.5 * coefflvarge[h * p + k] * (sr[k] * sr[k] - 1.0);
+        gradhyp[h] = s;
+      }
+    }
+    if (compute_gradpara) gradpara = {ss - (double)p};
+    if (compute_grad) {
+      grad.resize(p);
+      for (uint64_t k = 0; k < p; ++k) grad[k] = -1.0 * sr[k] / (coeffsd[k] * sca);
+    }
+    return 0;
+  }
+  double prec(uint64_t k) const { return 1.0 / ((coeffsd[k] * sca) * (coeffsd[k] * sca)); }
+  int hessmult(const double *g, double *out) override {  // :128-130
+    for (uint64_t k = 0; k < nterms; ++k) out[k] = g[k] * prec(k);
+    return 0;
+  }
+  int diaghess(double *out) override {  // :137-139
+    for (uint64_t k = 0; k < nterms; ++k) out[k] = prec(k);
+    return 0;
+  }
+  int diaghessgradhyp(double *out) override {  // :146-150
+    for (uint64_t h = 0; h < nhyp(); ++h)
+      for (uint64_t k = 0; k < nterms; ++k) out[h * nterms + k] = -coefflvarge[h * nterms + k] * prec(k);
+    return 0;
+  }
+  int diaghessgradpara(double *out) override {  // :158-160
+    for (uint64_t k = 0; k < nterms; ++k) out[k] = -2.0 * prec(k);
+    return 0;
+  }
+  int hess_dev(double *d_H, bool add) override {  // :167-172
+    const uint64_t p = nterms;
+    std::vector<double> pr(p);
+    for (uint64_t k = 0; k < p; ++k) pr[k] = prec(k);
+    DevBuf<double> dp;
+    OB_TRY(dp.upload(pr.data(), p));
+    if (!add) OB_HIP(hipMemsetAsync(d_H, 0, p * p * sizeof(double), cur_stream()));
+    const double *pp = dp.p;
+    OB_TRY(vmap(p, [=] __device__(uint64_t k) { d_H[k * p + k] += pp[k]; }));
+    OB_HIP(hipStreamSynchronize(cur_stream()));  // dp is a local
+    return 0;
+  }
+};
+
+// ---- what the three likelihoods share: the outerbase, y and the n-vectors in HBM ----------
+struct Loglik : obhip_lpdf {
+  obhip_basis *ob = nullptr;  // owned (class member `outerbase ob` of the reference)
+  obhip_terms *t = nullptr;   // owned device form of `terms`
+  uint64_t n = 0;
+  DevBuf<double> y, yhat, r, tmp, ones, dcoeff, dpv;
+  DevBuf<double> yhatge;      // n x nhyp, kept for gradhyp
+  DevBuf<double> red;         // scratch of the two-stage sums
+
+  ~Loglik() override {
+    if (ob) obhip_basis_destroy(ob);
+    if (t) obhip_terms_destroy(t);
+  }
+  obhip_basis *basis() override { return ob; }
+
+  int make_terms(const uint64_t *tt, uint64_t p) {
+    OB_TRY(check_terms(om, tt, p));
+    obhip_terms *nt = nullptr;
+    OB_TRY(obhip_terms_create(&nt, om, tt, p));
+    if (t) obhip_terms_destroy(t);
+    t = nt;
+    terms.assign(tt, tt + p * om->d);
+    nterms = p;
+    return 0;
+  }
+  // the basis is evaluated up to the highest level the terms use
+  int make_basis_from(const double *d_x) {
+    obhip_basis *nb = nullptr;
+    OB_TRY(obhip_basis_create_dev(&nb, om, d_x, n, t->maxlev.data()));
+    if (ob) obhip_basis_destroy(ob);
+    ob = nb;
+    return 0;
+  }
+  int init_common(const obhip_model *m, const uint64_t *tt, uint64_t p, const double *yh,
+                  const double *x, uint64_t n_, uint64_t ldx) {
+    if (!m || !tt || !yh || !x || n_ == 0 || ldx < n_) return fail(OBHIP_ERR_INVALID, "loglik: bad argument");
+    OB_TRY(require_device());
+    om = m;
+    n = n_;
+    OB_TRY(make_terms(tt, p));
+    obhip_basis *nb = nullptr;
+    OB_TRY(obhip_basis_create(&nb, om, x, n, ldx, t->maxlev.data()));
+    ob = nb;
+    OB_TRY(y.upload(yh, n));
+    OB_TRY(yhat.alloc(n));
+    OB_TRY(r.alloc(n));
+    OB_TRY(tmp.alloc(n));
+    OB_TRY(ones.alloc(n));
+    OB_TRY(launch_fill(ones.p, n, 1.0));
+    OB_TRY(launch_fill(yhat.p, n, 0.0));
+    OB_TRY(red.alloc(64 + kSumBlocks * 8));
+    return 0;
+  }
+  int updateom() override { return obhip_basis_rebuild(ob); }
+  int updateterms(const uint64_t *tt, uint64_t p) override {
+    // new terms may use other levels: the basis is rebuilt with their caps (the reference
+    // keeps all levels and only swaps the umat, loglik_gauss.cpp:99-102)
+    DevBuf<double> xkeep;
+    OB_TRY(xkeep.alloc(n * om->d));
+    OB_HIP(hipMemcpyAsync(xkeep.p, ob->x.p, n * om->d * sizeof(double), hipMemcpyDeviceToDevice,
+                          cur_stream()));
+    OB_TRY(make_terms(tt, p));
+    OB_TRY(make_basis_from(xkeep.p));
+    OB_HIP(hipStreamSynchronize(cur_stream()));
+    return 0;
+  }
+  // yhat = B c (and its hyper-parameter gradient when asked for)
+  int forward(const double *c) {
+    const uint64_t p = nterms;
+    coeff.assign(c, c + p);
+    OB_TRY(dcoeff.upload(c, p));
+    if (compute_gradhyp) return grad_mm_dev(*ob, *t, false, c, dcoeff.p, yhat.p, yhatge);
+    return launch_mm(*ob, *t, dcoeff.p, yhat.p, false);
+  }
+  // grad = B^T r and, when asked for, gradhyp = r^T yhatge
+  int backward() {
+    const uint64_t p = nterms;
+    OB_TRY(dpv.alloc(p));
+    OB_TRY(launch_tmm(*ob, *t, r.p, dpv.p, false));
+    grad.resize(p);
+    OB_TRY(d2h(grad.data(), dpv.p, p * sizeof(double)));
+    if (compute_gradhyp) {
+      gradhyp.assign(nhyp(), 0.0);
+      OB_TRY(grad_wdot_dev(yhatge.p, r.p, n, nhyp(), gradhyp.data()));
+    }
+    return 0;
+  }
+  // out (p, host) = B^T v (squared store: B^2)
+  int tmm_host(const double *d_v, bool squared, double *out) {
+    OB_TRY(dpv.alloc(nterms));
+    OB_TRY(launch_tmm(*ob, *t, d_v, dpv.p, squared));
+    return d2h(out, dpv.p, nterms * sizeof(double));
+  }
+};
+
+// ---- loglik_gauss / loglik_std (src/lpdfs/loglik_gauss.cpp:41-172, loglik_std.cpp:41-203):
+// one noise level.  The reference's loglik_std differs only in keeping the materialised
+// design matrix (and in having hess()); the values are the same expressions.
+struct LoglikGauss : Loglik {
+  int init(int kind_, const obhip_model *m, const uint64_t *tt, uint64_t p, const double *yh,
+           const double *x, uint64_t n_, uint64_t ldx) {
+    kind = kind_;
+    OB_TRY(init_common(m, tt, p, yh, x, n_, ldx));
+    npara = 1;
+    para0 = {std::log(0.01 * sample_var(yh, n_))};  // loglik_std.cpp:51, loglik_gauss.cpp:48
+    paravar = {1.0};
+    paranames = {"noisescale"};
+    para = para0;
+    return 0;
+  }
+  int updatepara(const double *pp, uint64_t np) override {
+    if (np != 1) return fail(OBHIP_ERR_INVALID, "this likelihood has one parameter");
+    para = {pp[0]};
+    return 0;
+  }
+  int update(const double *c) override {  // loglik_gauss.cpp:110-130, loglik_std.cpp:100-120
+    OB_TRY(forward(c));
+    const double e2 = std::exp(-2.0 * para[0]);
+    OB_TRY(launch_resid(yhat.p, y.p, n, e2, r.p, tmp.p));  // r = -e2 (yhat - y), tmp = yhat - y
+    double ss[2];
+    OB_TRY(launch_sum_sumsq(tmp.p, n, red.p, red.p + 64));
+    OB_TRY(d2h(ss, red.p, 2 * sizeof(double)));
+    if (compute_val) val = -0.5 * e2 * ss[1] - (double)n * para[0];
+    if (compute_grad) {
+      OB_TRY(backward());
+      if (compute_gradpara) gradpara = {e2 * ss[1] - (double)n};
+    }
+    return 0;
+  }
+  int hessmult(const double *g, double *out) override {  // loglik_gauss.cpp:137-145
+    OB_TRY(dcoeff.upload(g, nterms));
+    OB_TRY(launch_mm(*ob, *t, dcoeff.p, tmp.p, false));
+    OB_TRY(launch_scale(tmp.p, n, std::exp(-2.0 * para[0])));
+    return tmm_host(tmp.p, false, out);
+  }
+  int diaghess(double *out) override {  // loglik_gauss.cpp:154-157
+    OB_TRY(tmm_host(ones.p, true, out));
+    const double e2 = std::exp(-2.0 * para[0]);
+    for (uint64_t k = 0; k < nterms; ++k) out[k] *= e2;
+    return 0;
+  }
+  int diaghessgradhyp(double *out) override {  // loglik_gauss.cpp:158-161
+    OB_TRY(grad_tmm_host(*ob, *t, true, ones.p, out));
+    const double e2 = std::exp(-2.0 * para[0]);
+    for (uint64_t k = 0; k < nterms * nhyp(); ++k) out[k] *= e2;
+    return 0;
+  }
+  int diaghessgradpara(double *out) override {  // loglik_gauss.cpp:169-172
+    OB_TRY(tmm_host(ones.p, true, out));
+    const double c = -2.0 * std::exp(-2.0 * para[0]);
+    for (uint64_t k = 0; k < nterms; ++k) out[k] *= c;
+    return 0;
+  }
+  int hess_dev(double *d_H, bool add) override {  // loglik_std.cpp:170-173
+    if (kind != OBHIP_LPDF_LOGLIK_STD) return fail(OBHIP_ERR_STATE, "loglik_gauss never builds a Hessian");
+    const uint64_t p = nterms;
+    const double e2 = std::exp(-2.0 * para[0]);
+    if (!add) {
+      OB_TRY(launch_gram(*ob, *t, d_H));
+      return launch_scale(d_H, p * p, e2);
+    }
+    DevBuf<double> G;
+    OB_TRY(G.alloc(p * p));
+    OB_TRY(launch_gram(*ob, *t, G.p));
+    const double *g = G.p;
+    OB_TRY(vmap(p * p, [=] __device__(uint64_t e) { d_H[e] += e2 * g[e]; }));
+    OB_HIP(hipStreamSynchronize(cur_stream()));
+    return 0;
+  }
+};
+
+// ---- loglik_gda (src/lpdfs/loglik_gda.cpp:48-235): per-observation variance = noise +
+// residual variance of the truncated expansion ---------------------------------------------
+struct LoglikGda : Loglik {
+  bool doda = true, redostd = true;
+  DevBuf<double> obssd, obssd_gradhyp, obssd_gradpara, rterms, r2s, dvarc;
+
+  int init(const obhip_model *m, const uint64_t *tt, uint64_t p, const double *yh, const double *x,
+           uint64_t n_, uint64_t ldx) {
+    kind = OBHIP_LPDF_LOGLIK_GDA;
+    OB_TRY(init_common(m, tt, p, yh, x, n_, ldx));
+    npara = 2;
+    para0 = {0.5 * std::log(0.01 * sample_var(yh, n_)), 0.0};  // :58-60
+    paravar = {4.0, 4.0};
+    paranames = {"noisescale", "lik.coeffscale"};
+    para = para0;
+    OB_TRY(obssd.alloc(n));
+    OB_TRY(rterms.alloc(n));
+    OB_TRY(r2s.alloc(n));
+    OB_TRY(obssd_gradpara.alloc(2 * n));
+    return 0;
+  }
+  int updateom() override {  // :84-87
+    OB_TRY(Loglik::updateom());
+    if (doda) redostd = true;
+    return 0;
+  }
+  int updatepara(const double *pp, uint64_t np) override {  // :94-97
+    if (np != 2) return fail(OBHIP_ERR_INVALID, "loglik_gda has two parameters");
+    para = {pp[0], pp[1]};
+    redostd = true;
+    return 0;
+  }
+  int updateterms(const uint64_t *tt, uint64_t p) override {  // :104-108
+    OB_TRY(Loglik::updateterms(tt, p));
+    if (doda) redostd = true;
+    return 0;
+  }
+  // loglik_gda::buildstd (:215-235)
+  int buildstd() {
+    if (!redostd) return 0;
+    const uint64_t p = nterms, nh = nhyp(), nn = n;
+    const double e0 = std::exp(2.0 * para[0]), e1 = std::exp(2.0 * para[1]);
+    std::vector<double> varc, lvarge;
+    term_var_lvarge(*om, terms, p, varc, lvarge);
+    // rterms = ob.residvar(terms) = 1 - B^2 varc (modandbase.cpp:889-895)
+    OB_TRY(dvarc.upload(varc.data(), p));
+    OB_TRY(launch_mm(*ob, *t, dvarc.p, rterms.p, true));
+    {
+      double *rt = rterms.p, *sd = obssd.p, *gp = obssd_gradpara.p;
+      const bool da = doda;
+      OB_TRY(vmap(nn, [=] __device__(uint64_t i) {
+        const double rv = 1.0 - rt[i];
+        rt[i] = rv;
+        const double s = sqrt(da ? e0 + e1 * rv : e0);
+        sd[i] = s;
+        gp[i] = e0 / s;
+        gp[nn + i] = da ? e1 * rv / s : 0.0;
+      }));
+    }
+    if (doda) {
+      // ob.residvar_gradhyp(terms) (modandbase.cpp:904-925): -d(B^2 varc)/dhyp - B^2 (lvarge % varc),
+      // each column scaled by e1 / (2 obssd)
+      OB_TRY(grad_mm_dev(*ob, *t, true, varc.data(), dvarc.p, tmp.p, obssd_gradhyp));
+      DevBuf<double> dcol;
+      std::vector<double> col(p);
+      for (uint64_t h = 0; h < nh; ++h) {
+        for (uint64_t k = 0; k < p; ++k) col[k] = varc[k] * lvarge[h * p + k];
+        OB_TRY(dcol.upload(col.data(), p));
+        OB_TRY(launch_mm(*ob, *t, dcol.p, tmp.p, true));
+        double *gh = obssd_gradhyp.p + h * nn;
+        const double *tp = tmp.p, *sd = obssd.p;
+        OB_TRY(vmap(nn, [=] __device__(uint64_t i) { gh[i] = (-gh[i] - tp[i]) * (e1 * 0.5) / sd[i]; }));
+      }
+      OB_HIP(hipStreamSynchronize(cur_stream()));  // dcol is reused per hyper-parameter
+    }
+    redostd = false;
+    return 0;
+  }
+  int update(const double *c) override {  // :117-153
+    OB_TRY(forward(c));
+    OB_TRY(buildstd());
+    const uint64_t nn = n;
+    {
+      const double *yh = yhat.p, *yy = y.p, *sd = obssd.p;
+      double *rr = r.p, *r2 = r2s.p;
+      // r = -(yhat - y) / obssd^2, r2s = ((yhat - y) / obssd)^2 / obssd; sums for val
+      OB_TRY(vsum<2>(nn, [=] __device__(uint64_t i, double (&acc)[2]) {
+        const double s = sd[i], q = (yh[i] - yy[i]) / s;
+        acc[0] += q * q;
+        acc[1] += log(s);
+        rr[i] = -q / s;
+        r2[i] = q * q / s;
+      }, red.p, red.p + 64));
+    }
+    double ss[2];
+    OB_TRY(d2h(ss, red.p, sizeof ss));
+    if (compute_val) val = -0.5 * ss[0] - ss[1];
+    if (compute_grad) {
+      OB_TRY(backward());
+      // w = r2s - 1 / obssd: gradhyp += w^T obssd_gradhyp, gradpara = w^T obssd_gradpara
+      if ((compute_gradhyp && doda) || compute_gradpara) {
+        const double *sd = obssd.p, *r2 = r2s.p;
+        double *w = tmp.p;
+        OB_TRY(vmap(nn, [=] __device__(uint64_t i) { w[i] = r2[i] - 1.0 / sd[i]; }));
+      }
+      if (compute_gradhyp && doda) {
+        std::vector<double> add(nhyp());
+        OB_TRY(grad_wdot_dev(obssd_gradhyp.p, tmp.p, n, nhyp(), add.data()));
+        for (uint64_t h = 0; h < nhyp(); ++h) gradhyp[h] += add[h];
+      }
+      if (compute_gradpara) {
+        gradpara.assign(2, 0.0);
+        OB_TRY(grad_wdot_dev(obssd_gradpara.p, tmp.p, n, 2, gradpara.data()));
+      }
+    }
+    return 0;
+  }
+  int hessmult(const double *g, double *out) override {  // :160-169
+    OB_TRY(dcoeff.upload(g, nterms));
+    OB_TRY(launch_mm(*ob, *t, dcoeff.p, tmp.p, false));
+    double *v = tmp.p;
+    const double *sd = obssd.p;
+    OB_TRY(vmap(n, [=] __device__(uint64_t i) { v[i] = v[i] / sd[i] / sd[i]; }));
+    return tmm_host(tmp.p, false, out);
+  }
+  int diaghess(double *out) override {  // :177-180
+    OB_TRY(buildstd());
+    double *v = tmp.p;
+    const double *sd = obssd.p;
+    OB_TRY(vmap(n, [=] __device__(uint64_t i) { v[i] = 1.0 / (sd[i] * sd[i]); }));
+    return tmm_host(tmp.p, true, out);
+  }
+  // out (p x ncol) += sqtmmm(terms, M % temp2) with temp2 = -2 / obssd^3 (:187-214)
+  int sqtmmm_scaled(const double *d_M, uint64_t ncol, double *out, bool add) {
+    std::vector<double> colv(nterms);
+    for (uint64_t c = 0; c < ncol; ++c) {
+      double *v = tmp.p;
+      const double *sd = obssd.p, *mc = d_M + c * n;
+      OB_TRY(vmap(n, [=] __device__(uint64_t i) { v[i] = mc[i] * (-2.0 / (sd[i] * sd[i] * sd[i])); }));
+      OB_TRY(tmm_host(tmp.p, true, colv.data()));
+      for (uint64_t k = 0; k < nterms; ++k)
+        out[c * nterms + k] = add ? out[c * nterms + k] + colv[k] : colv[k];
+    }
+    return 0;
+  }
+  int diaghessgradhyp(double *out) override {  // :187-200
+    OB_TRY(buildstd());
+    double *v = r.p;  // r is rebuilt by every update(); free between updates
+    const double *sd = obssd.p;
+    OB_TRY(vmap(n, [=] __device__(uint64_t i) { v[i] = 1.0 / (sd[i] * sd[i]); }));
+    OB_TRY(grad_tmm_host(*ob, *t, true, r.p, out));
+    if (doda) OB_TRY(sqtmmm_scaled(obssd_gradhyp.p, nhyp(), out, true));
+    return 0;
+  }
+  int diaghessgradpara(double *out) override {  // :207-214
+    OB_TRY(buildstd());
+    return sqtmmm_scaled(obssd_gradpara.p, 2, out, false);
+  }
+};
+
+// ---- lpdfvec (fit.h:93-172, fit.cpp:174-612) ----------------------------------------------
+struct LpdfVec : obhip_lpdf {
+  obhip_lpdf *list[2] = {nullptr, nullptr};  // lpdflist (references in the reference)
+  uint64_t parasrt[2] = {0, 0}, paraend[2] = {0, 0};
+  bool domargadj = true, redohess = true, have_full = false;
+  double val_margadj = 0;
+  std::vector<double> gradhyp_margadj, gradpara_margadj;
+  std::vector<double> diaghessv, diaghessgradhypv, diaghessgradparav;
+  DevBuf<double> hessv;  // p x p
+
+  int init(obhip_lpdf *a, obhip_lpdf *b) {  // fit.cpp:174-200
+    if (!a || !b) return fail(OBHIP_ERR_INVALID, "lpdfvec: null member");
+    if (a->nterms != b->nterms) return fail(OBHIP_ERR_INVALID, "lpdfvec: members disagree on the terms");
+    kind = OBHIP_LPDF_VEC;
+    om = a->om ? a->om : b->om;
+    list[0] = a;
+    list[1] = b;
+    terms = a->terms;
+    nterms = a->nterms;
+    parasrt[0] = 0;
+    paraend[0] = a->npara;
+    parasrt[1] = a->npara;
+    paraend[1] = a->npara + b->npara;
+    npara = paraend[1];
+    para = a->para;
+    para.insert(para.end(), b->para.begin(), b->para.end());
+    para0 = a->para0;
+    para0.insert(para0.end(), b->para0.begin(), b->para0.end());
+    paravar = a->paravar;
+    paravar.insert(paravar.end(), b->paravar.begin(), b->paravar.end());
+    paranames = a->paranames;
+    paranames.insert(paranames.end(), b->paranames.begin(), b->paranames.end());
+    return 0;
+  }
+  obhip_basis *basis() override {
+    for (obhip_lpdf *l : list)
+      if (l->basis()) return l->basis();
+    return nullptr;
+  }
+  Loglik *loglik() const {
+    for (obhip_lpdf *l : list)
+      if (l->kind == OBHIP_LPDF_LOGLIK_STD || l->kind == OBHIP_LPDF_LOGLIK_GAUSS ||
+          l->kind == OBHIP_LPDF_LOGLIK_GDA)
+        return static_cast<Loglik *>(l);
+    return nullptr;
+  }
+  LogprGauss *logpr() const {
+    for (obhip_lpdf *l : list)
+      if (l->kind == OBHIP_LPDF_LOGPR_GAUSS) return static_cast<LogprGauss *>(l);
+    return nullptr;
+  }
+  int updateom() override {  // fit.cpp:208-211
+    for (obhip_lpdf *l : list) OB_TRY(l->updateom());
+    redohess = true;
+    return 0;
+  }
+  int updatepara(const double *pp, uint64_t np) override {  // fit.cpp:220-229
+    if (np != npara) return fail(OBHIP_ERR_INVALID, "lpdfvec: wrong number of parameters");
+    para.assign(pp, pp + np);
+    for (int c = 0; c < 2; ++c) OB_TRY(list[c]->updatepara(pp + parasrt[c], paraend[c] - parasrt[c]));
+    redohess = true;
+    return 0;
+  }
+  int updateterms(const uint64_t *tt, uint64_t p) override {  // fit.cpp:238-245
+    for (obhip_lpdf *l : list) OB_TRY(l->updateterms(tt, p));
+    terms.assign(tt, tt + p * om->d);
+    nterms = p;
+    redohess = true;
+    return 0;
+  }
+  void settotdiaghess(const std::vector<double> &d) override {  // fit.cpp:604-607
+    totdiaghess = d;
+    for (obhip_lpdf *l : list) l->settotdiaghess(d);
+  }
+  int settothess(const double *d_H) override {  // fit.cpp:609-612
+    for (obhip_lpdf *l : list) OB_TRY(l->settothess(d_H));
+    return obhip_lpdf::settothess(d_H);
+  }
+  int diaghess_(std::vector<double> &out) {  // fit.cpp:557-566
+    const uint64_t p = nterms;
+    std::vector<double> a(p), b(p);
+    OB_TRY(list[0]->diaghess(a.data()));
+    OB_TRY(list[1]->diaghess(b.data()));
+    out.resize(p);
+    for (uint64_t k = 0; k < p; ++k) out[k] = a[k] + b[k];
+    return 0;
+  }
+  int hess_dev(double *d_H, bool add) override {  // hess_, fit.cpp:503-512
+    OB_TRY(list[0]->hess_dev(d_H, add));
+    return list[1]->hess_dev(d_H, true);
+  }
+  // lpdfvec::buildhess (fit.cpp:252-302)
+  int buildhess() {
+    const uint64_t p = nterms, nh = nhyp();
+    if (!redohess && !(fullhess && !have_full)) return 0;
+    OB_TRY(diaghess_(diaghessv));
+    settotdiaghess(diaghessv);
+    if (domargadj) {
+      std::vector<double> a(p * nh), b(p * nh);
+      OB_TRY(list[0]->diaghessgradhyp(a.data()));
+      OB_TRY(list[1]->diaghessgradhyp(b.data()));
+      diaghessgradhypv.resize(p * nh);
+      for (uint64_t e = 0; e < p * nh; ++e) diaghessgradhypv[e] = a[e] + b[e];
+      diaghessgradparav.assign(p * npara, 0.0);
+      for (int c = 0; c < 2; ++c)
+        OB_TRY(list[c]->diaghessgradpara(diaghessgradparav.data() + parasrt[c] * p));
+      val_margadj = 0;
+      for (uint64_t k = 0; k < p; ++k) val_margadj -= 0.5 * std::log(diaghessv[k]);
+      gradhyp_margadj.assign(nh, 0.0);
+      for (uint64_t h = 0; h < nh; ++h)
+        for (uint64_t k = 0; k < p; ++k) gradhyp_margadj[h] -= 0.5 * diaghessgradhypv[h * p + k] / diaghessv[k];
+      gradpara_margadj.assign(npara, 0.0);
+      for (uint64_t c = 0; c < npara; ++c)
+        for (uint64_t k = 0; k < p; ++k) gradpara_margadj[c] -= 0.5 * diaghessgradparav[c * p + k] / diaghessv[k];
+    }
+    have_full = false;
+    if (fullhess) {
+      OB_TRY(hessv.alloc(p * p));
+      OB_TRY(hess_dev(hessv.p, false));
+      OB_TRY(settothess(hessv.p));
+      have_full = true;
+      if (domargadj) OB_TRY(margadj_full());
+    }
+    redohess = false;
+    return 0;
+  }
+  // -1/2 log det H and -1/2 tr(inv(H) dH) (fit.cpp:270-299); the reference goes through
+  // eig_sym and the p x p x nhyp cubes, here Cholesky + streaming traces (posterior.cpp)
+  int margadj_full() {
+    Loglik *lik = loglik();
+    LogprGauss *pr = logpr();
+    if (!lik || !pr || lik->kind != OBHIP_LPDF_LOGLIK_STD)
+      return fail(OBHIP_ERR_STATE, "full-Hessian marginal adjustment needs loglik_std + logpr_gauss");
+    const uint64_t p = nterms;
+    std::vector<double> H(p * p), gh(nhyp()), gp(2);
+    OB_TRY(d2h(H.data(), hessv.p, p * p * sizeof(double)));
+    OB_TRY(obhip_margadj_full(lik->ob, lik->t, om, H.data(), lik->para[0], pr->para[0], &val_margadj,
+                              gh.data(), gp.data()));
+    gradhyp_margadj = gh;
+    gradpara_margadj.assign(npara, 0.0);
+    for (int c = 0; c < 2; ++c) gradpara_margadj[parasrt[c]] = list[c] == lik ? gp[0] : gp[1];
+    return 0;
+  }
+  int update(const double *c) override {  // fit.cpp:323-363
+    const uint64_t p = nterms, nh = nhyp();
+    coeff.assign(c, c + p);
+    for (obhip_lpdf *l : list) {
+      l->compute_val = compute_val;
+      l->compute_grad = compute_grad;
+      l->compute_gradhyp = compute_gradhyp;
+      l->compute_gradpara = compute_gradpara;
+    }
+    for (obhip_lpdf *l : list) OB_TRY(l->update(c));
+    if (compute_val) val = 0;
+    if (compute_grad) grad.assign(p, 0.0);
+    if (compute_gradhyp) gradhyp.assign(nh, 0.0);
+    if (compute_gradpara) gradpara.assign(npara, 0.0);
+    OB_TRY(buildhess());
+    for (int k = 0; k < 2; ++k) {
+      obhip_lpdf *l = list[k];
+      if (compute_val) val += l->val;
+      if (compute_grad)
+        for (uint64_t i = 0; i < p; ++i) grad[i] += l->grad[i];
+      if (compute_gradhyp)
+        for (uint64_t h = 0; h < nh && h < l->gradhyp.size(); ++h) gradhyp[h] += l->gradhyp[h];
+      if (compute_gradpara)
+        for (uint64_t i = 0; i < l->gradpara.size(); ++i) gradpara[parasrt[k] + i] += l->gradpara[i];
+    }
+    if (domargadj) {  // lpdfvec::margadj, fit.cpp:371-380
+      if (compute_val) val += val_margadj;
+      if (compute_gradhyp)
+        for (uint64_t h = 0; h < nh; ++h) gradhyp[h] += gradhyp_margadj[h];
+      if (compute_gradpara)
+        for (uint64_t i = 0; i < npara; ++i) gradpara[i] += gradpara_margadj[i];
+    }
+    return 0;
+  }
+  int hessmult(const double *g, double *out) override {  // fit.cpp:382-392
+    std::vector<double> b(nterms);
+    OB_TRY(list[0]->hessmult(g, out));
+    OB_TRY(list[1]->hessmult(g, b.data()));
+    for (uint64_t k = 0; k < nterms; ++k) out[k] += b[k];
+    return 0;
+  }
+  int diaghess(double *out) override {  // returns the cached diaghessv (fit.cpp:400-402)
+    if (diaghessv.size() != nterms) OB_TRY(diaghess_(diaghessv));
+    std::copy(diaghessv.begin(), diaghessv.end(), out);
+    return 0;
+  }
+  int diaghessgradhyp(double *out) override {
+    if (diaghessgradhypv.size() != nterms * nhyp()) return fail(OBHIP_ERR_STATE, "lpdfvec: not built (domarg off?)");
+    std::copy(diaghessgradhypv.begin(), diaghessgradhypv.end(), out);
+    return 0;
+  }
+  int diaghessgradpara(double *out) override {
+    if (diaghessgradparav.size() != nterms * npara) return fail(OBHIP_ERR_STATE, "lpdfvec: not built (domarg off?)");
+    std::copy(diaghessgradparav.begin(), diaghessgradparav.end(), out);
+    return 0;
+  }
+  double paralpdf(const double *pp, uint64_t np) const override {  // fit.cpp:470-478
+    if (np != npara) return -std::numeric_limits<double>::infinity();
+    double out = 0;
+    for (int c = 0; c < 2; ++c) out += list[c]->paralpdf(pp + parasrt[c], paraend[c] - parasrt[c]);
+    return out;
+  }
+  void paralpdf_grad(const double *pp, uint64_t np, double *out) const override {  // fit.cpp:487-496
+    for (uint64_t k = 0; k < npara; ++k) out[k] = 0;
+    if (np != npara) return;
+    for (int c = 0; c < 2; ++c) list[c]->paralpdf_grad(pp + parasrt[c], paraend[c] - parasrt[c], out + parasrt[c]);
+  }
+  bool one_noise_level() const {
+    Loglik *lik = loglik();
+    return lik && logpr() && lik->kind != OBHIP_LPDF_LOGLIK_GDA;
+  }
+  // lpdf::optcg for (loglik_gauss | loglik_std) + logpr_gauss: the device-resident loop of
+  // obhip_fit_cg_dev; the generic loop otherwise (loglik_gda)
+  int optcg(double tol, uint64_t maxepch) override {
+    // what a previous optnewton() left of the full-Hessian adjustment does not belong to a
+    // diagonal fit (the reference keeps it until the next updateom / updatepara)
+    if (have_full) redohess = true;
+    if (!one_noise_level()) return obhip_lpdf::optcg(tol, maxepch);
+    Loglik *lik = loglik();
+    LogprGauss *pr = logpr();
+    fullhess = false;
+    compute_val = compute_grad = true;
+    compute_gradhyp = compute_gradpara = false;
+    const uint64_t p = nterms;
+    if (coeff.size() != p) coeff.assign(p, 0.0);
+    DevBuf<double> dth, ddiag;
+    OB_TRY(dth.upload(coeff.data(), p));
+    OB_TRY(ddiag.alloc(p));
+    double v = 0;
+    OB_TRY(obhip_fit_cg_dev(lik->ob, lik->t, om, lik->y.p, lik->para[0], pr->para[0], tol, maxepch,
+                            dth.p, &cgiters, ddiag.p, &v, nullptr));
+    std::vector<double> c(p);
+    OB_TRY(d2h(c.data(), dth.p, p * sizeof(double)));
+    compute_gradhyp = compute_gradpara = true;  // fit.cpp:87-93
+    OB_TRY(update(c.data()));
+    compute_gradhyp = compute_gradpara = false;
+    return 0;
+  }
+  // lpdf::optnewton for loglik_std + logpr_gauss: G and g by the Gram kernels, Cholesky
+  int optnewton() override {
+    Loglik *lik = loglik();
+    LogprGauss *pr = logpr();
+    if (!lik || !pr || lik->kind != OBHIP_LPDF_LOGLIK_STD) return obhip_lpdf::optnewton();
+    fullhess = true;
+    compute_val = compute_grad = true;
+    compute_gradhyp = compute_gradpara = false;
+    const uint64_t p = nterms;
+    // H does not depend on coeff: build it (and the marginal adjustment) once, then the
+    // step from coeff = 0, which is where one Newton step from anywhere lands
+    redohess = true;
+    std::vector<double> zero(p, 0.0);
+    OB_TRY(update(zero.data()));  // buildhess(): hessv = H, settothess
+    DevBuf<double> dH, dr, dth;
+    DevBuf<char> ws;
+    OB_TRY(dH.alloc(p * p));
+    OB_HIP(hipMemcpyAsync(dH.p, hessv.p, p * p * sizeof(double), hipMemcpyDeviceToDevice, cur_stream()));
+    bool gfin = true;
+    for (uint64_t k = 0; k < p; ++k) gfin = gfin && std::isfinite(grad[k]);
+    if (!gfin) {
+      val = -std::numeric_limits<double>::infinity();
+      return 0;
+    }
+    OB_TRY(dr.upload(grad.data(), p));  // grad at 0 = e^{-2 sigma} B^T y
+    OB_TRY(dth.alloc(p));
+    const uint64_t wsb = newton_workspace_bytes(p);
+    OB_TRY(ws.alloc(wsb));
+    OB_TRY(launch_newton_solve(p, dH.p, dr.p, dth.p, ws.p, wsb));
+    std::vector<double> c(p);
+    OB_TRY(d2h(c.data(), dth.p, p * sizeof(double)));
+    compute_gradhyp = compute_gradpara = true;  // fit.cpp:122-128
+    OB_TRY(update(c.data()));
+    compute_gradhyp = compute_gradpara = false;
+    return 0;
+  }
+};
+
+}  // namespace
+
+// ---- predictor (fit.h:9-20,352-361; predr_std loglik_std.cpp:218-256, pred_gauss
+// loglik_gauss.cpp:196-227, pred_gda loglik_gda.cpp:247-281) -------------------------------
+struct obhip_predictor {
+  int kind = -1;
+  const obhip_model *om = nullptr;
+  obhip_terms *t = nullptr;  // owned
+  std::vector<double> coeff, para, cv;  // cv: what multiplies B^2 (see create)
+  bool doda = false, full = false;
+  std::vector<double> H;  // tothess (host, p x p) for predr_std with the full Hessian
+  std::vector<uint64_t> terms;
+  DevBuf<double> x, dmean, dvar;
+  uint64_t n = 0;
+  bool fresh = false;
+  ~obhip_predictor() {
+    if (t) obhip_terms_destroy(t);
+  }
+  int run() {
+    const uint64_t p = coeff.size();
+    OB_TRY(dmean.alloc(n));
+    OB_TRY(dvar.alloc(n));
+    if (kind == OBHIP_LPDF_LOGLIK_STD && full) {
+      std::vector<double> xm(n * om->d), mean(n), var(n);
+      OB_TRY(d2h(xm.data(), x.p, xm.size() * sizeof(double)));
+      OB_TRY(obhip_predict_std(om, t, coeff.data(), H.data(), xm.data(), n, n, mean.data(), para[0],
+                               var.data()));
+      OB_TRY(dmean.upload(mean.data(), n));
+      OB_TRY(dvar.upload(var.data(), n));
+    } else {
+      DevBuf<double> dth, dcv;
+      OB_TRY(dth.upload(coeff.data(), p));
+      OB_TRY(dcv.upload(cv.data(), p));
+      OB_TRY(obhip_predict_dev(om, t, dth.p, x.p, n, dmean.p, dcv.p, para[0], dvar.p));
+      if (kind == OBHIP_LPDF_LOGLIK_GDA && doda) {
+        // + e^{2 para[1]} residvar at the new points (loglik_gda.cpp:276-281)
+        obhip_basis *b = nullptr;
+        OB_TRY(obhip_basis_create_dev(&b, om, x.p, n, t->maxlev.data()));
+        struct G {
+          obhip_basis *b;
+          ~G() { obhip_basis_destroy(b); }
+        } guard{b};
+        std::vector<double> varc(p);
+        for (uint64_t k = 0; k < p; ++k) {
+          double s = 0;
+          for (uint64_t l = 0; l < om->d; ++l) s += om->basisvar[om->knotptst[l] + terms[l * p + k]];
+          varc[k] = std::exp(s);
+        }
+        DevBuf<double> dv, rv;
+        OB_TRY(dv.upload(varc.data(), p));
+        OB_TRY(rv.alloc(n));
+        OB_TRY(launch_mm(*b, *t, dv.p, rv.p, true));
+        double *var = dvar.p;
+        const double *r = rv.p;
+        const double e1 = std::exp(2.0 * para[1]);
+        OB_TRY(vmap(n, [=] __device__(uint64_t i) { var[i] += e1 * (1.0 - r[i]); }));
+      }
+      OB_HIP(hipStreamSynchronize(cur_stream()));
+    }
+    fresh = true;
+    return 0;
+  }
+};
+
+extern "C" {
+
+// ---- constructors ----------------------------------------------------------------------------
+int obhip_loglik_create(obhip_lpdf **out, int kind, const obhip_model *om, const uint64_t *terms,
+                        uint64_t p, const double *y, const double *x, uint64_t n, uint64_t ldx) {
+  if (!out) return fail(OBHIP_ERR_INVALID, "loglik_create: null argument");
+  int rc = 0;
+  obhip_lpdf *l = nullptr;
+  if (kind == OBHIP_LPDF_LOGLIK_STD || kind == OBHIP_LPDF_LOGLIK_GAUSS) {
+    LoglikGauss *g = new LoglikGauss();
+    rc = g->init(kind, om, terms, p, y, x, n, ldx);
+    l = g;
+  } else if (kind == OBHIP_LPDF_LOGLIK_GDA) {
+    LoglikGda *g = new LoglikGda();
+    rc = g->init(om, terms, p, y, x, n, ldx);
+    l = g;
+  } else {
+    return fail(OBHIP_ERR_INVALID, "loglik_create: unknown kind");
+  }
+  if (rc) {
+    delete l;
+    return rc;
+  }
+  *out = l;
+  return 0;
+}
+
+int obhip_logpr_gauss_create(obhip_lpdf **out, const obhip_model *om, const uint64_t *terms, uint64_t p) {
+  if (!out) return fail(OBHIP_ERR_INVALID, "logpr_gauss_create: null argument");
+  LogprGauss *l = new LogprGauss();
+  const int rc = l->init(om, terms, p);
+  if (rc) {
+    delete l;
+    return rc;
+  }
+  *out = l;
+  return 0;
+}
+
+int obhip_lpdfvec_create(obhip_lpdf **out, obhip_lpdf *a, obhip_lpdf *b) {
+  if (!out) return fail(OBHIP_ERR_INVALID, "lpdfvec_create: null argument");
+  LpdfVec *l = new LpdfVec();
+  const int rc = l->init(a, b);
+  if (rc) {
+    delete l;
+    return rc;
+  }
+  *out = l;
+  return 0;
+}
+
+int obhip_lpdf_destroy(obhip_lpdf *l) {
+  if (l) (void)hipStreamSynchronize(cur_stream());
+  delete l;
+  return 0;
+}
+
+// ---- fields ----------------------------------------------------------------------------------
+int obhip_lpdf_dims(const obhip_lpdf *l, int *kind, uint64_t *nterms, uint64_t *npara, uint64_t *nhyp,
+                    uint64_t *n) {
+  if (!l) return fail(OBHIP_ERR_INVALID, "null lpdf");
+  if (kind) *kind = l->kind;
+  if (nterms) *nterms = l->nterms;
+  if (npara) *npara = l->npara;
+  if (nhyp) *nhyp = l->nhyp();
+  if (n) {
+    obhip_basis *b = const_cast<obhip_lpdf *>(l)->basis();
+    *n = b ? b->n : 0;
+  }
+  return 0;
+}
+
+int obhip_lpdf_get_flag(const obhip_lpdf *l, int flag, int *value) {
+  if (!l || !value) return fail(OBHIP_ERR_INVALID, "lpdf_get_flag: null argument");
+  switch (flag) {
+    case OBHIP_FLAG_COMPUTE_VAL: *value = l->compute_val; return 0;
+    case OBHIP_FLAG_COMPUTE_GRAD: *value = l->compute_grad; return 0;
+    case OBHIP_FLAG_COMPUTE_GRADHYP: *value = l->compute_gradhyp; return 0;
+    case OBHIP_FLAG_COMPUTE_GRADPARA: *value = l->compute_gradpara; return 0;
+    case OBHIP_FLAG_FULLHESS: *value = l->fullhess; return 0;
+    case OBHIP_FLAG_DOMARG:
+      if (l->kind != OBHIP_LPDF_VEC) break;
+      *value = static_cast<const LpdfVec *>(l)->domargadj;
+      return 0;
+    case OBHIP_FLAG_DODIAG:
+      if (l->kind != OBHIP_LPDF_LOGLIK_GDA) break;
+      *value = static_cast<const LoglikGda *>(l)->doda;
+      return 0;
+  }
+  return fail(OBHIP_ERR_INVALID, "lpdf_get_flag: this object has no such field");
+}
+
+int obhip_lpdf_set_flag(obhip_lpdf *l, int flag, int value) {
+  if (!l) return fail(OBHIP_ERR_INVALID, "null lpdf");
+  const bool v = value != 0;
+  switch (flag) {
+    case OBHIP_FLAG_COMPUTE_VAL: l->compute_val = v; return 0;
+    case OBHIP_FLAG_COMPUTE_GRAD: l->compute_grad = v; return 0;
+    case OBHIP_FLAG_COMPUTE_GRADHYP: l->compute_gradhyp = v; return 0;
+    case OBHIP_FLAG_COMPUTE_GRADPARA: l->compute_gradpara = v; return 0;
+    case OBHIP_FLAG_FULLHESS: return fail(OBHIP_ERR_INVALID, "fullhess is read-only (interfaceR.cpp:702)");
+    case OBHIP_FLAG_DOMARG:
+      if (l->kind != OBHIP_LPDF_VEC) break;
+      if (static_cast<LpdfVec *>(l)->domargadj != v) static_cast<LpdfVec *>(l)->redohess = true;
+      static_cast<LpdfVec *>(l)->domargadj = v;
+      return 0;
+    case OBHIP_FLAG_DODIAG:
+      if (l->kind != OBHIP_LPDF_LOGLIK_GDA) break;
+      static_cast<LoglikGda *>(l)->doda = v;
+      static_cast<LoglikGda *>(l)->redostd = true;
+      return 0;
+  }
+  return fail(OBHIP_ERR_INVALID, "lpdf_set_flag: this object has no such field");
+}
+
+int obhip_lpdf_get_val(const obhip_lpdf *l, double *val) {
+  if (!l || !val) return fail(OBHIP_ERR_INVALID, "lpdf_get_val: null argument");
+  *val = l->val;
+  return 0;
+}
+
+int obhip_lpdf_get_vec(const obhip_lpdf *lc, int which, double *out, uint64_t cap, uint64_t *len) {
+  if (!lc) return fail(OBHIP_ERR_INVALID, "null lpdf");
+  obhip_lpdf *l = const_cast<obhip_lpdf *>(lc);
+  const std::vector<double> *v = nullptr;
+  switch (which) {
+    case OBHIP_VEC_COEFF: v = &l->coeff; break;
+    case OBHIP_VEC_GRAD: v = &l->grad; break;
+    case OBHIP_VEC_GRADHYP: v = &l->gradhyp; break;
+    case OBHIP_VEC_GRADPARA: v = &l->gradpara; break;
+    case OBHIP_VEC_PARA: v = &l->para; break;
+    case OBHIP_VEC_PARA0: v = &l->para0; break;
+    case OBHIP_VEC_PARAVAR: v = &l->paravar; break;
+    case OBHIP_VEC_TOTDIAGHESS: v = &l->totdiaghess; break;
+    case OBHIP_VEC_COEFFSD:
+      if (l->kind != OBHIP_LPDF_LOGPR_GAUSS) return fail(OBHIP_ERR_INVALID, "coeffsd is a field of logpr_gauss");
+      v = &static_cast<LogprGauss *>(l)->coeffsd;
+      break;
+    case OBHIP_VEC_YHAT: {
+      Loglik *lik = l->kind <= OBHIP_LPDF_LOGLIK_GDA ? static_cast<Loglik *>(l) : nullptr;
+      if (!lik) return fail(OBHIP_ERR_INVALID, "yhat is a field of the likelihoods");
+      if (len) *len = lik->n;
+      if (!out) return 0;
+      if (cap < lik->n) return fail(OBHIP_ERR_INVALID, "lpdf_get_vec: buffer too small");
+      return d2h(out, lik->yhat.p, lik->n * sizeof(double));
+    }
+    default: return fail(OBHIP_ERR_INVALID, "lpdf_get_vec: unknown field");
+  }
+  if (len) *len = v->size();
+  if (!out) return 0;
+  if (cap < v->size()) return fail(OBHIP_ERR_INVALID, "lpdf_get_vec: buffer too small");
+  std::copy(v->begin(), v->end(), out);
+  return 0;
+}
+
+int obhip_lpdf_paraname(const obhip_lpdf *l, uint64_t i, const char **name) {
+  if (!l || !name || i >= l->paranames.size()) return fail(OBHIP_ERR_INVALID, "lpdf_paraname: bad argument");
+  *name = l->paranames[i].c_str();
+  return 0;
+}
+
+int obhip_lpdf_terms(const obhip_lpdf *l, uint64_t *terms_out) {
+  if (!l || !terms_out) return fail(OBHIP_ERR_INVALID, "lpdf_terms: null argument");
+  std::copy(l->terms.begin(), l->terms.end(), terms_out);
+  return 0;
+}
+
+int obhip_lpdf_basis(obhip_lpdf *l, obhip_basis **b, obhip_terms **t) {
+  if (!l) return fail(OBHIP_ERR_INVALID, "null lpdf");
+  if (l->kind > OBHIP_LPDF_LOGLIK_GDA) return fail(OBHIP_ERR_INVALID, "only the likelihoods own an outerbase");
+  if (b) *b = static_cast<Loglik *>(l)->ob;
+  if (t) *t = static_cast<Loglik *>(l)->t;
+  return 0;
+}
+
+// ---- methods ----------------------------------------------------------------------------------
+int obhip_lpdf_setnthreads(obhip_lpdf *l, int) { return l ? 0 : fail(OBHIP_ERR_INVALID, "null lpdf"); }
+
+int obhip_lpdf_update(obhip_lpdf *l, const double *coeff, uint64_t ncoeff) {
+  if (!l || !coeff) return fail(OBHIP_ERR_INVALID, "lpdf_update: null argument");
+  if (ncoeff != l->nterms) return fail(OBHIP_ERR_INVALID, "lpdf_update: coeff must have one entry per term");
+  return l->update(coeff);
+}
+int obhip_lpdf_updateom(obhip_lpdf *l) { return l ? l->updateom() : fail(OBHIP_ERR_INVALID, "null lpdf"); }
+int obhip_lpdf_updatepara(obhip_lpdf *l, const double *para, uint64_t npara) {
+  if (!l || !para) return fail(OBHIP_ERR_INVALID, "lpdf_updatepara: null argument");
+  return l->updatepara(para, npara);
+}
+int obhip_lpdf_updateterms(obhip_lpdf *l, const uint64_t *terms, uint64_t p) {
+  if (!l || !terms || p == 0) return fail(OBHIP_ERR_INVALID, "lpdf_updateterms: bad argument");
+  return l->updateterms(terms, p);
+}
+int obhip_lpdf_hessmult(obhip_lpdf *l, const double *g, double *out) {
+  if (!l || !g || !out) return fail(OBHIP_ERR_INVALID, "lpdf_hessmult: null argument");
+  return l->hessmult(g, out);
+}
+int obhip_lpdf_diaghess(obhip_lpdf *l, double *out) {
+  if (!l || !out) return fail(OBHIP_ERR_INVALID, "lpdf_diaghess: null argument");
+  return l->diaghess(out);
+}
+int obhip_lpdf_diaghessgradhyp(obhip_lpdf *l, double *out) {
+  if (!l || !out) return fail(OBHIP_ERR_INVALID, "lpdf_diaghessgradhyp: null argument");
+  return l->diaghessgradhyp(out);
+}
+int obhip_lpdf_diaghessgradpara(obhip_lpdf *l, double *out) {
+  if (!l || !out) return fail(OBHIP_ERR_INVALID, "lpdf_diaghessgradpara: null argument");
+  return l->diaghessgradpara(out);
+}
+int obhip_lpdf_hess(obhip_lpdf *l, double *out) {
+  if (!l || !out) return fail(OBHIP_ERR_INVALID, "lpdf_hess: null argument");
+  OB_TRY(require_device());
+  const uint64_t p = l->nterms;
+  DevBuf<double> dH;
+  OB_TRY(dH.alloc(p * p));
+  OB_TRY(l->hess_dev(dH.p, false));
+  return d2h(out, dH.p, p * p * sizeof(double));  // symmetric: row-major == column-major
+}
+int obhip_lpdf_optcg(obhip_lpdf *l, double tol, uint64_t maxepch, uint64_t *iters) {
+  if (!l) return fail(OBHIP_ERR_INVALID, "null lpdf");
+  OB_TRY(l->optcg(tol, maxepch));
+  if (iters) *iters = l->cgiters;
+  return 0;
+}
+int obhip_lpdf_optnewton(obhip_lpdf *l) { return l ? l->optnewton() : fail(OBHIP_ERR_INVALID, "null lpdf"); }
+int obhip_lpdf_paralpdf(const obhip_lpdf *l, const double *parap, uint64_t n, double *out) {
+  if (!l || !parap || !out) return fail(OBHIP_ERR_INVALID, "lpdf_paralpdf: null argument");
+  *out = l->paralpdf(parap, n);
+  return 0;
+}
+int obhip_lpdf_paralpdf_grad(const obhip_lpdf *l, const double *parap, uint64_t n, double *out) {
+  if (!l || !parap || !out) return fail(OBHIP_ERR_INVALID, "lpdf_paralpdf_grad: null argument");
+  l->paralpdf_grad(parap, n, out);
+  return 0;
+}
+
+// ---- predictor ---------------------------------------------------------------------------------
+int obhip_predictor_create(obhip_predictor **out, const obhip_lpdf *lc) {
+  if (!out || !lc) return fail(OBHIP_ERR_INVALID, "predictor_create: null argument");
+  obhip_lpdf *l = const_cast<obhip_lpdf *>(lc);
+  if (l->kind == OBHIP_LPDF_VEC) {  // the R harness hands over the likelihood; accept the pair too
+    l = static_cast<LpdfVec *>(l)->loglik();
+    if (!l) return fail(OBHIP_ERR_INVALID, "cannot produce a predictor from this obj.");
+  }
+  if (l->kind > OBHIP_LPDF_LOGLIK_GDA)
+    return fail(OBHIP_ERR_INVALID, "cannot produce a predictor from this obj.");  // fit.h:53
+  Loglik *lik = static_cast<Loglik *>(l);
+  const uint64_t p = lik->nterms;
+  obhip_predictor *pr = new obhip_predictor();
+  pr->kind = lik->kind;
+  pr->om = lik->om;
+  pr->terms = lik->terms;
+  pr->para = lik->para;
+  pr->coeff = lik->coeff.size() == p ? lik->coeff : std::vector<double>(p, 0.0);
+  int rc = obhip_terms_create(&pr->t, lik->om, lik->terms.data(), p);
+  // coefficient covariance (loglik_std.cpp:226-237, loglik_gauss.cpp:204-211, loglik_gda.cpp:256-263)
+  pr->cv.assign(p, 0.0);
+  if (!rc && !lik->didnotothess) {
+    if (lik->kind == OBHIP_LPDF_LOGLIK_STD) {
+      if (lik->didfulltothess) {
+        pr->full = true;
+        pr->H.resize(p * p);
+        rc = d2h(pr->H.data(), lik->tothess.p, p * p * sizeof(double));
+      } else {
+        // predr_std without the full Hessian puts totdiaghess ITSELF on the diagonal of
+        // coeffcov (loglik_std.cpp:228-232) -- kept as the reference has it
+        pr->cv = lik->totdiaghess;
+      }
+    } else {
+      for (uint64_t k = 0; k < p; ++k) pr->cv[k] = 1.0 / lik->totdiaghess[k];
+    }
+  }
+  if (lik->kind == OBHIP_LPDF_LOGLIK_GDA) pr->doda = static_cast<LoglikGda *>(lik)->doda;
+  // the predictor starts at the training inputs (x(loglik.x), loglik_gauss.cpp:198)
+  pr->n = lik->n;
+  if (!rc) rc = pr->x.alloc(pr->n * lik->om->d);
+  if (!rc && hipMemcpyAsync(pr->x.p, lik->ob->x.p, pr->n * lik->om->d * sizeof(double),
+                            hipMemcpyDeviceToDevice, cur_stream()) != hipSuccess)
+    rc = fail(OBHIP_ERR_HIP, "copy of x failed");
+  if (rc) {
+    delete pr;
+    return rc;
+  }
+  *out = pr;
+  return 0;
+}
+
+int obhip_predictor_destroy(obhip_predictor *p) {
+  if (p) (void)hipStreamSynchronize(cur_stream());
+  delete p;
+  return 0;
+}
+
+int obhip_predictor_setnthreads(obhip_predictor *p, int) {
+  return p ? 0 : fail(OBHIP_ERR_INVALID, "null predictor");
+}
+
+int obhip_predictor_update(obhip_predictor *p, const double *x, uint64_t n, uint64_t ldx) {
+  if (!p || !x || n == 0 || ldx < n) return fail(OBHIP_ERR_INVALID, "predictor_update: bad argument");
+  const uint64_t d = p->om->d;
+  if (ldx == n) {
+    OB_TRY(p->x.upload(x, n * d));
+  } else {
+    std::vector<double> xc(n * d);
+    for (uint64_t l = 0; l < d; ++l) std::memcpy(&xc[l * n], x + l * ldx, n * sizeof(double));
+    OB_TRY(p->x.upload(xc.data(), xc.size()));
+  }
+  p->n = n;
+  p->fresh = false;
+  return 0;
+}
+
+int obhip_predictor_n(const obhip_predictor *p, uint64_t *n) {
+  if (!p || !n) return fail(OBHIP_ERR_INVALID, "predictor_n: null argument");
+  *n = p->n;
+  return 0;
+}
+
+int obhip_predictor_mean(obhip_predictor *p, double *out) {
+  if (!p || !out) return fail(OBHIP_ERR_INVALID, "predictor_mean: null argument");
+  if (!p->fresh) OB_TRY(p->run());
+  return d2h(out, p->dmean.p, p->n * sizeof(double));
+}
+
+int obhip_predictor_var(obhip_predictor *p, double *out) {
+  if (!p || !out) return fail(OBHIP_ERR_INVALID, "predictor_var: null argument");
+  if (!p->fresh) OB_TRY(p->run());
+  return d2h(out, p->dvar.p, p->n * sizeof(double));
+}
+
+}  // extern "C"

@@ -276,6 +276,11 @@ bool gram_panel_supports(const obhip_basis &b, const obhip_terms &t);
 int ensure_gradbasis(obhip_basis &b);
 int ensure_gradbasis_sq(obhip_basis &b);
 obhip_terms *grad_view(obhip_terms &t, const obhip_basis &b, uint64_t h);
+// device-level forms (inputs and n-sized results in HBM) for the likelihood classes
+int grad_mm_dev(obhip_basis &b, obhip_terms &t, bool squared, const double *a_host, const double *d_a,
+                double *d_M, DevBuf<double> &dge);
+int grad_wdot_dev(const double *d_G, const double *d_w, uint64_t n, uint64_t ncol, double *out_host);
+int grad_tmm_host(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a, double *out_host);
 // kernels_chol.hip
 uint64_t newton_workspace_bytes(uint64_t p);
 bool materialize_tl_supports(const obhip_terms &t);

@@ -5,8 +5,10 @@ tests read like the reference's own testthat files.  Every method forwards to
 the C ABI in include/obhip.h; nothing is computed in Python except O(p) vector
 algebra on results.
 
-Scope: value paths only -- no hyper-gradient methods
-(`*_gradhyp`), no loglik_gda, no marginal adjustment.
+Everything is a holder of a libobhip handle: outermod / outerbase / the lpdf family
+(loglik_std, loglik_gauss, loglik_gda, logpr_gauss, lpdfvec) / predictor, value and
+hyper-gradient paths and the marginal adjustment included.  The likelihood objects keep
+their n-vectors in HBM (csrc/lpdf.cpp); a method call moves p-sized vectors only.
 """
 import ctypes as C
 import math
@@ -294,9 +296,16 @@ def _terms_of(om, terms):
 # outerbase (interfaceR.cpp:680-694)
 # ----------------------------------------------------------------------------
 class outerbase:
-    def __init__(self, om, x, levelcap=None):
+    def __init__(self, om, x, levelcap=None, _borrow=None):
         om._need()
         self.om = om
+        self._owned = _borrow is None
+        if _borrow is not None:      # the outerbase a likelihood owns (member `ob`)
+            self._h, self.n_row = _borrow
+            self.xp = None
+            self.nthreads = 1
+            self.vertpl = False
+            return
         x = _fmat(x)
         if x.ndim != 2 or x.shape[1] != om.d:
             raise ValueError("x must be n x d")
@@ -312,9 +321,10 @@ class outerbase:
         self.vertpl = False
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None and _lib.lib is not None:
+        if getattr(self, "_h", None) and getattr(self, "_owned", False) and _lib is not None \
+                and _lib.lib is not None:
             _lib.lib.obhip_basis_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def build(self):
         call("obhip_basis_rebuild", self._h)
@@ -446,516 +456,259 @@ def rvar(y):
 
 
 # ----------------------------------------------------------------------------
-# lpdf family (interfaceR.cpp:696-762), value paths
+# lpdf family (interfaceR.cpp:696-762): holders of an obhip_lpdf handle
 # ----------------------------------------------------------------------------
+_LOGLIK_STD, _LOGLIK_GAUSS, _LOGLIK_GDA, _LOGPR_GAUSS, _LPDF_VEC = range(5)
+_FLAGS = {"compute_val": 0, "compute_grad": 1, "compute_gradhyp": 2, "compute_gradpara": 3,
+          "fullhess": 4, "domarg": 5, "dodiag": 6}
+_VECS = {"coeff": 0, "grad": 1, "gradhyp": 2, "gradpara": 3, "para": 4, "para0": 5, "paravar": 6,
+         "totdiaghess": 7, "coeffsd": 8, "yhat": 9}
+
+
 class lpdf:
-    def __init__(self):
-        self.val = 0.0
-        self.coeff = np.zeros(0)
-        self.grad = np.zeros(0)
-        self.para = np.zeros(0)
-        self.nterms = 0
-        self.fullhess = False
-        self.compute_val = True
-        self.compute_grad = True
-        self.compute_gradhyp = False   # fit.h:36-38
-        self.compute_gradpara = False
-        self.gradhyp = np.zeros(0)
-        self.gradpara = np.zeros(0)
-        self.paranames = []
+    """class lpdf (fit.h:23-90, module rows interfaceR.cpp:696-723).  Fields are read from
+    the object behind the handle on every access."""
+    _h = None
 
-    def setnthreads(self, k):  # fit.h:57 (no-op on the device)
-        return None
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None and _lib.lib is not None:
+            _lib.lib.obhip_lpdf_destroy(self._h)
+            self._h = None
 
-    def paralpdf(self, parap):
-        parap = np.asarray(parap, dtype=np.float64)
-        if len(parap) != len(self.para0):
-            return -np.inf
-        return float(-0.5 * np.sum((parap - self.para0) ** 2 / self.paravar))  # fit.cpp:133-139
+    # -- fields ---------------------------------------------------------------------------
+    def __getattr__(self, name):
+        if name in _FLAGS:
+            v = C.c_int(0)
+            call("obhip_lpdf_get_flag", self._h, _FLAGS[name], C.byref(v))
+            return bool(v.value)
+        if name in _VECS:
+            n = C.c_uint64(0)
+            call("obhip_lpdf_get_vec", self._h, _VECS[name], None, 0, C.byref(n))
+            out = np.empty(n.value)
+            call("obhip_lpdf_get_vec", self._h, _VECS[name], ptr(out), n.value, None)
+            return out
+        if name == "val":
+            v = C.c_double(0)
+            call("obhip_lpdf_get_val", self._h, C.byref(v))
+            return v.value
+        if name in ("nterms", "npara"):
+            return self._dims()[name]
+        if name == "paranames":
+            out = []
+            for i in range(self._dims()["npara"]):
+                s = C.c_char_p()
+                call("obhip_lpdf_paraname", self._h, i, C.byref(s))
+                out.append(s.value.decode())
+            return out
+        if name == "terms":
+            dd = self._dims()
+            t = np.empty((dd["nterms"], self.om.d), dtype=np.uint64, order="F")
+            call("obhip_lpdf_terms", self._h, ptr(t))
+            return t.astype(np.int64)
+        raise AttributeError(name)
 
-    def paralpdf_grad(self, parap):
-        parap = np.asarray(parap, dtype=np.float64)
-        if len(parap) != len(self.para0):
-            return np.zeros(len(self.para))
-        return -(parap - self.para0) / self.paravar                            # fit.cpp:146-157
+    def __setattr__(self, name, value):
+        if name in _FLAGS:
+            call("obhip_lpdf_set_flag", self._h, _FLAGS[name], int(bool(value)))
+        else:
+            object.__setattr__(self, name, value)
+
+    def _dims(self):
+        k, nt, npar, nh, n = C.c_int(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        call("obhip_lpdf_dims", self._h, C.byref(k), C.byref(nt), C.byref(npar), C.byref(nh),
+             C.byref(n))
+        return dict(kind=k.value, nterms=nt.value, npara=npar.value, nhyp=nh.value, n=n.value)
+
+    # -- methods (interfaceR.cpp:710-722) ---------------------------------------------------
+    def setnthreads(self, k):  # fit.h:57 (no meaning on the device)
+        call("obhip_lpdf_setnthreads", self._h, int(k))
+
+    def update(self, coeff):
+        c = _f64(coeff)
+        call("obhip_lpdf_update", self._h, ptr(c), len(c))
+
+    def updateom(self):
+        call("obhip_lpdf_updateom", self._h)
+
+    def updatepara(self, para):
+        pp = _f64(np.asarray(para, dtype=np.float64).reshape(-1))
+        call("obhip_lpdf_updatepara", self._h, ptr(pp), len(pp))
+
+    def updateterms(self, terms):
+        t = _umat(terms)
+        call("obhip_lpdf_updateterms", self._h, ptr(t), t.shape[0])
+
+    def hessmult(self, g):
+        g = _f64(g)
+        if len(g) != self.nterms:
+            raise ValueError("non-conformable arguments")
+        out = np.empty(len(g))
+        call("obhip_lpdf_hessmult", self._h, ptr(g), ptr(out))
+        return out
+
+    def diaghess(self):
+        out = np.empty(self.nterms)
+        call("obhip_lpdf_diaghess", self._h, ptr(out))
+        return out
+
+    def diaghessgradhyp(self):
+        dd = self._dims()
+        out = np.empty((dd["nterms"], dd["nhyp"]), order="F")
+        call("obhip_lpdf_diaghessgradhyp", self._h, ptr(out))
+        return out
+
+    def diaghessgradpara(self):
+        dd = self._dims()
+        out = np.empty((dd["nterms"], dd["npara"]), order="F")
+        call("obhip_lpdf_diaghessgradpara", self._h, ptr(out))
+        return out
+
+    def hess(self):
+        p = self.nterms
+        out = np.empty((p, p), order="F")
+        call("obhip_lpdf_hess", self._h, ptr(out))
+        return out
 
     def optcg(self, tol, maxepch):
-        """lpdf::optcg (fit.cpp:37-96), generic form: diagonally preconditioned CG on
-        update / hessmult / diaghess of this object (the n-passes run on the device through
-        those methods, the p-vector algebra here).  lpdfvec overrides it with the
-        device-resident loop when the likelihood has one noise level."""
-        self.fullhess = False
-        self.compute_gradhyp = self.compute_gradpara = False
-        if len(self.coeff) != self.nterms:
-            self.coeff = np.zeros(self.nterms)
-        coeff = np.array(self.coeff, dtype=np.float64)
-        self.update(coeff)
-        m = self.diaghess()
-        if not np.all(np.isfinite(m)) and not np.all(np.isfinite(self.grad)):
-            self.val = -np.inf
-            return
-        rm = self.grad / m
-        pv = rm.copy()
-        q = self.hessmult(pv)
-        valdiff = 10.0
-        self.cgiters = 0
-        num0 = None
-        for _ in range(int(maxepch)):
-            num = float(np.sum(self.grad * rm))
-            if num < tol and valdiff < tol:
-                break
-            if num0 is None:
-                num0 = num
-            if num <= 1e-28 * num0:   # rounding floor, see obhip_fit_cg_dev
-                break
-            if not num > 0.0:     # exactly stationary: the next direction would be 0 / 0
-                break
-            denom = float(np.sum(q * pv))
-            if not denom > 0.0:   # the direction cancelled to zero (p = 1, second iteration)
-                break
-            alpha = num / denom
-            coeff = coeff + alpha * pv
-            valo = self.val
-            self.update(coeff)
-            valdiff = self.val - valo
-            rm = self.grad / m
-            beta = -float(np.sum((alpha * q) * rm)) / num
-            pv = rm + beta * pv
-            q = self.hessmult(pv)
-            self.cgiters += 1
-        self.compute_gradhyp = self.compute_gradpara = True    # fit.cpp:87-93
-        self.update(coeff)
-        self.compute_gradhyp = self.compute_gradpara = False
+        it = C.c_uint64(0)
+        call("obhip_lpdf_optcg", self._h, float(tol), int(maxepch), C.byref(it))
+        self.cgiters = it.value
+
+    def optnewton(self):
+        call("obhip_lpdf_optnewton", self._h)
+
+    def paralpdf(self, parap):
+        pp = _f64(np.asarray(parap, dtype=np.float64).reshape(-1))
+        out = C.c_double(0)
+        call("obhip_lpdf_paralpdf", self._h, ptr(pp), len(pp), C.byref(out))
+        return out.value
+
+    def paralpdf_grad(self, parap):
+        pp = _f64(np.asarray(parap, dtype=np.float64).reshape(-1))
+        out = np.zeros(self.npara)
+        call("obhip_lpdf_paralpdf_grad", self._h, ptr(pp), len(pp), ptr(out))
+        return out
 
 
 class logpr_gauss(lpdf):
-    """src/lpdfs/logpr_gauss.cpp:41-158"""
+    """src/lpdfs/logpr_gauss.cpp:41-186 (interfaceR.cpp:752-756)"""
 
     def __init__(self, om, terms):
-        super().__init__()
+        om._need()
         self.om = om
-        self.terms = np.asarray(terms).astype(np.int64)
-        self.para0 = np.array([6.0])
-        self.paravar = np.array([4.0])
-        self.paranames = ["coeffscale"]
-        self.para = self.para0.copy()
-        self.nterms = self.terms.shape[0]
-        self.updateom()
-
-    def updateom(self):
-        self.coeffsd = np.sqrt(self.om.getvar(self.terms))
-        self.coefflvarge = self.om.getlvar_gradhyp(self.terms)   # logpr_gauss.cpp:80
-
-    def updatepara(self, para):
-        self.para = np.array(para, dtype=np.float64).reshape(-1)
-
-    def updateterms(self, terms):
-        self.terms = np.asarray(terms).astype(np.int64)
-        self.nterms = self.terms.shape[0]
-        self.updateom()
-
-    def update(self, coeff):
-        self.coeff = np.array(coeff, dtype=np.float64)
-        sca = math.exp(self.para[0])
-        stdresid = self.coeff / (self.coeffsd * sca)
-        self.val = float(-0.5 * np.sum(stdresid ** 2) - np.sum(np.log(self.coeffsd * sca)))
-        if self.compute_gradhyp:      # logpr_gauss.cpp:102
-            self.gradhyp = (0.5 * self.coefflvarge).T @ (stdresid ** 2 - 1)
-        if self.compute_gradpara:     # :103
-            self.gradpara = np.array([np.sum(stdresid ** 2) - len(self.coeffsd)])
-        self.grad = -1.0 * stdresid / (self.coeffsd * sca)
-
-    def diaghess(self):
-        return 1.0 / np.square(self.coeffsd * math.exp(self.para[0]))
-
-    def diaghessgradhyp(self):        # logpr_gauss.cpp:131-135
-        return -self.coefflvarge / np.square(self.coeffsd * math.exp(self.para[0]))[:, None]
-
-    def diaghessgradpara(self):       # logpr_gauss.cpp:143-145
-        return (-2.0 / np.square(self.coeffsd * math.exp(self.para[0])))[:, None]
-
-    def hessmult(self, g):
-        return np.asarray(g) / np.square(self.coeffsd * math.exp(self.para[0]))
+        t = _umat(terms)
+        if t.shape[1] != om.d:
+            raise ValueError("terms must have one column per input dimension")
+        h = C.c_void_p()
+        call("obhip_logpr_gauss_create", C.byref(h), om._h, ptr(t), t.shape[0])
+        self._h = h
 
 
 class _loglik(lpdf):
+    _kind = None
+
     def __init__(self, om, terms, y, x):
-        super().__init__()
+        om._need()
         self.om = om
-        self.y = _f64(y)
-        self.x = _fmat(x)
-        self._t = _Terms(om, terms)
-        self.terms = self._t.array
-        self.nterms = self._t.p
-        self.para0 = np.array([math.log(0.01 * rvar(self.y))])  # loglik_std.cpp:51
-        self.paravar = np.array([1.0])
-        self.paranames = ["noisescale"]
-        self.para = self.para0.copy()
-        # the basis is evaluated up to the highest level the terms use
-        self.ob = outerbase(om, self.x, levelcap=self._t.maxlevels())
-        self.yhat = np.zeros(len(self.y))
+        y = _f64(y)
+        x = _fmat(x)
+        t = _umat(terms)
+        if x.ndim != 2 or x.shape[1] != om.d or x.shape[0] != len(y):
+            raise ValueError("x must be n x d and y must have n entries")
+        if t.shape[1] != om.d:
+            raise ValueError("terms must have one column per input dimension")
+        h = C.c_void_p()
+        call("obhip_loglik_create", C.byref(h), self._kind, om._h, ptr(t), t.shape[0], ptr(y),
+             ptr(x), x.shape[0], x.shape[0])
+        self._h = h
+        self.y = y
+        self.x = x
 
-    def updateom(self):
-        self.ob.build()
+    @property
+    def ob(self):
+        """the outerbase the likelihood owns (member `ob`, fit.h:185)"""
+        b = C.c_void_p()
+        call("obhip_lpdf_basis", self._h, C.byref(b), None)
+        return outerbase(self.om, None, _borrow=(b, len(self.y)))
 
-    def updatepara(self, para):
-        self.para = np.array(para, dtype=np.float64).reshape(-1)
-
-    def updateterms(self, terms):
-        self._t = _Terms(self.om, terms)
-        self.terms = self._t.array
-        self.nterms = self._t.p
-        self.ob = outerbase(self.om, self.x, levelcap=self._t.maxlevels())
-
-    def update(self, coeff):
-        # loglik_gauss.cpp:110-130 / loglik_std.cpp:100-120
-        self.coeff = np.array(coeff, dtype=np.float64)
-        s = self.para[0]
-        self.yhat = self.ob.matmul(self._t, self.coeff)
-        resid = math.exp(-s) * (self.yhat - self.y)
-        self.val = float(-0.5 * np.sum(resid ** 2) - len(self.y) * s)
-        r2 = -math.exp(-s) * resid
-        self.grad = self.ob.tmatmul(self._t, r2)
-        if self.compute_gradhyp:      # loglik_gauss.cpp:114-117,127
-            self.gradhyp = self.ob.matmul_gradhyp_dot(self._t, self.coeff, r2)
-        if self.compute_gradpara:     # :128
-            self.gradpara = np.array([np.sum(resid ** 2) - len(self.y)])
-
-    def hessmult(self, g):
-        v = self.ob.matmul(self._t, np.asarray(g, dtype=np.float64))
-        return self.ob.tmatmul(self._t, math.exp(-2 * self.para[0]) * v)
-
-    def diaghess(self):
-        return math.exp(-2 * self.para[0]) * self.ob.sqcolsums(self._t)
-
-    def diaghessgradhyp(self):        # loglik_gauss.cpp:158-161
-        return math.exp(-2 * self.para[0]) * self.ob.sqcolsums_gradhyp(self._t)
-
-    def diaghessgradpara(self):       # loglik_gauss.cpp:169-172
-        return (-2 * math.exp(-2 * self.para[0]) * self.ob.sqcolsums(self._t))[:, None]
+    @property
+    def _t(self):
+        return _Terms(self.om, self.terms)
 
 
 class loglik_gauss(_loglik):
-    """src/lpdfs/loglik_gauss.cpp:41-157 (matrix-free)"""
+    """src/lpdfs/loglik_gauss.cpp:41-172 (matrix-free; interfaceR.cpp:739-743)"""
+    _kind = _LOGLIK_GAUSS
 
 
 class loglik_std(_loglik):
-    """src/lpdfs/loglik_std.cpp:41-173.  The reference materialises the design
-    matrix; here it stays factored and hess() runs the fused Gram kernel."""
-
-    def hess(self):
-        G = _gram_host(self.ob, self._t)
-        return math.exp(-2 * self.para[0]) * G
+    """src/lpdfs/loglik_std.cpp:41-203 (interfaceR.cpp:733-737).  The reference materialises
+    the design matrix; here it stays factored and hess() runs the Gram kernel."""
+    _kind = _LOGLIK_STD
 
 
 class loglik_gda(_loglik):
-    """src/lpdfs/loglik_gda.cpp:48-235: Gaussian likelihood whose per-observation variance
-    adds the residual variance of the truncated expansion (the diagonal adjustment,
-    field `dodiag`), composed from the device products (residvar, sqtmm, the *_gradhyp
-    family); the n-vectors live on the host as in the Rcpp module."""
-
-    def __init__(self, om, terms, y, x):
-        super().__init__(om, terms, y, x)
-        self.para0 = np.array([0.5 * math.log(0.01 * rvar(self.y)), 0.0])   # :58-60
-        self.paravar = np.array([4.0, 4.0])
-        self.paranames = ["noisescale", "lik.coeffscale"]
-        self.para = self.para0.copy()
-        self.dodiag = True
-        self._redostd = True
-
-    def updateom(self):
-        super().updateom()
-        self._redostd = True
-
-    def updatepara(self, para):
-        super().updatepara(para)
-        self._redostd = True
-
-    def updateterms(self, terms):
-        super().updateterms(terms)
-        self._redostd = True
-
-    def _buildstd(self):              # :215-235
-        if not self._redostd:
-            return
-        e0, e1 = math.exp(2 * self.para[0]), math.exp(2 * self.para[1])
-        rterms = self.ob.residvar(self._t)
-        obsvar = np.full(len(self.y), e0)
-        if self.dodiag:
-            obsvar = obsvar + e1 * rterms
-        self.obssd = np.sqrt(obsvar)
-        if self.dodiag:
-            self.obssd_gradhyp = self.ob.residvar_gradhyp(self._t) * ((e1 * 0.5) / self.obssd)[:, None]
-        self.obssd_gradpara = np.zeros((len(self.y), 2))
-        self.obssd_gradpara[:, 0] = e0 / self.obssd
-        if self.dodiag:
-            self.obssd_gradpara[:, 1] = e1 * rterms / self.obssd
-        self._redostd = False
-
-    def update(self, coeff):          # :117-153
-        self.coeff = np.array(coeff, dtype=np.float64)
-        self.yhat = self.ob.matmul(self._t, self.coeff)
-        self._buildstd()
-        r = (self.yhat - self.y) / self.obssd
-        r2 = np.square(r)
-        self.val = float(-0.5 * np.sum(r2) - np.sum(np.log(self.obssd)))
-        r = -r / self.obssd
-        r2 = r2 / self.obssd
-        self.grad = self.ob.tmatmul(self._t, r)
-        if self.compute_gradhyp:
-            self.gradhyp = self.ob.matmul_gradhyp_dot(self._t, self.coeff, r)
-            if self.dodiag:
-                self.gradhyp = self.gradhyp + r2 @ self.obssd_gradhyp \
-                    - (1.0 / self.obssd) @ self.obssd_gradhyp
-        if self.compute_gradpara:
-            self.gradpara = r2 @ self.obssd_gradpara - (1.0 / self.obssd) @ self.obssd_gradpara
-
-    def hessmult(self, g):            # :160-169
-        v = self.ob.matmul(self._t, np.asarray(g, dtype=np.float64))
-        return self.ob.tmatmul(self._t, v / np.square(self.obssd))
-
-    def diaghess(self):               # :177-180
-        self._buildstd()
-        return self.ob.sqtmm(self._t, 1.0 / np.square(self.obssd))
-
-    def diaghessgradhyp(self):        # :187-200
-        self._buildstd()
-        temp = 1.0 / np.square(self.obssd)
-        lh = self.ob.sqtmm_gradhyp(self._t, temp)
-        if self.dodiag:
-            lh = lh + self.ob.sqtmm(self._t, self.obssd_gradhyp * (temp * (-2.0 / self.obssd))[:, None])
-        return lh
-
-    def diaghessgradpara(self):       # :207-214
-        self._buildstd()
-        temp = (1.0 / np.square(self.obssd)) * (-2.0 / self.obssd)
-        return self.ob.sqtmm(self._t, self.obssd_gradpara * temp[:, None])
-
-
-def _gram_host(ob, t):
-    """B^T B through the device Gram kernel, returned to the host."""
-    import torch
-    if not torch.cuda.is_available():
-        raise _lib.ObhipError(2, "no HIP device visible: libobhip has no CPU fallback")
-    G = torch.empty((t.p, t.p), dtype=torch.float64, device="cuda")
-    call("obhip_gram_dev", ob._h, t._h, None, ptr(G), None)
-    torch.cuda.synchronize()
-    return G.cpu().numpy()
+    """src/lpdfs/loglik_gda.cpp:48-235 (interfaceR.cpp:745-750): Gaussian likelihood whose
+    per-observation variance adds the residual variance of the truncated expansion (field
+    `dodiag`)."""
+    _kind = _LOGLIK_GDA
 
 
 class lpdfvec(lpdf):
-    """src/fit.cpp:174-380 for a (likelihood, prior) pair; domarg switches the marginal
-    adjustment on in its diagonal form (what obfit uses, R/fitting.R:110)."""
+    """src/fit.cpp:174-612 (interfaceR.cpp:758-762): a pair of lpdfs; field `domarg`."""
 
     def __init__(self, a, b):
-        super().__init__()
+        if not isinstance(a, lpdf) or not isinstance(b, lpdf):
+            raise ValueError("lpdfvec needs two lpdf objects")
+        h = C.c_void_p()
+        call("obhip_lpdfvec_create", C.byref(h), a._h, b._h)
+        self._h = h
+        self.lpdflist = [a, b]          # keeps the members alive (fit.h:133 holds references)
+        self.om = a.om
         liks = [o for o in (a, b) if isinstance(o, _loglik)]
         prs = [o for o in (a, b) if isinstance(o, logpr_gauss)]
-        if len(liks) != 1 or len(prs) != 1:
-            raise ValueError("lpdfvec needs one likelihood and one logpr_gauss")
-        self.lpdflist = [a, b]
-        self.loglik, self.logpr = liks[0], prs[0]
-        self.terms = self.loglik.terms
-        self.nterms = self.loglik.nterms
-        self.para = np.concatenate([a.para, b.para])
-        self.para0 = np.concatenate([a.para0, b.para0])
-        self.paravar = np.concatenate([a.paravar, b.paravar])
-        self.paranames = a.paranames + b.paranames
-        self.domarg = True            # fit.h:98 (field domargadj)
-        self.coeff = np.zeros(self.nterms)
-        self.totdiaghess = None
-        self.tothess = None
-
-    def _sigma_rho(self):
-        return float(self.loglik.para[0]), float(self.logpr.para[0])
-
-    def updateom(self):
-        for o in self.lpdflist:
-            o.updateom()
-
-    def updatepara(self, para):
-        para = np.array(para, dtype=np.float64).reshape(-1)
-        n0 = len(self.lpdflist[0].para)
-        self.lpdflist[0].updatepara(para[:n0])
-        self.lpdflist[1].updatepara(para[n0:])
-        self.para = para
-
-    def updateterms(self, terms):
-        for o in self.lpdflist:
-            o.updateterms(terms)
-        self.terms = self.loglik.terms
-        self.nterms = self.loglik.nterms
-        self.coeff = np.zeros(self.nterms)
-
-    def update(self, coeff):
-        self.coeff = np.array(coeff, dtype=np.float64)
-        for o in self.lpdflist:       # fit.cpp:323-328: the flags are pushed down
-            o.compute_gradhyp = self.compute_gradhyp
-            o.compute_gradpara = self.compute_gradpara
-            o.update(self.coeff)
-        self.val = sum(o.val for o in self.lpdflist)
-        self.grad = self.lpdflist[0].grad + self.lpdflist[1].grad
-        if self.compute_gradhyp:      # fit.cpp:339-342,347-352: summed over the list
-            self.gradhyp = self.lpdflist[0].gradhyp + self.lpdflist[1].gradhyp
-        if self.compute_gradpara:     # concatenated like para
-            self.gradpara = np.concatenate([self.lpdflist[0].gradpara, self.lpdflist[1].gradpara])
-        if self.domarg:
-            self._margadj()
-
-    def _settotdiaghess(self, D):     # lpdfvec::settotdiaghess: the members see it too
-        self.totdiaghess = D
-        for o in self.lpdflist:
-            o.totdiaghess = D
-
-    def _margadj(self):
-        """Marginal adjustment (lpdfvec::buildhess fit.cpp:252-299, margadj :371-380):
-        -1/2 sum log diag(H) and its hyp / para gradients in the diagonal form; with the
-        full Hessian (after optnewton) -1/2 log det H and -1/2 tr(inv(H) dH)."""
-        if self.fullhess:
-            # -1/2 log det H and -1/2 tr(inv(H) dH) on the device (obhip_margadj_full)
-            lik, pr = self.loglik, self.logpr
-            nh = len(lik.om.grad_layout()[0])
-            H = _fmat(self.hess())
-            val = C.c_double(0)
-            gh, gp = np.zeros(nh), np.zeros(2)
-            want_g = self.compute_gradhyp or self.compute_gradpara
-            call("obhip_margadj_full", lik.ob._h, lik._t._h, lik.om._h, ptr(H), float(lik.para[0]),
-                 float(pr.para[0]), C.byref(val), ptr(gh) if want_g else None,
-                 ptr(gp) if want_g else None)
-            self.val += val.value
-            if self.compute_gradhyp:
-                self.gradhyp = self.gradhyp + gh
-            if self.compute_gradpara:
-                order = [gp[0] if o is lik else gp[1] for o in self.lpdflist]
-                self.gradpara = self.gradpara + np.array(order)
-            return
-        D = self.diaghess()
-        self._settotdiaghess(D)
-        self.val += float(-0.5 * np.sum(np.log(D)))
-        if self.compute_gradhyp:
-            dgh = self.lpdflist[0].diaghessgradhyp() + self.lpdflist[1].diaghessgradhyp()
-            self.gradhyp = self.gradhyp - 0.5 * np.sum(dgh / D[:, None], axis=0)
-        if self.compute_gradpara:
-            dgp = np.concatenate([self.lpdflist[0].diaghessgradpara(),
-                                  self.lpdflist[1].diaghessgradpara()], axis=1)
-            self.gradpara = self.gradpara - 0.5 * np.sum(dgp / D[:, None], axis=0)
-
-    def hessmult(self, g):
-        return self.lpdflist[0].hessmult(g) + self.lpdflist[1].hessmult(g)
-
-    def diaghess(self):
-        return self.lpdflist[0].diaghess() + self.lpdflist[1].diaghess()
-
-    def hess(self):
-        H = self.loglik.hess()
-        H[np.diag_indices_from(H)] += self.logpr.diaghess()
-        return H
-
-    def optnewton(self):
-        """lpdf::optnewton (fit.cpp:98-131): Gram + Cholesky on the device."""
-        if not isinstance(self.loglik, loglik_std):
-            raise RuntimeError("optnewton needs a loglik_std (loglik_gauss never builds a Hessian)")
-        self.fullhess = True
-        sigma, rho = self._sigma_rho()
-        p = self.nterms
-        theta = np.zeros(p)
-        diagH = np.zeros(p)
-        call("obhip_fit_newton", self.loglik.ob._h, self.loglik._t._h, self.loglik.om._h,
-             ptr(self.loglik.y), sigma, rho, ptr(theta), ptr(diagH), None)
-        self._settotdiaghess(diagH)
-        self.compute_gradhyp = self.compute_gradpara = True    # fit.cpp:122-128
-        self.update(theta)
-        self.compute_gradhyp = self.compute_gradpara = False
-
-    def optcg(self, tol, maxepch):
-        """lpdf::optcg (fit.cpp:37-96): matrix-free PCG, device-resident for a likelihood
-        with one noise level; the generic loop of lpdf.optcg otherwise (loglik_gda)."""
-        if isinstance(self.loglik, loglik_gda):
-            return lpdf.optcg(self, tol, maxepch)
-        self.fullhess = False
-        sigma, rho = self._sigma_rho()
-        p = self.nterms
-        theta = np.array(self.coeff if len(self.coeff) == p else np.zeros(p), dtype=np.float64)
-        diagH = np.zeros(p)
-        iters = C.c_uint64(0)
-        val = C.c_double(0)
-        call("obhip_fit_cg", self.loglik.ob._h, self.loglik._t._h, self.loglik.om._h,
-             ptr(self.loglik.y), sigma, rho, float(tol), int(maxepch), ptr(theta), C.byref(iters),
-             ptr(diagH), C.byref(val))
-        self._settotdiaghess(diagH)
-        self.cgiters = iters.value
-        self.compute_gradhyp = self.compute_gradpara = True    # fit.cpp:87-93
-        self.update(theta)
-        self.compute_gradhyp = self.compute_gradpara = False
+        self.loglik = liks[0] if liks else None
+        self.logpr = prs[0] if prs else None
 
 
 class predictor:
     """interfaceR.cpp:725-731: the predictor that belongs to the likelihood (lpdf::pred):
     pred_gauss (loglik_gauss.cpp:196-227), predr_std (loglik_std.cpp:218-256) with the full
-    posterior covariance, pred_gda (loglik_gda.cpp:247-281)."""
+    posterior covariance after optnewton, pred_gda (loglik_gda.cpp:247-281)."""
 
     def __init__(self, logpdf):
-        lik = logpdf.loglik if isinstance(logpdf, lpdfvec) else logpdf
-        if not isinstance(lik, _loglik):
-            raise ValueError("cannot produce a predictor from this obj.")  # fit.h:53
-        self.om = lik.om
-        self._t = lik._t
-        self._lik = lik
-        self.coeff = np.array(lik.coeff if len(lik.coeff) == lik.nterms
-                              else np.zeros(lik.nterms), dtype=np.float64)
-        self.para = np.array(lik.para, dtype=np.float64)
-        self.sigma = float(lik.para[0])
-        # lpdfvec::settotdiaghess / settothess hand the Hessian pieces to the members
-        td = getattr(logpdf, "totdiaghess", None)
-        if td is None:
-            td = getattr(lik, "totdiaghess", None)
-        self.totdiaghess = None if td is None else np.asarray(td, dtype=np.float64)
-        self.coeffvar = (1.0 / self.totdiaghess) if td is not None else np.zeros(lik.nterms)
-        self.tothess = None
-        if isinstance(lik, loglik_std) and isinstance(logpdf, lpdfvec) and logpdf.fullhess:
-            self.tothess = _fmat(logpdf.hess())      # loglik_std.cpp:226-227 (didfulltothess)
-        self.x = lik.x
-        self._mean = None
-        self._var = None
+        if not isinstance(logpdf, lpdf):
+            raise ValueError("cannot produce a predictor from this obj.")
+        h = C.c_void_p()
+        call("obhip_predictor_create", C.byref(h), logpdf._h)      # fit.h:53 for non-likelihoods
+        self._h = h
+        self.om = logpdf.om
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None and _lib.lib is not None:
+            _lib.lib.obhip_predictor_destroy(self._h)
+            self._h = None
 
     def setnthreads(self, k):
-        return None
+        call("obhip_predictor_setnthreads", self._h, int(k))
 
     def update(self, x):
         x = _fmat(x)
         if x.ndim != 2 or x.shape[1] != self.om.d:
             raise ValueError("x must be n x d")
-        n = x.shape[0]
-        self._mean = np.empty(n)
-        self._var = np.empty(n)
-        lik = self._lik
-        if isinstance(lik, loglik_std) and self.tothess is not None:
-            # predr_std::var with coeffcov = inv(tothess), loglik_std.cpp:249-256
-            call("obhip_predict_std", self.om._h, self._t._h, ptr(_f64(self.coeff)),
-                 ptr(self.tothess), ptr(x), n, n, ptr(self._mean), self.sigma, ptr(self._var))
-        else:
-            # pred_gauss::var = B^2 (1 / totdiaghess) + e^{2 sigma} (loglik_gauss.cpp:224-225);
-            # predr_std without a full Hessian puts totdiaghess ITSELF on the diagonal of
-            # coeffcov (loglik_std.cpp:228-232) -- kept as the reference has it
-            cv = self.coeffvar
-            if isinstance(lik, loglik_std):
-                cv = self.totdiaghess if self.totdiaghess is not None else np.zeros(lik.nterms)
-            cv = _f64(cv)
-            call("obhip_predict", self.om._h, self._t._h, ptr(_f64(self.coeff)), ptr(x), n, n,
-                 ptr(self._mean), ptr(cv), self.sigma, ptr(self._var))
-            if isinstance(lik, loglik_gda) and lik.dodiag:
-                # pred_gda::var adds the residual variance of the truncated expansion
-                # (loglik_gda.cpp:276-281)
-                obn = outerbase(self.om, x, levelcap=self._t.maxlevels())
-                self._var = self._var + math.exp(2 * self.para[1]) * obn.residvar(self._t)
-        self.x = x
+        call("obhip_predictor_update", self._h, ptr(x), x.shape[0], x.shape[0])
+
+    def _n(self):
+        n = C.c_uint64(0)
+        call("obhip_predictor_n", self._h, C.byref(n))
+        return n.value
 
     def mean(self):
-        if self._mean is None:
-            self.update(self.x)
-        return self._mean
+        out = np.empty(self._n())
+        call("obhip_predictor_mean", self._h, ptr(out))
+        return out
 
     def var(self):
-        if self._var is None:
-            self.update(self.x)
-        return self._var
+        out = np.empty(self._n())
+        call("obhip_predictor_var", self._h, ptr(out))
+        return out
