@@ -85,6 +85,10 @@ int obhip_cov_info(int kind, double *hyp0, double *hyplb, double *hypub,
  * column-major.  Host arithmetic (knot-sized problems). */
 int obhip_cov(int kind, const double *hyp, const double *x1, uint64_t n1,
               const double *x2, uint64_t n2, double *out);
+/* covf::cov_gradhyp (covfuncs.cpp:134-150,220-243,318-347; module row interfaceR.cpp:775):
+ * out is n1 x n2 x numhyp, column-major slices.  Host arithmetic. */
+int obhip_cov_gradhyp(int kind, const double *hyp, const double *x1, uint64_t n1,
+                      const double *x2, uint64_t n2, double *out);
 /* covf::lpdf (covfuncs.cpp:35-50) */
 int obhip_cov_hyplpdf(int kind, const double *hyp, double *out);
 
@@ -97,6 +101,8 @@ int obhip_model_destroy(obhip_model *m);
  * (modandbase.h:18), knotpt has knotptst[d]. Triggers outermod::build. */
 int obhip_model_set_knots(obhip_model *m, const uint64_t *knotptst,
                           const double *knotpt);
+/* the knots as set (fields knotptst / knotpt, modandbase.h:18-19); either pointer may be NULL */
+int obhip_model_get_knots(const obhip_model *m, uint64_t *knotptst, double *knotpt);
 /* om$updatehyp(hyp): outermod::hyp_set modandbase.cpp:161-202 */
 int obhip_model_set_hyp(obhip_model *m, const double *hyp, uint64_t nhyp);
 /* gethyp(om): interfaceR.cpp:167-180 */

@@ -335,9 +335,26 @@ int obhip_cov(int kind, const double *hyp, const double *x1, uint64_t n1,
   return 0;
 }
 
+int obhip_cov_gradhyp(int kind, const double *hyp, const double *x1, uint64_t n1, const double *x2,
+                      uint64_t n2, double *out) {
+  if (kind < 0 || kind >= kNumCov) return fail(OBHIP_ERR_INVALID, "bad covariance kind");
+  if (!hyp || (!x1 && n1) || (!x2 && n2) || (!out && n1 * n2))
+    return fail(OBHIP_ERR_INVALID, "null argument");
+  cov_gradhyp_host(kind, hyp, x1, n1, x2, n2, out);
+  return 0;
+}
+
 int obhip_cov_hyplpdf(int kind, const double *hyp, double *out) {
   if (kind < 0 || kind >= kNumCov || !hyp || !out) return fail(OBHIP_ERR_INVALID, "bad argument");
   *out = cov_hyplpdf_host(kind, hyp);
+  return 0;
+}
+
+int obhip_model_get_knots(const obhip_model *m, uint64_t *knotptst, double *knotpt) {
+  if (!m) return fail(OBHIP_ERR_INVALID, "null model");
+  if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
+  if (knotptst) std::copy(m->knotptst.begin(), m->knotptst.end(), knotptst);
+  if (knotpt) std::copy(m->knotpt.begin(), m->knotpt.end(), knotpt);
   return 0;
 }
 

@@ -77,6 +77,14 @@ class covf:
     def covdiag(self, x):
         return np.ones(len(x))  # covfuncs.cpp:128-132
 
+    def cov_gradhyp(self, x1, x2):
+        """n1 x n2 x numhyp cube (covfuncs.cpp:134-150,220-243,318-347)"""
+        x1, x2 = _f64(x1), _f64(x2)
+        out = np.empty((len(x1), len(x2), len(self.hyp)), order="F")
+        call("obhip_cov_gradhyp", _KINDS[self.kind], ptr(_f64(self.hyp)), ptr(x1), len(x1),
+             ptr(x2), len(x2), ptr(out))
+        return out
+
     def lpdf(self, hyp):
         out = C.c_double(0)
         call("obhip_cov_hyplpdf", _KINDS[self.kind], ptr(_f64(hyp)), C.byref(out))
