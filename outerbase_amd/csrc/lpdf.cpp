@@ -667,7 +667,8 @@ struct LpdfVec : obhip_lpdf {
 
   int init(obhip_lpdf *a, obhip_lpdf *b) {  // fit.cpp:174-200
     if (!a || !b) return fail(OBHIP_ERR_INVALID, "lpdfvec: null member");
-    if (a->nterms != b->nterms) return fail(OBHIP_ERR_INVALID, "lpdfvec: members disagree on the terms");
+    // (the members may still disagree on their terms here: obfit pairs the old prior with a
+    // new likelihood and calls updateterms on the pair afterwards, R/fitting.R:106-121)
     kind = OBHIP_LPDF_VEC;
     om = a->om ? a->om : b->om;
     list[0] = a;

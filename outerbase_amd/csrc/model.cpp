@@ -8,6 +8,8 @@
 // 197-212,285-310; src/modandbase.cpp:128-276,350-356,387-440;
 // src/interfaceR.cpp:53-149.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -220,7 +222,9 @@ int obhip_model::build() {
     rotmat_gradhyp.assign(mmax * cur, 0.0);
     logbasisvar_gradhyp.assign(cur, 0.0);
   }
-  for (uint64_t k = 0; k < d; ++k) {
+  // The dimensions are independent eigen-problems writing disjoint slices; a BFGS run calls
+  // this once per function evaluation (om$updatehyp), so they run on host threads.
+  auto build_dim = [&](uint64_t k) {
     const uint64_t lenh = m_of(k), o = knotptst[k];
     const double *xs = &knotpt[o];
     std::vector<double> R(lenh * lenh), w, U;
@@ -297,6 +301,19 @@ int obhip_model::build() {
         }
       }
     }
+  };
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const uint64_t nthr = std::min<uint64_t>({d, (uint64_t)hw, 16});
+  if (nthr <= 1) {
+    for (uint64_t k = 0; k < d; ++k) build_dim(k);
+  } else {
+    std::atomic<uint64_t> next{0};
+    std::vector<std::thread> pool;
+    for (uint64_t t = 0; t < nthr; ++t)
+      pool.emplace_back([&] {
+        for (uint64_t k = next++; k < d; k = next++) build_dim(k);
+      });
+    for (std::thread &th : pool) th.join();
   }
   ++version;
   return 0;

@@ -71,7 +71,7 @@ def test_plain_c_caller_reproduces_golden(tmp_path, path):
     assert relerr(parts["mean"], g["mean"]) < 1e-6            # north_star tolerance
     assert relerr(parts["mean2"], g["mean"]) < 1e-6
     assert relerr(g["B"] @ parts["theta"], g["B"] @ g["theta"]) < 1e-6
-    assert relerr(parts["theta2"], parts["theta"]) < 1e-9     # fused entry point == object path
+    assert relerr(parts["theta2"], parts["theta"]) < 1e-7     # fused entry point == object path (all levels built vs capped: other rounding)
     assert relerr(parts["var_std"], g["var_std"]) < 1e-7
     assert relerr(parts["var_gauss"], g["var_gauss"]) < 1e-9
     assert int(parts["iters"][0]) == int(g["cg_iters"]) == 12
