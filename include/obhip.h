@@ -255,13 +255,12 @@ int obhip_basis_residvar_gradhyp(const obhip_basis *b, const obhip_terms *t, con
  * NULL (then d_g is untouched). */
 int obhip_gram_dev(const obhip_basis *b, const obhip_terms *t,
                    const double *d_y, double *d_G, double *d_g);
-/* Which kernel forms G: 0 = automatic, 1 = FP64 matrix cores with
- * v_mfma_f64_16x16x4_f64, 2 = FP64 vector pipe (register-tiled v_fma_f64),
- * 3 = FP64 matrix cores with v_mfma_f64_4x4x4_4b_f64, operand panels generated
- * inside the kernel (no extra memory), 4 = the same matrix-core tiles fed from a
- * row-major design matrix materialised in HBM (n_pad x p_pad doubles, kept with the
- * basis).  0 picks 4 when that buffer fits in half of the free HBM, else 3, else 1.
- * All give the same G up to summation order; DESIGN.md has the measurements. */
+/* Which kernel forms G: 0 / 4 = FP64 matrix cores (v_mfma_f64_4x4x4_4b_f64) fed from a
+ * row-major design matrix staged in HBM -- all n_pad x p_pad doubles at once (kept with the
+ * basis) when that fits in half of the free memory, in row chunks otherwise; 3 = the same
+ * matrix-core tiles with the operand panels generated inside the kernel (no staging memory;
+ * terms of at most 8 factors on at most 128 used basis columns).  Both give the same G up to
+ * summation order; DESIGN.md has the measurements. */
 int obhip_set_gram_backend(int backend);
 /* bytes of device workspace obhip_newton_solve_dev needs for p terms */
 int obhip_newton_workspace_bytes(uint64_t p, uint64_t *bytes);

@@ -248,7 +248,8 @@ int obhip_gram_dev(const obhip_basis *b, const obhip_terms *t, const double *d_y
 }
 
 int obhip_set_gram_backend(int backend) {
-  if (backend < 0 || backend > 4) return fail(OBHIP_ERR_INVALID, "gram backend must be 0..4");
+  if (backend != 0 && backend != 3 && backend != 4)
+    return fail(OBHIP_ERR_INVALID, "gram backend must be 0 (automatic), 3 (fused) or 4 (staged design matrix)");
   set_gram_backend(backend);
   return 0;
 }

@@ -43,7 +43,8 @@
 
 namespace obhip {
 
-int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, double *d_G);
+int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, double *d_G,
+                       bool accumulate);
 
 namespace {
 
@@ -282,7 +283,7 @@ int run_gram_mfma4(const obhip_basis &b, obhip_terms &t, double *d_G) {
                        ntiles, tps, part);
     OB_HIP(hipGetLastError());
   }
-  return launch_gram_reduce(part, npairs, (int)nsplit, nb, (int)t.p, d_G);
+  return launch_gram_reduce(part, npairs, (int)nsplit, nb, (int)t.p, d_G, false);
 }
 
 }  // namespace

@@ -37,7 +37,8 @@
 
 namespace obhip {
 
-int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, double *d_G);
+int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, double *d_G,
+                       bool accumulate);
 
 namespace {
 
@@ -148,13 +149,20 @@ __device__ __forceinline__ void lds_rd_h1(const uint32_t (&baddr)[4], double (&b
   }
 }
 
+// DBG: one block reports its s_memtime / s_memrealtime span (clock and matrix-pipe cycles per
+// chunk under load, OBHIP_GRAM_DBG=1); the production instantiation carries none of it
+template <bool DBG>
 __global__ void __launch_bounds__(256, 2)
 k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntiles,
             uint64_t tiles_per_split, const uint32_t *__restrict__ pairs,
             double *__restrict__ part, unsigned long long *dbgout) {
   extern __shared__ double T[];  // [2][16][272]
   constexpr int tszb = kCR * kTP * 8;  // bytes per buffer
-  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st0 = 0, sr0 = 0;
+  if constexpr (DBG) {
+    st0 = __builtin_amdgcn_s_memtime();
+    sr0 = __builtin_amdgcn_s_memrealtime();
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,10 +267,12 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntile
         const int col = wn * 64 + j * 16 + ((mblk + r) & 3) * 4 + me;
         out[row * kGT + col] = acc[i][j][r];
       }
-  if (dbgout && blockIdx.x == 7 && blockIdx.y == 3 && tid == 0) {
-    dbgout[0] = __builtin_amdgcn_s_memtime() - st0;
-    dbgout[1] = __builtin_amdgcn_s_memrealtime() - sr0;
-    dbgout[2] = nchunks;
+  if constexpr (DBG) {
+    if (dbgout && blockIdx.x == 7 && blockIdx.y == gridDim.y / 2 && tid == 0) {
+      dbgout[0] = __builtin_amdgcn_s_memtime() - st0;
+      dbgout[1] = __builtin_amdgcn_s_memrealtime() - sr0;
+      dbgout[2] = nchunks;
+    }
   }
 }
 
@@ -305,22 +315,43 @@ int run_materialize(const obhip_basis &b, obhip_terms &t, double *d_B) {
 
 }  // namespace
 
-// the design matrix needs n_pad * p_pad doubles; use it only when it takes at most half
-// of the free HBM (the fused kernel needs none)
+// The staged design matrix needs n_pad * p_pad doubles.  It is kept whole (and with the basis,
+// for the next fit on the same terms) when it takes at most half of the free HBM; otherwise
+// the Gram is accumulated over row chunks staged one after the other.
 bool gram_panel_supports(const obhip_basis &b, const obhip_terms &t) {
-  if (t.Mu > 280) return false;
   const size_t need = (size_t)b.n_pad * t.p_pad * sizeof(double);
   if (b.bmat.n * sizeof(double) >= need) return true;
+  if (getenv("OBHIP_GRAM_CHUNK_ROWS")) return false;  // tests: force the chunked path
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
   return need <= free_b / 2;
 }
 
-// d_B: n_pad x p_pad doubles, row-major (= column-major p_pad x n_pad); padding rows are 0
-int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B) {
-  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
-  if (t.Mu > 280) return fail(OBHIP_ERR_INVALID, "terms touch too many basis columns for the LDS tile");
-  ProfScope ps("materialize_B");
+namespace {
+
+// rows [tile0 * 64, (tile0 + ntiles) * 64) of a basis as a basis of its own for the product
+// kernels (they use bm, scale, Mc, n, n_pad only); owns nothing
+struct RowView {
+  obhip_basis v;
+  RowView(const obhip_basis &b, uint64_t tile0, uint64_t ntiles) {
+    v.model = b.model;
+    v.d = b.d;
+    v.device = b.device;
+    v.md.Mc = b.md.Mc;
+    v.n_pad = ntiles * kTileRows;
+    const uint64_t r0 = tile0 * kTileRows;
+    v.n = r0 >= b.n ? 0 : std::min<uint64_t>(v.n_pad, b.n - r0);
+    v.bm.p = b.bm.p + tile0 * b.md.Mc * kTileRows;
+    v.scale.p = b.scale.p + r0;
+  }
+  ~RowView() {
+    v.bm.p = nullptr;  // borrowed
+    v.scale.p = nullptr;
+  }
+};
+
+int materialize_any(const obhip_basis &b, obhip_terms &t, double *d_B) {
+  if (t.Mu > 280 || getenv("OBHIP_FORCE_GENERIC")) return launch_materialize_generic(b, t, d_B);
   static const bool lane_row = getenv("OBHIP_MATERIALIZE_LANE_ROW") != nullptr;
   if (!lane_row && materialize_tl_supports(t)) return launch_materialize_tl(b, t, d_B);
   switch (t.W / 2) {
@@ -332,41 +363,20 @@ int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B) {
   }
 }
 
-// b.bmat = row-major design matrix of (b, t); kept until the basis is rebuilt or other
-// terms need the buffer
-int ensure_bmat(obhip_basis &b, obhip_terms &t) {
-  if (b.bmat_terms == t.uid && t.uid != 0) return 0;
-  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
-  if (!gram_panel_supports(b, t))
-    return fail(OBHIP_ERR_INVALID, "not enough free HBM for the n x p design matrix");
-  const size_t need = (size_t)b.n_pad * t.p_pad;
-  if (b.bmat.n < need) OB_TRY(b.bmat.alloc(need));
-  b.bmat_terms = 0;
-  OB_TRY(launch_materialize_rows(b, t, b.bmat.p));
-  b.bmat_terms = t.uid;
-  return 0;
-}
-
-int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
-  obhip_basis &b = const_cast<obhip_basis &>(bc);
-  if (!gram_panel_supports(b, t))
-    return fail(OBHIP_ERR_INVALID, "materialised-B Gram kernel: not enough free HBM for n x p doubles");
-  OB_TRY(ensure_bmat(b, t));
-  // OBHIP_GRAM_DBG=1: print one block's s_memtime / s_memrealtime span (clock and
-  // matrix-pipe cycles per chunk under load)
+// partial tiles of B^T B over the ntiles row tiles of d_B, reduced into d_G
+int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_terms &t, double *d_G,
+                   bool accumulate) {
+  // OBHIP_GRAM_DBG=1: print one block's s_memtime / s_memrealtime span
   const bool dbg = getenv("OBHIP_GRAM_DBG") && atoi(getenv("OBHIP_GRAM_DBG")) != 0;
   const int nb = (int)((t.p + kGT - 1) / kGT);
   const int npairs = nb * (nb + 1) / 2;
-  const uint64_t ntiles = b.n_pad / kTileRows;
   // Row split: two blocks per CU at a time and all blocks equally long, so the launch takes
   // ceil(blocks / slots) rounds of tiles-per-split each; pick the split that minimises that
   // product (528 pairs x 32 splits = 33 x 512 exactly on MI355X), 2 tiles per block charged
   // for its prologue and partial-tile write.
-  static int ncu = 0;
-  if (!ncu) {
-    OB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b.device));
-    if (ncu <= 0) ncu = 256;
-  }
+  int ncu = 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b.device) != hipSuccess || ncu <= 0)
+    ncu = 256;
   const uint64_t slots = 2 * (uint64_t)ncu;
   uint64_t nsplit = 1, best = ~0ull;
   const uint64_t max_split = std::max<uint64_t>(
@@ -391,13 +401,19 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
     b.gram_pairs_nb = nb;
   }
   const size_t lds = (size_t)2 * kCR * kTP * sizeof(double);
-  OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma2, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)lds));
   {
     ProfScope ps("gram");
-    hipLaunchKernelGGL(k_gram_dma2, dim3((unsigned)npairs, (unsigned)nsplit), dim3(256), lds,
-                       cur_stream(), b.bmat.p, t.p_pad, nb, ntiles, tps, b.gram_pairs.p, part,
-                       dbgout);
+    if (dbg) {
+      OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma2<true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_gram_dma2<true>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(256), lds,
+                         cur_stream(), d_B, t.p_pad, nb, ntiles, tps, b.gram_pairs.p, part, dbgout);
+    } else {
+      OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma2<false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_gram_dma2<false>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(256), lds,
+                         cur_stream(), d_B, t.p_pad, nb, ntiles, tps, b.gram_pairs.p, part, nullptr);
+    }
     OB_HIP(hipGetLastError());
   }
   if (dbgout) {
@@ -408,7 +424,64 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
             "per 16-row chunk (8192 = matrix pipe saturated by two blocks)\n",
             h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0, h[2] ? (double)h[0] / h[2] : 0.0);
   }
-  return launch_gram_reduce(part, npairs, (int)nsplit, nb, (int)t.p, d_G);
+  return launch_gram_reduce(part, npairs, (int)nsplit, nb, (int)t.p, d_G, accumulate);
+}
+
+}  // namespace
+
+// d_B: n_pad x p_pad doubles, row-major (= column-major p_pad x n_pad); padding rows are 0
+int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B) {
+  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  ProfScope ps("materialize_B");
+  return materialize_any(b, t, d_B);
+}
+
+// b.bmat = row-major design matrix of (b, t); kept until the basis is rebuilt or other
+// terms need the buffer
+int ensure_bmat(obhip_basis &b, obhip_terms &t) {
+  if (b.bmat_terms == t.uid && t.uid != 0) return 0;
+  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  if (!gram_panel_supports(b, t))
+    return fail(OBHIP_ERR_INVALID, "not enough free HBM for the n x p design matrix");
+  const size_t need = (size_t)b.n_pad * t.p_pad;
+  if (b.bmat.n < need) OB_TRY(b.bmat.alloc(need));
+  b.bmat_terms = 0;
+  OB_TRY(launch_materialize_rows(b, t, b.bmat.p));
+  b.bmat_terms = t.uid;
+  return 0;
+}
+
+int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
+  obhip_basis &b = const_cast<obhip_basis &>(bc);
+  const uint64_t ntiles = b.n_pad / kTileRows;
+  if (gram_panel_supports(b, t)) {
+    OB_TRY(ensure_bmat(b, t));
+    return gram_of_staged(b, b.bmat.p, ntiles, t, d_G, false);
+  }
+  // Not enough memory for all rows at once: stage and contract row chunks one after the
+  // other, the later ones accumulating into G.  Chunk = a quarter of the free HBM (at most
+  // 16 GB, at least 64 tiles so that the launch still fills the GPU).
+  size_t free_b = 0, total_b = 0;
+  OB_HIP(hipMemGetInfo(&free_b, &total_b));
+  const size_t row_bytes = (size_t)t.p_pad * kTileRows * sizeof(double);
+  uint64_t ctiles = std::min<size_t>(free_b / 4, (size_t)16 << 30) / row_bytes;
+  if (const char *e = getenv("OBHIP_GRAM_CHUNK_ROWS")) ctiles = (uint64_t)atoll(e) / kTileRows;
+  ctiles = std::max<uint64_t>(ctiles, 1);
+  ctiles = std::min(ctiles, ntiles);
+  if ((size_t)ctiles * row_bytes > free_b)
+    return fail(OBHIP_ERR_HIP, "not enough free HBM for even one row chunk of the design matrix");
+  b.bmat_terms = 0;  // the buffer no longer holds the whole matrix of any terms
+  if (b.bmat.n < (size_t)ctiles * kTileRows * t.p_pad) OB_TRY(b.bmat.alloc((size_t)ctiles * kTileRows * t.p_pad));
+  for (uint64_t t0 = 0; t0 < ntiles; t0 += ctiles) {
+    const uint64_t nt = std::min(ctiles, ntiles - t0);
+    RowView view(b, t0, nt);
+    {
+      ProfScope ps("materialize_B");
+      OB_TRY(materialize_any(view.v, t, b.bmat.p));
+    }
+    OB_TRY(gram_of_staged(b, b.bmat.p, nt, t, d_G, t0 != 0));
+  }
+  return 0;
 }
 
 }  // namespace obhip

@@ -359,10 +359,21 @@ int launch_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, 
     t.pred_model = &m;
   }
   OB_TRY(t.prepare(t.pred_md.cap, t.pred_md.dims_h));
-  if (t.Mu > 296)
-    return fail(OBHIP_ERR_INVALID, "terms touch too many basis columns for the LDS tile");
   if (n == 0) return 0;
   ProfScope ps("predict");
+  if (t.Mu > 296 || getenv("OBHIP_FORCE_GENERIC")) {
+    // more used columns than the fused kernel's LDS tile holds: evaluate the basis at the new
+    // rows into HBM (levels the terms use only) and take the products from there
+    obhip_basis *bn = nullptr;
+    OB_TRY(obhip_basis_create_dev(&bn, &m, d_x, n, t.maxlev.data()));
+    int rc = launch_mm(*bn, t, d_theta, d_mean, false);
+    if (!rc && d_coeffvar != nullptr && d_var != nullptr) {
+      rc = launch_mm(*bn, t, d_coeffvar, d_var, true);
+      if (!rc) rc = launch_affine(d_var, n, -e2sigma, 1.0);
+    }
+    obhip_basis_destroy(bn);  // synchronises the stream first
+    return rc;
+  }
   static const bool lane_row = getenv("OBHIP_PREDICT_LANE_ROW") != nullptr;
   const int w2 = (int)(t.W / 2);
   if (!lane_row && w2 >= 1 && w2 <= 4 &&

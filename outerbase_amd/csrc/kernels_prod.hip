@@ -742,12 +742,9 @@ int set_lds(K kernel, size_t bytes) {
   return 0;
 }
 
-int check_mu(const obhip_terms &t) {
-  if (t.Mu > (uint64_t)kMaxMuLds)
-    return fail(OBHIP_ERR_INVALID, "terms touch " + std::to_string(t.Mu) +
-                                       " basis columns; at most " + std::to_string(kMaxMuLds) +
-                                       " fit the LDS tile");
-  return 0;
+// more used columns than one LDS tile holds: the generic kernels (kernels_generic.hip)
+bool beyond_lds(const obhip_terms &t) {
+  return t.Mu > (uint64_t)kMaxMuLds || getenv("OBHIP_FORCE_GENERIC") != nullptr;  // env: tests
 }
 
 template <int W2, int MODE>
@@ -805,8 +802,8 @@ int dispatch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double
 
 int launch_getmat(const obhip_basis &b, obhip_terms &t, double *d_out) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
-  OB_TRY(check_mu(t));
   ProfScope ps("getmat");
+  if (beyond_lds(t)) return launch_mm_generic(b, t, nullptr, d_out, 2);
   return dispatch_mm<2>(b, t, nullptr, d_out);
 }
 
@@ -861,7 +858,10 @@ int mm_tl_supports(const obhip_terms &t) {
 
 int launch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, bool squared) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
-  OB_TRY(check_mu(t));
+  if (beyond_lds(t)) {
+    ProfScope ps(squared ? "sqmm" : "mm");
+    return launch_mm_generic(b, t, d_a, d_out, squared ? 1 : 0);
+  }
   static const bool force_rows = getenv("OBHIP_MM_LANE_ROW") != nullptr;
   if (!mm_tl_supports(t) || force_rows) {
     ProfScope ps(squared ? "sqmm" : "mm");
@@ -990,7 +990,10 @@ int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B) {
 
 int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, bool squared) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
-  OB_TRY(check_mu(t));
+  if (beyond_lds(t)) {
+    ProfScope ps(squared ? "sqtmm" : "tmm");
+    return launch_tmm_generic(b, t, d_a, d_out, squared);
+  }
   const uint64_t ntiles = b.n_pad / kTileRows;
   const uint64_t p_pad = t.p_pad;  // multiple of 256 (obhip_terms::prepare)
   double *part = nullptr;

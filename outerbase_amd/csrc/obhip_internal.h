@@ -264,6 +264,11 @@ int launch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a,
               double *d_out, bool squared);
 int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a,
                double *d_out, bool squared);
+// kernels_generic.hip: any number of used columns / factors, columns read from HBM
+int launch_mm_generic(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, int mode);
+int launch_tmm_generic(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out,
+                       bool squared);
+int launch_materialize_generic(const obhip_basis &b, obhip_terms &t, double *d_B);
 // kernels_gram.hip
 int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G);
 void set_gram_backend(int b);

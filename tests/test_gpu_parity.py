@@ -5,6 +5,7 @@ through the device path in test_reference_identities.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -172,15 +173,15 @@ def test_ragged_sizes(n, p):
 
 @pytest.fixture
 def gram_backend(request):
-    """1 = 16x16x4 matrix-core kernel, 2 = vector-pipe kernel, 3 = fused 4x4x4
-    matrix-core kernel, 4 = materialised-B 4x4x4 matrix-core kernel, 0 = automatic."""
+    """3 = fused 4x4x4 matrix-core kernel, 4 = staged-design-matrix 4x4x4 matrix-core
+    kernel (0 = automatic = 4, in row chunks when memory is short)."""
     from outerbase_amd import _lib
     _lib.call("obhip_set_gram_backend", request.param)
     yield request.param
     _lib.call("obhip_set_gram_backend", 0)
 
 
-@pytest.mark.parametrize("gram_backend", [1, 2, 3, 4], indirect=True)
+@pytest.mark.parametrize("gram_backend", [3, 4], indirect=True)
 @pytest.mark.parametrize("n,p", [(2, 1), (65, 127), (200, 128), (1000, 129), (5000, 700)])
 def test_gram_backends(gram_backend, n, p):
     """both Gram kernels on single/multi tile pairs, ragged edges and multiple
@@ -202,7 +203,7 @@ def test_gram_backends(gram_backend, n, p):
     assert np.array_equal(G, G.T)
 
 
-@pytest.mark.parametrize("gram_backend", [1, 2, 3, 4], indirect=True)
+@pytest.mark.parametrize("gram_backend", [3, 4], indirect=True)
 @pytest.mark.parametrize("max_nnz", [1, 2, 3, 5, 6, 8])
 def test_gram_term_widths(gram_backend, max_nnz):
     """terms with 1..8 non-zero levels (MFMA kernel template widths W = 2, 4, 6,
@@ -228,8 +229,8 @@ def test_gram_term_widths(gram_backend, max_nnz):
 
 
 def test_gram_wide_terms():
-    """a term with 9 non-zero levels: the fused kernels (widths up to 8) refuse it
-    loudly; the materialised-B kernel (and with it the automatic choice) and the
+    """a term with 9 non-zero levels: the fused kernel (widths up to 8) refuses it
+    loudly; the staged-design-matrix kernel (and with it the automatic choice) and the
     matrix-free path take it."""
     import ob_oracle as O
     import outerbase_amd as ob
@@ -244,10 +245,12 @@ def test_gram_wide_terms():
     lik = ob.loglik_std(om_d, terms, rng.standard_normal(100), x)
     B = O.ob_getmat(O.OuterBase(om_o, x), terms)
     try:
-        for backend in (1, 2, 3):
-            _lib.call("obhip_set_gram_backend", backend)
+        _lib.call("obhip_set_gram_backend", 3)
+        with pytest.raises(ob.ObhipError):
+            lik.hess()
+        for backend in (1, 2, 5):            # the pruned generations are gone from the ABI
             with pytest.raises(ob.ObhipError):
-                lik.hess()
+                _lib.call("obhip_set_gram_backend", backend)
         for backend in (0, 4):
             _lib.call("obhip_set_gram_backend", backend)
             G = lik.hess() * math.exp(2 * lik.para[0])
@@ -892,13 +895,28 @@ def test_random_terms_caps_and_gram_backends(seed):
     lik = ob.loglik_std(om_d, terms, y, x)
     e2 = math.exp(-2 * lik.para[0])
     try:
-        for backend in (1, 2, 3, 4, 0):
+        for backend in (3, 4, 0):
             _lib.call("obhip_set_gram_backend", backend)
-            if backend in (1, 2, 3) and max_nnz > 8:
-                continue
             G = lik.hess() / e2
             assert relerr(G, B.T @ B) < tol, backend
             assert np.array_equal(G, G.T)
+        # the design matrix staged in row chunks of 128 (what happens when n x p doubles do
+        # not fit in memory), and the column-from-HBM kernels that take over beyond the LDS tile
+        for var in ("OBHIP_GRAM_CHUNK_ROWS", "OBHIP_FORCE_GENERIC"):
+            os.environ[var] = "128"
+            try:
+                lik2 = ob.loglik_std(om_d, terms, y, x)
+                G = lik2.hess() / e2
+                assert relerr(G, B.T @ B) < tol, var
+                assert np.array_equal(G, G.T)
+                if var == "OBHIP_FORCE_GENERIC":
+                    assert relerr(bd.matmul(terms, a), B @ a) < tol
+                    assert relerr(bd.tmatmul(terms, v), B.T @ v) < tol
+                    assert relerr(bd.getmat(terms), B) < tol
+                    assert relerr(bd.sqmm(terms, np.abs(a)), (B * B) @ np.abs(a)) < tol
+                    assert relerr(bd.sqtmm(terms, v), (B * B).T @ v) < tol
+            finally:
+                del os.environ[var]
     finally:
         _lib.call("obhip_set_gram_backend", 0)
     # pred_gauss variance with an arbitrary coefficient variance
