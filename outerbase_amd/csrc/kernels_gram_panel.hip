@@ -153,8 +153,8 @@ __device__ __forceinline__ void lds_rd_h1(const uint32_t (&baddr)[4], double (&b
 // chunk under load, OBHIP_GRAM_DBG=1); the production instantiation carries none of it
 template <bool DBG>
 __global__ void __launch_bounds__(256, 2)
-k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntiles,
-            uint64_t tiles_per_split, const uint32_t *__restrict__ pairs,
+k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, int npairs, uint64_t ntiles,
+            uint64_t tiles_per_split, const uint32_t *__restrict__ tasks,
             double *__restrict__ part, unsigned long long *dbgout) {
   extern __shared__ double T[];  // [2][16][272]
   constexpr int tszb = kCR * kTP * 8;  // bytes per buffer
@@ -167,13 +167,14 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntile
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // XCD-aware order: pairs[] deals compact squares of the (I, J) triangle to the blocks
-  // that share an XCD (and with it an L2), see build_pair_order
-  const uint32_t ij = pairs[blockIdx.x];
-  const int I = ij & 0xffff, J = ij >> 16;
+  // XCD-aware order: tasks[] hands every XCD (blocks x, x + 8, ... share one, and with it an
+  // L2) whole (square of tile pairs, row split) units, see build_task_order
+  const uint32_t task = tasks[blockIdx.x];
+  if (task == 0xffffffffu) return;  // padding of the shorter per-XCD sequences
+  const int I = task & 0xff, J = (task >> 8) & 0xff, ysplit = task >> 16;
   const int slot = I * nb - I * (I - 1) / 2 + (J - I);  // row-major index in the upper triangle
 
-  const uint64_t t0 = (uint64_t)blockIdx.y * tiles_per_split;
+  const uint64_t t0 = (uint64_t)ysplit * tiles_per_split;
   const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
   const int nchunks = (int)(t1 > t0 ? (t1 - t0) * (kTileRows / kCR) : 0);
 
@@ -184,9 +185,17 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntile
   const char *gA = (const char *)(B + (t0 * kTileRows + wave) * p_pad + (uint64_t)I * kGT);
   const char *gB = (const char *)(B + (t0 * kTileRows + wave) * p_pad + (uint64_t)J * kGT);
   const uint64_t pitch4 = 4 * p_pad * sizeof(double), pitch16 = 4 * pitch4;
+  // The 8 blocks of a unit that share a panel (same I or same J) walk the row chunks of the
+  // split with starts rotated by (I + J) mod 8 chunks: requests for one line that reach the L2
+  // together are NOT merged (each goes out to the fabric), so sharers in lockstep miss
+  // together; one chunk (~3.6 us) apart, the first brings the line in and seven hit.  The
+  // window of 8 chunks x 16 panels x 16 KB = 2 MB stays inside the 4-MB L2.
+  const int rot = nchunks > 0 ? ((I + J) & 7) % nchunks : 0;
   auto issue = [&](int ch, int buf) {
     const uint32_t l = lds0 + buf * tszb;
-    const char *a = gA + (uint64_t)ch * pitch16, *b = gB + (uint64_t)ch * pitch16;
+    int cr = ch + rot;
+    cr = cr >= nchunks ? cr - nchunks : cr;
+    const char *a = gA + (uint64_t)cr * pitch16, *b = gB + (uint64_t)cr * pitch16;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       lds_dma_1k(a + q * pitch4, voff, l + q * 4 * kTP * 8);
@@ -256,7 +265,7 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntile
 #undef OB_CHUNK_BODY2
 #undef OB_STEP
 
-  double *out = part + ((uint64_t)blockIdx.y * gridDim.x + slot) * (kGT * kGT);
+  double *out = part + ((uint64_t)ysplit * npairs + slot) * (kGT * kGT);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -268,7 +277,7 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntile
         out[row * kGT + col] = acc[i][j][r];
       }
   if constexpr (DBG) {
-    if (dbgout && blockIdx.x == 7 && blockIdx.y == gridDim.y / 2 && tid == 0) {
+    if (dbgout && blockIdx.x == gridDim.x / 2 + 7 && tid == 0) {
       dbgout[0] = __builtin_amdgcn_s_memtime() - st0;
       dbgout[1] = __builtin_amdgcn_s_memrealtime() - sr0;
       dbgout[2] = nchunks;
@@ -276,29 +285,47 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, uint64_t ntile
   }
 }
 
-// Workgroups go to the 8 XCDs round-robin by linear id, so blocks x, x + 8, x + 16, ... of
-// a row split share one 4-MB L2.  Give each XCD a contiguous run of the tile pairs sorted
-// square-major (8 x 8 squares of the (I, J) triangle): its ~66 resident blocks then touch
-// ~16-24 of the 32 column blocks instead of all of them, and panel rows fetched by one
-// block are L2 hits for the others.
-constexpr int kXcd = 8;
-void build_pair_order(int nb, std::vector<uint32_t> &tab) {
-  const int npairs = nb * (nb + 1) / 2;
-  const int group = (npairs + kXcd - 1) / kXcd;
-  int sq = 1;
-  while ((sq + 1) * (sq + 1) <= group) ++sq;
-  std::vector<uint32_t> sorted;
-  sorted.reserve(npairs);
-  for (int bi = 0; bi * sq < nb; ++bi)
-    for (int bj = bi; bj * sq < nb; ++bj)
-      for (int i = bi * sq; i < std::min(nb, (bi + 1) * sq); ++i)
-        for (int j = std::max(i, bj * sq); j < std::min(nb, (bj + 1) * sq); ++j)
-          sorted.push_back((uint32_t)i | ((uint32_t)j << 16));
-  tab.assign(npairs, 0);
-  // block x = kXcd * m + k runs on XCD k: hand it element m of XCD k's run
-  int next = 0;
+// Workgroups go to the 8 XCDs round-robin by linear id, so blocks x, x + 8, x + 16, ... share
+// one 4-MB L2, and an XCD keeps 64 of them resident (32 CUs x 2).  The work is cut into units
+// of (8 x 8 square of the tile-pair triangle, row split): the 64 blocks of a unit read 16
+// panel column blocks over the same rows, so a panel row fetched by one block is an L2 hit
+// for the others.  Every XCD gets whole units, one after the other (diagonal squares hold
+// 36 pairs; the next unit fills the slots they leave), and all XCDs the same number of blocks
+// (padding tasks exit at once).  At p = 4096: 10 squares x 32 splits = 320 units, 2112 blocks
+// per XCD = 33 rounds of 64.  (The first version dealt every XCD a 66-pair run of the sorted
+// pair list per split: runs straddle squares and touch 16-24 column blocks.)
+constexpr int kXcd = 8, kSq = 8;
+void build_task_order(int nb, int nsplit, std::vector<uint32_t> &tab) {
+  struct Unit {
+    int bi, bj, y, size;
+  };
+  std::vector<Unit> units;
+  const int nsq = (nb + kSq - 1) / kSq;
+  for (int y = 0; y < nsplit; ++y)
+    for (int bi = 0; bi < nsq; ++bi)
+      for (int bj = bi; bj < nsq; ++bj) {
+        int size = 0;
+        for (int i = bi * kSq; i < std::min(nb, (bi + 1) * kSq); ++i)
+          for (int j = std::max(i, bj * kSq); j < std::min(nb, (bj + 1) * kSq); ++j) ++size;
+        if (size) units.push_back({bi, bj, y, size});
+      }
+  // largest units first, each to the XCD with the fewest blocks so far (stable: the order
+  // of equal-sized units keeps squares of one split together)
+  std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.size > b.size; });
+  std::vector<std::vector<uint32_t>> seq(kXcd);
+  for (const Unit &u : units) {
+    int k = 0;
+    for (int q = 1; q < kXcd; ++q)
+      if (seq[q].size() < seq[k].size()) k = q;
+    for (int i = u.bi * kSq; i < std::min(nb, (u.bi + 1) * kSq); ++i)
+      for (int j = std::max(i, u.bj * kSq); j < std::min(nb, (u.bj + 1) * kSq); ++j)
+        seq[k].push_back((uint32_t)i | ((uint32_t)j << 8) | ((uint32_t)u.y << 16));
+  }
+  size_t len = 0;
+  for (auto &q : seq) len = std::max(len, q.size());
+  tab.assign(len * kXcd, 0xffffffffu);
   for (int k = 0; k < kXcd; ++k)
-    for (int x = k; x < npairs; x += kXcd) tab[x] = sorted[next++];
+    for (size_t m = 0; m < seq[k].size(); ++m) tab[m * kXcd + k] = seq[k][m];
 }
 
 template <int W2>
@@ -394,25 +421,28 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 64, (void **)&part));
   unsigned long long *dbgout =
       dbg ? (unsigned long long *)(part + (size_t)nsplit * npairs * kGT * kGT) : nullptr;
-  if (b.gram_pairs_nb != nb) {
+  if (nb > 255 || nsplit > 65535) return fail(OBHIP_ERR_INVALID, "Gram: p beyond 32640 terms");
+  if (b.gram_pairs_nb != nb || b.gram_pairs_ns != (int)nsplit) {
     std::vector<uint32_t> tab;
-    build_pair_order(nb, tab);
+    build_task_order(nb, (int)nsplit, tab);
     OB_TRY(b.gram_pairs.upload(tab.data(), tab.size()));
     b.gram_pairs_nb = nb;
+    b.gram_pairs_ns = (int)nsplit;
   }
+  const unsigned nblocks = (unsigned)b.gram_pairs.n;
   const size_t lds = (size_t)2 * kCR * kTP * sizeof(double);
   {
     ProfScope ps("gram");
     if (dbg) {
       OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma2<true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_gram_dma2<true>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(256), lds,
-                         cur_stream(), d_B, t.p_pad, nb, ntiles, tps, b.gram_pairs.p, part, dbgout);
+      hipLaunchKernelGGL(k_gram_dma2<true>, dim3(nblocks), dim3(256), lds, cur_stream(), d_B, t.p_pad,
+                         nb, npairs, ntiles, tps, b.gram_pairs.p, part, dbgout);
     } else {
       OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma2<false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_gram_dma2<false>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(256), lds,
-                         cur_stream(), d_B, t.p_pad, nb, ntiles, tps, b.gram_pairs.p, part, nullptr);
+      hipLaunchKernelGGL(k_gram_dma2<false>, dim3(nblocks), dim3(256), lds, cur_stream(), d_B, t.p_pad,
+                         nb, npairs, ntiles, tps, b.gram_pairs.p, part, nullptr);
     }
     OB_HIP(hipGetLastError());
   }

@@ -234,8 +234,8 @@ struct obhip_basis {
   obhip::DevBuf<double> bmat;   // row-major design matrix [n_pad][p_pad], staging of the
                                 // materialised-B Gram kernel (allocated on first use)
   uint64_t bmat_terms = 0;      // uid of the terms bmat currently holds (0: none)
-  obhip::DevBuf<uint32_t> gram_pairs;  // XCD-aware tile-pair order of that kernel
-  int gram_pairs_nb = -1;
+  obhip::DevBuf<uint32_t> gram_pairs;  // XCD-aware (tile pair, row split) task order of that kernel
+  int gram_pairs_nb = -1, gram_pairs_ns = -1;
   std::unique_ptr<obhip_gradbasis> grad;  // built on first *_gradhyp call, dropped on rebuild
   int device = 0;
   int workspace(size_t bytes, void **out) {
