@@ -515,8 +515,8 @@ def main():
         # rocprofv3 --pmc passes on this exact workload (profiles/); see the files for the
         # commands and the gfx950 corrections
         traffic = mfma_util = None
-        kernel = {0: "k_gram_dma2", 1: "k_gram", 3: "k_gram_mfma4", 4: "k_gram_dma2"}.get(
-            args.gram_backend, "k_gram_dma2")
+        kernel = {0: "k_atb_dma2", 3: "k_gram_mfma4", 4: "k_atb_dma2"}.get(
+            args.gram_backend, "k_atb_dma2")
         for fn in ("r02_gram_traffic.json", "r01_gram_traffic.json"):
             tf = os.path.join(ROOT, "profiles", fn)
             if os.path.exists(tf):

@@ -43,7 +43,7 @@ template <int MODE>
 __global__ void __launch_bounds__(kGW * 64)
 k_mm_generic(const double *__restrict__ bm, const double *__restrict__ scale, uint64_t Mc,
              const uint16_t *__restrict__ cols, const uint32_t *__restrict__ ucol, int W, int p,
-             const double *__restrict__ a, uint64_t n, double *__restrict__ out) {
+             const double *__restrict__ a, uint64_t n, uint64_t ld, double *__restrict__ out) {
   __shared__ double red[kGW][kTileRows];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -54,7 +54,7 @@ k_mm_generic(const double *__restrict__ bm, const double *__restrict__ scale, ui
   for (int k = wave; k < p; k += kGW) {
     const double v = term_prod_hbm<MODE == 1>(tb, lane, cols, ucol, W, k);
     if constexpr (MODE == 2) {
-      if (row < n) out[(uint64_t)k * n + row] = s * v;
+      if (row < n) out[(uint64_t)k * ld + row] = s * v;
     } else {
       acc = fma(a[k], v, acc);
     }
@@ -128,11 +128,13 @@ k_materialize_generic(const double *__restrict__ bm, const double *__restrict__ 
 }  // namespace
 
 // t must be prepared for b (obhip_terms::prepare)
-int launch_mm_generic(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, int mode) {
+int launch_mm_generic(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, int mode,
+                      uint64_t ld) {
+  if (ld == 0) ld = b.n;
   const dim3 grid((unsigned)(b.n_pad / kTileRows));
 #define OB_GMM(M_)                                                                                 \
   hipLaunchKernelGGL(k_mm_generic<M_>, grid, dim3(kGW * 64), 0, cur_stream(), b.bm.p, b.scale.p,    \
-                     b.md.Mc, t.cols.p, t.ucol.p, (int)t.W, (int)t.p, d_a, b.n, d_out)
+                     b.md.Mc, t.cols.p, t.ucol.p, (int)t.W, (int)t.p, d_a, b.n, ld, d_out)
   if (mode == 0) OB_GMM(0);
   else if (mode == 1) OB_GMM(1);
   else OB_GMM(2);

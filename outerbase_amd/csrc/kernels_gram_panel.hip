@@ -149,13 +149,28 @@ __device__ __forceinline__ void lds_rd_h1(const uint32_t (&baddr)[4], double (&b
   }
 }
 
-// DBG: one block reports its s_memtime / s_memrealtime span (clock and matrix-pipe cycles per
-// chunk under load, OBHIP_GRAM_DBG=1); the production instantiation carries none of it
-template <bool DBG>
+// One kernel body, three uses (MODE), all C = A^T Bm with the contraction index k the SLOW
+// index of both operands (rows of k, 128 contiguous output indices per 1-KB panel row):
+//   kAtbGram   A = Bm = the staged design matrix: tile pair (I <= J) of B^T B over the rows
+//              of one row split; the partial tile goes to out[(split, pair)]
+//   kAtbNorm   out[J][i] = sum over the 128 columns of tile J of C[i][c]^2 (C never stored):
+//              || L^-1 b_i ||^2 of predr_std with A = B^T (term-major), Bm = L^-T
+//   kAtbStore  C[I-tile rows][J-tile columns] stored row-major with leading dimension ldo
+// For the last two the k range of column tile J ends at (J + 1) * 128 when `tri` says Bm is
+// upper triangular.  DBG: one block reports its s_memtime / s_memrealtime span (clock and
+// matrix-pipe cycles per chunk under load, OBHIP_GRAM_DBG=1); production carries none of it.
+constexpr int kAtbGram = 0, kAtbNorm = 1, kAtbStore = 2;
+__host__ __device__ inline uint64_t atb_task(uint64_t I, uint64_t J, uint64_t y) {
+  return I | (J << 24) | (y << 48);
+}
+constexpr uint64_t kAtbNoTask = ~0ull;
+
+template <int MODE, bool DBG>
 __global__ void __launch_bounds__(256, 2)
-k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, int npairs, uint64_t ntiles,
-            uint64_t tiles_per_split, const uint32_t *__restrict__ tasks,
-            double *__restrict__ part, unsigned long long *dbgout) {
+k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict__ Bm, uint64_t ldB,
+           int nb, int npairs, uint64_t ntiles, uint64_t tiles_per_split, int tri,
+           const uint64_t *__restrict__ tasks, double *__restrict__ part, uint64_t ldo,
+           unsigned long long *dbgout) {
   extern __shared__ double T[];  // [2][16][272]
   constexpr int tszb = kCR * kTP * 8;  // bytes per buffer
   unsigned long long st0 = 0, sr0 = 0;
@@ -169,22 +184,28 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, int npairs, ui
 
   // XCD-aware order: tasks[] hands every XCD (blocks x, x + 8, ... share one, and with it an
   // L2) whole (square of tile pairs, row split) units, see build_task_order
-  const uint32_t task = tasks[blockIdx.x];
-  if (task == 0xffffffffu) return;  // padding of the shorter per-XCD sequences
-  const int I = task & 0xff, J = (task >> 8) & 0xff, ysplit = task >> 16;
-  const int slot = I * nb - I * (I - 1) / 2 + (J - I);  // row-major index in the upper triangle
+  const uint64_t task = tasks[blockIdx.x];
+  if (task == kAtbNoTask) return;  // padding of the shorter per-XCD sequences
+  const int I = (int)(task & 0xffffff), J = (int)((task >> 24) & 0xffffff), ysplit = (int)(task >> 48);
 
-  const uint64_t t0 = (uint64_t)ysplit * tiles_per_split;
-  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+  uint64_t t0, t1;  // range of 64-row tiles of k
+  if constexpr (MODE == kAtbGram) {
+    t0 = (uint64_t)ysplit * tiles_per_split;
+    t1 = min(ntiles, t0 + tiles_per_split);
+  } else {
+    t0 = 0;
+    t1 = tri ? min(ntiles, (uint64_t)(J + 1) * (kGT / kTileRows)) : ntiles;
+  }
   const int nchunks = (int)(t1 > t0 ? (t1 - t0) * (kTileRows / kCR) : 0);
 
   // wave w moves rows w, w + 4, w + 8, w + 12 of both panels of a chunk
   const uint32_t ldsT = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)T;
   const uint32_t lds0 = ldsT + wave * kTP * 8;
   const uint32_t voff = lane * 16;
-  const char *gA = (const char *)(B + (t0 * kTileRows + wave) * p_pad + (uint64_t)I * kGT);
-  const char *gB = (const char *)(B + (t0 * kTileRows + wave) * p_pad + (uint64_t)J * kGT);
-  const uint64_t pitch4 = 4 * p_pad * sizeof(double), pitch16 = 4 * pitch4;
+  const char *gA = (const char *)(A + (t0 * kTileRows + wave) * ldA + (uint64_t)I * kGT);
+  const char *gB = (const char *)(Bm + (t0 * kTileRows + wave) * ldB + (uint64_t)J * kGT);
+  const uint64_t pitch4 = 4 * ldA * sizeof(double), pitch16 = 4 * pitch4;
+  const uint64_t pitch4b = MODE == kAtbGram ? pitch4 : 4 * ldB * sizeof(double), pitch16b = 4 * pitch4b;
   // The 8 blocks of a unit that share a panel (same I or same J) walk the row chunks of the
   // split with starts rotated by (I + J) mod 8 chunks: requests for one line that reach the L2
   // together are NOT merged (each goes out to the fabric), so sharers in lockstep miss
@@ -195,11 +216,11 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, int npairs, ui
     const uint32_t l = lds0 + buf * tszb;
     int cr = ch + rot;
     cr = cr >= nchunks ? cr - nchunks : cr;
-    const char *a = gA + (uint64_t)cr * pitch16, *b = gB + (uint64_t)cr * pitch16;
+    const char *a = gA + (uint64_t)cr * pitch16, *b = gB + (uint64_t)cr * pitch16b;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       lds_dma_1k(a + q * pitch4, voff, l + q * 4 * kTP * 8);
-      lds_dma_1k(b + q * pitch4, voff, l + q * 4 * kTP * 8 + kGT * 8);
+      lds_dma_1k(b + q * pitch4b, voff, l + q * 4 * kTP * 8 + kGT * 8);
     }
   };
 
@@ -265,17 +286,51 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, int npairs, ui
 #undef OB_CHUNK_BODY2
 #undef OB_STEP
 
-  double *out = part + ((uint64_t)ysplit * npairs + slot) * (kGT * kGT);
+  if constexpr (MODE == kAtbGram) {
+    const int slot = I * nb - I * (I - 1) / 2 + (J - I);  // row-major index in the upper triangle
+    double *out = part + ((uint64_t)ysplit * npairs + slot) * (kGT * kGT);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wm * 64 + i * 16 + mblk * 4 + mk;
-        const int col = wn * 64 + j * 16 + ((mblk + r) & 3) * 4 + me;
-        out[row * kGT + col] = acc[i][j][r];
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * 64 + i * 16 + mblk * 4 + mk;
+          const int col = wn * 64 + j * 16 + ((mblk + r) & 3) * 4 + me;
+          out[row * kGT + col] = acc[i][j][r];
+        }
+  } else if constexpr (MODE == kAtbStore) {
+    double *out = part + ((uint64_t)I * kGT) * ldo + (uint64_t)J * kGT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * 64 + i * 16 + mblk * 4 + mk;
+          const int col = wn * 64 + j * 16 + ((mblk + r) & 3) * 4 + me;
+          out[(uint64_t)row * ldo + col] = acc[i][j][r];
+        }
+  } else {
+    // per output row the sum of squares over this wave's 64 columns: 16 values per lane and
+    // row group i, then the 4 lanes (me) that hold the other columns of the row; the two
+    // waves (wn) that share the rows meet in LDS (the panel buffers are free: every wave is
+    // past the loop's last barrier)
+    double *red = T;  // [2][128]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s = fma(acc[i][j][r], acc[i][j][r], s);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      if (me == 0) red[wn * kGT + wm * 64 + i * 16 + mblk * 4 + mk] = s;
+    }
+    __syncthreads();
+    if (tid < kGT) part[(uint64_t)J * ldo + (uint64_t)I * kGT + tid] = red[tid] + red[kGT + tid];
+  }
   if constexpr (DBG) {
     if (dbgout && blockIdx.x == gridDim.x / 2 + 7 && tid == 0) {
       dbgout[0] = __builtin_amdgcn_s_memtime() - st0;
@@ -295,7 +350,7 @@ k_gram_dma2(const double *__restrict__ B, uint64_t p_pad, int nb, int npairs, ui
 // per XCD = 33 rounds of 64.  (The first version dealt every XCD a 66-pair run of the sorted
 // pair list per split: runs straddle squares and touch 16-24 column blocks.)
 constexpr int kXcd = 8, kSq = 8;
-void build_task_order(int nb, int nsplit, std::vector<uint32_t> &tab) {
+void build_task_order(int nb, int nsplit, std::vector<uint64_t> &tab) {
   struct Unit {
     int bi, bj, y, size;
   };
@@ -312,18 +367,18 @@ void build_task_order(int nb, int nsplit, std::vector<uint32_t> &tab) {
   // largest units first, each to the XCD with the fewest blocks so far (stable: the order
   // of equal-sized units keeps squares of one split together)
   std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.size > b.size; });
-  std::vector<std::vector<uint32_t>> seq(kXcd);
+  std::vector<std::vector<uint64_t>> seq(kXcd);
   for (const Unit &u : units) {
     int k = 0;
     for (int q = 1; q < kXcd; ++q)
       if (seq[q].size() < seq[k].size()) k = q;
     for (int i = u.bi * kSq; i < std::min(nb, (u.bi + 1) * kSq); ++i)
       for (int j = std::max(i, u.bj * kSq); j < std::min(nb, (u.bj + 1) * kSq); ++j)
-        seq[k].push_back((uint32_t)i | ((uint32_t)j << 8) | ((uint32_t)u.y << 16));
+        seq[k].push_back(atb_task(i, j, u.y));
   }
   size_t len = 0;
   for (auto &q : seq) len = std::max(len, q.size());
-  tab.assign(len * kXcd, 0xffffffffu);
+  tab.assign(len * kXcd, kAtbNoTask);
   for (int k = 0; k < kXcd; ++k)
     for (size_t m = 0; m < seq[k].size(); ++m) tab[m * kXcd + k] = seq[k][m];
 }
@@ -421,9 +476,8 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 64, (void **)&part));
   unsigned long long *dbgout =
       dbg ? (unsigned long long *)(part + (size_t)nsplit * npairs * kGT * kGT) : nullptr;
-  if (nb > 255 || nsplit > 65535) return fail(OBHIP_ERR_INVALID, "Gram: p beyond 32640 terms");
   if (b.gram_pairs_nb != nb || b.gram_pairs_ns != (int)nsplit) {
-    std::vector<uint32_t> tab;
+    std::vector<uint64_t> tab;
     build_task_order(nb, (int)nsplit, tab);
     OB_TRY(b.gram_pairs.upload(tab.data(), tab.size()));
     b.gram_pairs_nb = nb;
@@ -434,15 +488,17 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   {
     ProfScope ps("gram");
     if (dbg) {
-      OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma2<true>,
+      OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbGram, true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_gram_dma2<true>, dim3(nblocks), dim3(256), lds, cur_stream(), d_B, t.p_pad,
-                         nb, npairs, ntiles, tps, b.gram_pairs.p, part, dbgout);
+      hipLaunchKernelGGL((k_atb_dma2<kAtbGram, true>), dim3(nblocks), dim3(256), lds, cur_stream(), d_B,
+                         t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, tps, 0, b.gram_pairs.p, part,
+                         (uint64_t)0, dbgout);
     } else {
-      OB_HIP(hipFuncSetAttribute((const void *)k_gram_dma2<false>,
+      OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbGram, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_gram_dma2<false>, dim3(nblocks), dim3(256), lds, cur_stream(), d_B, t.p_pad,
-                         nb, npairs, ntiles, tps, b.gram_pairs.p, part, nullptr);
+      hipLaunchKernelGGL((k_atb_dma2<kAtbGram, false>), dim3(nblocks), dim3(256), lds, cur_stream(),
+                         d_B, t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, tps, 0, b.gram_pairs.p, part,
+                         (uint64_t)0, nullptr);
     }
     OB_HIP(hipGetLastError());
   }
@@ -511,6 +567,58 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
     }
     OB_TRY(gram_of_staged(b, b.bmat.p, nt, t, d_G, t0 != 0));
   }
+  return 0;
+}
+
+// C = A^T Bm on the matrix cores for two different operands, k the slow index of both:
+// A is K x M (leading dimension ldA), Bm is K x N (ldB); K a multiple of 64 and M, N multiples
+// of 128 (callers pad with zeros).  tri: Bm[k][c] = 0 for k > c (column tile J needs
+// k < (J + 1) * 128 only).  mode kAtbNorm: out[J * ldo + i] = sum_{c in tile J} C[i][c]^2;
+// mode kAtbStore: out[i * ldo + c] = C[i][c].  Tasks go to the XCDs in 8 x 8 squares of
+// (row tile, column tile) like the Gram's.
+int launch_atb(int mode, const double *A, uint64_t ldA, uint64_t M, const double *Bm, uint64_t ldB,
+               uint64_t N, uint64_t K, bool tri, double *out, uint64_t ldo) {
+  if (M % kGT || N % kGT || K % kTileRows)
+    return fail(OBHIP_ERR_INVALID, "launch_atb: sizes must be padded to the tile");
+  const uint64_t mt = M / kGT, nt = N / kGT;
+  if (mt >= (1ull << 24) || nt >= (1ull << 24)) return fail(OBHIP_ERR_INVALID, "launch_atb: too many tiles");
+  // units of up to 8 x 8 tiles, column-tile squares of equal k range together, dealt to the
+  // XCD with the fewest blocks so far
+  std::vector<std::vector<uint64_t>> seq(kXcd);
+  for (uint64_t bj = 0; bj * kSq < nt; ++bj)
+    for (uint64_t bi = 0; bi * kSq < mt; ++bi) {
+      int k = 0;
+      for (int q = 1; q < kXcd; ++q)
+        if (seq[q].size() < seq[k].size()) k = q;
+      for (uint64_t i = bi * kSq; i < std::min(mt, (bi + 1) * kSq); ++i)
+        for (uint64_t j = bj * kSq; j < std::min(nt, (bj + 1) * kSq); ++j) seq[k].push_back(atb_task(i, j, 0));
+    }
+  size_t len = 0;
+  for (auto &q : seq) len = std::max(len, q.size());
+  std::vector<uint64_t> tab(len * kXcd, kAtbNoTask);
+  for (int k = 0; k < kXcd; ++k)
+    for (size_t m = 0; m < seq[k].size(); ++m) tab[m * kXcd + k] = seq[k][m];
+  DevBuf<uint64_t> dtab;
+  OB_TRY(dtab.upload(tab.data(), tab.size()));
+  const size_t lds = (size_t)2 * kCR * kTP * sizeof(double);
+  const uint64_t ktiles = K / kTileRows;
+  if (mode == kAtbNorm) {
+    OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbNorm, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_atb_dma2<kAtbNorm, false>), dim3((unsigned)tab.size()), dim3(256), lds,
+                       cur_stream(), A, ldA, Bm, ldB, 0, 0, ktiles, ktiles, tri ? 1 : 0, dtab.p, out,
+                       ldo, nullptr);
+  } else if (mode == kAtbStore) {
+    OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbStore, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_atb_dma2<kAtbStore, false>), dim3((unsigned)tab.size()), dim3(256), lds,
+                       cur_stream(), A, ldA, Bm, ldB, 0, 0, ktiles, ktiles, tri ? 1 : 0, dtab.p, out,
+                       ldo, nullptr);
+  } else {
+    return fail(OBHIP_ERR_INVALID, "launch_atb: unknown mode");
+  }
+  OB_HIP(hipGetLastError());
+  OB_HIP(hipStreamSynchronize(cur_stream()));  // dtab is a local
   return 0;
 }
 

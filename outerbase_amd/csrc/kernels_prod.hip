@@ -87,7 +87,8 @@ template <int W2, int MODE>
 __global__ void __launch_bounds__(kMmThreads)
 k_mm(const double *__restrict__ bm, const double *__restrict__ scale,
      const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc, const uint32_t *__restrict__ colsw,
-     int W2rt, int p, const double *__restrict__ a, double *__restrict__ out, uint64_t n) {
+     int W2rt, int p, const double *__restrict__ a, double *__restrict__ out, uint64_t n,
+     uint64_t ld /* MODE 2: leading dimension of the column-major result */) {
   extern __shared__ double lds[];
   double *red = lds + (size_t)Mu * kTileRows;  // [kMmWaves][64]
   const int lane = threadIdx.x & 63;
@@ -124,7 +125,7 @@ k_mm(const double *__restrict__ bm, const double *__restrict__ scale,
         for (int t = 0; t < 64; ++t) {
           if (MODE == 2) {
             const double v = term_prod_rl<W2>(lds, cw, t, lane, s);
-            if (row < n) out[(uint64_t)(k0 + t) * n + row] = v;
+            if (row < n) out[(uint64_t)(k0 + t) * ld + row] = v;
           } else {
             acc += term_prod_rl<W2>(lds, cw, t, lane, readlane_f64(av, t));
           }
@@ -133,7 +134,7 @@ k_mm(const double *__restrict__ bm, const double *__restrict__ scale,
         for (int t = 0; t < cnt; ++t) {
           if (MODE == 2) {
             const double v = term_prod_rl<W2>(lds, cw, t, lane, s);
-            if (row < n) out[(uint64_t)(k0 + t) * n + row] = v;
+            if (row < n) out[(uint64_t)(k0 + t) * ld + row] = v;
           } else {
             acc += term_prod_rl<W2>(lds, cw, t, lane, readlane_f64(av, t));
           }
@@ -147,7 +148,7 @@ k_mm(const double *__restrict__ bm, const double *__restrict__ scale,
     for (int k = wave; k < p; k += kMmWaves) {
       if (MODE == 2) {
         const double v = term_prod_mem(lds, colsw + (size_t)k * W2rt, W2rt, lane, s);
-        if (row < n) out[(uint64_t)k * n + row] = v;
+        if (row < n) out[(uint64_t)k * ld + row] = v;
       } else {
         acc += term_prod_mem(lds, colsw + (size_t)k * W2rt, W2rt, lane, a[k]);
       }
@@ -748,24 +749,25 @@ bool beyond_lds(const obhip_terms &t) {
 }
 
 template <int W2, int MODE>
-int run_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out) {
+int run_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, uint64_t ld) {
   const size_t lds = (t.Mu * kTileRows + kMmWaves * kTileRows) * sizeof(double);
   OB_TRY(set_lds(k_mm<W2, MODE>, lds));
   hipLaunchKernelGGL((k_mm<W2, MODE>), dim3((unsigned)(b.n_pad / kTileRows)), dim3(kMmThreads), lds,
                      cur_stream(), b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc,
-                     (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p, d_a, d_out, b.n);
+                     (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p, d_a, d_out, b.n, ld);
   OB_HIP(hipGetLastError());
   return 0;
 }
 
 template <int MODE>
-int dispatch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out) {
+int dispatch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out,
+                uint64_t ld = 0) {
   switch (t.W / 2) {
-    case 1: return run_mm<1, MODE>(b, t, d_a, d_out);
-    case 2: return run_mm<2, MODE>(b, t, d_a, d_out);
-    case 3: return run_mm<3, MODE>(b, t, d_a, d_out);
-    case 4: return run_mm<4, MODE>(b, t, d_a, d_out);
-    default: return run_mm<0, MODE>(b, t, d_a, d_out);
+    case 1: return run_mm<1, MODE>(b, t, d_a, d_out, ld);
+    case 2: return run_mm<2, MODE>(b, t, d_a, d_out, ld);
+    case 3: return run_mm<3, MODE>(b, t, d_a, d_out, ld);
+    case 4: return run_mm<4, MODE>(b, t, d_a, d_out, ld);
+    default: return run_mm<0, MODE>(b, t, d_a, d_out, ld);
   }
 }
 
@@ -800,11 +802,13 @@ int dispatch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double
 
 }  // namespace
 
-int launch_getmat(const obhip_basis &b, obhip_terms &t, double *d_out) {
+// d_out: column-major n x p with leading dimension ld (0: n)
+int launch_getmat(const obhip_basis &b, obhip_terms &t, double *d_out, uint64_t ld) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  if (ld == 0) ld = b.n;
   ProfScope ps("getmat");
-  if (beyond_lds(t)) return launch_mm_generic(b, t, nullptr, d_out, 2);
-  return dispatch_mm<2>(b, t, nullptr, d_out);
+  if (beyond_lds(t)) return launch_mm_generic(b, t, nullptr, d_out, 2, ld);
+  return dispatch_mm<2>(b, t, nullptr, d_out, ld);
 }
 
 int device_cus(int device) {
@@ -860,7 +864,7 @@ int launch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   if (beyond_lds(t)) {
     ProfScope ps(squared ? "sqmm" : "mm");
-    return launch_mm_generic(b, t, d_a, d_out, squared ? 1 : 0);
+    return launch_mm_generic(b, t, d_a, d_out, squared ? 1 : 0, 0);
   }
   static const bool force_rows = getenv("OBHIP_MM_LANE_ROW") != nullptr;
   if (!mm_tl_supports(t) || force_rows) {

@@ -945,7 +945,7 @@ struct obhip_predictor {
   obhip_terms *t = nullptr;  // owned
   std::vector<double> coeff, para, cv;  // cv: what multiplies B^2 (see create)
   bool doda = false, full = false;
-  std::vector<double> H;  // tothess (host, p x p) for predr_std with the full Hessian
+  PostFactor post;  // predr_std with the full Hessian: Cholesky factor of tothess and L^-T
   std::vector<uint64_t> terms;
   DevBuf<double> x, dmean, dvar;
   uint64_t n = 0;
@@ -958,12 +958,12 @@ struct obhip_predictor {
     OB_TRY(dmean.alloc(n));
     OB_TRY(dvar.alloc(n));
     if (kind == OBHIP_LPDF_LOGLIK_STD && full) {
-      std::vector<double> xm(n * om->d), mean(n), var(n);
-      OB_TRY(d2h(xm.data(), x.p, xm.size() * sizeof(double)));
-      OB_TRY(obhip_predict_std(om, t, coeff.data(), H.data(), xm.data(), n, n, mean.data(), para[0],
-                               var.data()));
-      OB_TRY(dmean.upload(mean.data(), n));
-      OB_TRY(dvar.upload(var.data(), n));
+      // predr_std::var with coeffcov = inv(tothess), loglik_std.cpp:249-256
+      DevBuf<double> dth;
+      OB_TRY(dth.upload(coeff.data(), p));
+      OB_TRY(obhip_predict_dev(om, t, dth.p, x.p, n, dmean.p, nullptr, para[0], nullptr));
+      OB_TRY(post_var_dev(*om, *t, post, x.p, n, std::exp(2.0 * para[0]), dvar.p));
+      OB_HIP(hipStreamSynchronize(cur_stream()));
     } else {
       DevBuf<double> dth, dcv;
       OB_TRY(dth.upload(coeff.data(), p));
@@ -1258,9 +1258,8 @@ int obhip_predictor_create(obhip_predictor **out, const obhip_lpdf *lc) {
   if (!rc && !lik->didnotothess) {
     if (lik->kind == OBHIP_LPDF_LOGLIK_STD) {
       if (lik->didfulltothess) {
-        pr->full = true;
-        pr->H.resize(p * p);
-        rc = d2h(pr->H.data(), lik->tothess.p, p * p * sizeof(double));
+        pr->full = true;  // coeffcov = inv(tothess), loglik_std.cpp:227: factor and invert once
+        rc = post_factor_build(lik->tothess.p, p, pr->post, true);
       } else {
         // predr_std without the full Hessian puts totdiaghess ITSELF on the diagonal of
         // coeffcov (loglik_std.cpp:228-232) -- kept as the reference has it

@@ -234,7 +234,7 @@ struct obhip_basis {
   obhip::DevBuf<double> bmat;   // row-major design matrix [n_pad][p_pad], staging of the
                                 // materialised-B Gram kernel (allocated on first use)
   uint64_t bmat_terms = 0;      // uid of the terms bmat currently holds (0: none)
-  obhip::DevBuf<uint32_t> gram_pairs;  // XCD-aware (tile pair, row split) task order of that kernel
+  obhip::DevBuf<uint64_t> gram_pairs;  // XCD-aware (tile pair, row split) task order of that kernel
   int gram_pairs_nb = -1, gram_pairs_ns = -1;
   std::unique_ptr<obhip_gradbasis> grad;  // built on first *_gradhyp call, dropped on rebuild
   int device = 0;
@@ -259,13 +259,14 @@ constexpr int kTileRows = 64;
 int launch_build_basis(obhip_basis &b);
 int launch_getbase(const obhip_basis &b, uint64_t k, double *d_out /* n x m */);
 // kernels_prod.hip
-int launch_getmat(const obhip_basis &b, obhip_terms &t, double *d_out);
+int launch_getmat(const obhip_basis &b, obhip_terms &t, double *d_out, uint64_t ld = 0);
 int launch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a,
               double *d_out, bool squared);
 int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a,
                double *d_out, bool squared);
 // kernels_generic.hip: any number of used columns / factors, columns read from HBM
-int launch_mm_generic(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, int mode);
+int launch_mm_generic(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, int mode,
+                      uint64_t ld);
 int launch_tmm_generic(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out,
                        bool squared);
 int launch_materialize_generic(const obhip_basis &b, obhip_terms &t, double *d_B);
@@ -277,6 +278,23 @@ int get_gram_backend();
 int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B);
 int ensure_bmat(obhip_basis &b, obhip_terms &t);  // b.bmat = design matrix of (b, t)
 bool gram_panel_supports(const obhip_basis &b, const obhip_terms &t);
+// C = A^T Bm on the matrix cores (kernels_gram_panel.hip): mode 1 = row norms of C into
+// out[J * ldo + i] per 128-column tile J, mode 2 = C stored row-major with ldo
+int launch_atb(int mode, const double *A, uint64_t ldA, uint64_t M, const double *Bm, uint64_t ldB,
+               uint64_t N, uint64_t K, bool tri, double *out, uint64_t ldo);
+// kernels_trtri.hip: X (pp x pp, zeroed) = L^-T in its upper triangle; transpose of an n x n block
+int launch_trtri_lt(const double *d_L, uint64_t ldl, uint64_t p, double *d_X, uint64_t pp,
+                    double *d_dinv);
+int launch_transpose(const double *d_in, uint64_t ldi, double *d_out, uint64_t ldo, uint64_t n);
+// posterior.cpp: Cholesky factor of the total Hessian and X = L^-T for predr_std
+struct PostFactor {
+  uint64_t p = 0, pp = 0;  // pp = p rounded up to 128
+  DevBuf<double> L;        // p x p row-major, lower triangle = L
+  DevBuf<double> X;        // pp x pp row-major, upper triangle = L^-T, zero elsewhere
+};
+int post_factor_build(const double *d_H, uint64_t p, PostFactor &f, bool want_inverse);
+int post_var_dev(const obhip_model &m, obhip_terms &t, const PostFactor &f, const double *d_x,
+                 uint64_t n, double e2sigma, double *d_var);
 // kernels_grad.hip
 int ensure_gradbasis(obhip_basis &b);
 int ensure_gradbasis_sq(obhip_basis &b);

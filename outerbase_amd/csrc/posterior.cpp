@@ -1,89 +1,102 @@
 // Posterior-covariance quantities of the loglik_std model (SURVEY.md 8f-2 and the
-// full-Hessian part of 8f-4), both built on H = L L^T from the library's own Cholesky
-// (kernels_chol.hip) and on the row-major design matrix, which is exactly the column-major
-// p x n matrix B^T:
+// full-Hessian part of 8f-4), all on this library's own kernels: H = L L^T by the Cholesky of
+// kernels_chol.hip, X = L^-T by kernels_trtri.hip, and every p^2 n product as one pass of the
+// FP64 matrix-core kernel of kernels_gram_panel.hip in its two-operand form (C = A^T Bm with
+// both operands stored with the contraction index slow).
 //
 //   obhip_predict_std   predr_std (src/lpdfs/loglik_std.cpp:218-256): mean = B theta,
-//                       var_i = b_i^T inv(H) b_i + e^{2 sigma} = || L^{-1} b_i ||^2 + e^{2 sigma}
-//                       (the reference forms inv(tothess), :227, and rowsum((B C) % B), :251-255)
+//                       var_i = b_i^T inv(H) b_i + e^{2 sigma} = || L^-1 b_i ||^2 + e^{2 sigma}.
+//                       The reference forms inv(tothess) (arma::inv, :227) and
+//                       rowsum((B inv(H)) % B) (:251-255); here Z = B L^-T is never stored:
+//                       the kernel's epilogue squares and row-sums its 128 x 128 tiles.
 //   obhip_margadj_full  lpdfvec::buildhess with the full Hessian (src/fit.cpp:270-299):
 //                       -1/2 log det H and -1/2 tr(inv(H) dH) for every hyper-parameter and
-//                       parameter, from Y = inv(H) B^T and streaming dot products instead of
-//                       the reference's p x p x nhyp cubes
-//
-// The triangular solves with n right-hand sides are plain library calls (rocBLAS dtrsm,
-// p^2 n flop each); rocBLAS is loaded at run time so that the hot path neither links nor
-// needs it.  Every other step (basis, design matrices, Cholesky, norms, dot products) is
-// this library's own HIP code.
-#include <dlfcn.h>
-
+//                       parameter, from Y = inv(H) B^T (inv(H) = L^-T L^-1 formed once) and
+//                       streaming dot products instead of the reference's p x p x nhyp cubes.
 #include <cmath>
 #include <cstring>
 
 #include "obhip_internal.h"
+#include "vec_ops.h"
 
 using namespace obhip;
 
-namespace {
+namespace obhip {
+int launch_dot_cols(const double *d_A, const double *d_B, uint64_t ld, uint64_t p, uint64_t n,
+                    double *d_out, double *d_part);
 
-// the few rocBLAS entry points, by their documented C signatures (rocblas.h)
-typedef void *rb_handle;
-typedef int (*rb_create_t)(rb_handle *);
-typedef int (*rb_destroy_t)(rb_handle);
-typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
-typedef int (*rb_dtrsm64_t)(rb_handle, int side, int uplo, int trans, int diag, int64_t m, int64_t n,
-                            const double *alpha, const double *A, int64_t lda, double *B,
-                            int64_t ldb);
-// enum values of rocblas-types.h
-constexpr int kSideLeft = 141, kFillUpper = 121, kOpNone = 111, kOpTranspose = 112, kDiagNonUnit = 131;
+static uint64_t pad128(uint64_t v) { return (v + 127) / 128 * 128; }
 
-struct RocBlas {
-  void *lib = nullptr;
-  rb_create_t create = nullptr;
-  rb_destroy_t destroy = nullptr;
-  rb_set_stream_t set_stream = nullptr;
-  rb_dtrsm64_t dtrsm = nullptr;
-  rb_handle h = nullptr;
-};
-
-int rocblas(RocBlas **out) {
-  static RocBlas rb;
-  if (!rb.lib) {
-    // a copy already in the process (e.g. the one PyTorch ships) wins
-    const char *names[] = {"librocblas.so.5", "librocblas.so.4", "librocblas.so"};
-    for (const char *nm : names)
-      if ((rb.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;
-    if (!rb.lib)
-      for (const char *nm : names)
-        if ((rb.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
-    if (!rb.lib)
-      return fail(OBHIP_ERR_STATE, "predict_std needs rocBLAS (librocblas.so) for its triangular solve");
-    rb.create = (rb_create_t)dlsym(rb.lib, "rocblas_create_handle");
-    rb.destroy = (rb_destroy_t)dlsym(rb.lib, "rocblas_destroy_handle");
-    rb.set_stream = (rb_set_stream_t)dlsym(rb.lib, "rocblas_set_stream");
-    rb.dtrsm = (rb_dtrsm64_t)dlsym(rb.lib, "rocblas_dtrsm_64");
-    if (!rb.create || !rb.set_stream || !rb.dtrsm) {
-      rb.lib = nullptr;
-      return fail(OBHIP_ERR_STATE, "rocBLAS lacks rocblas_dtrsm_64");
-    }
-    if (rb.create(&rb.h) != 0) {
-      rb.lib = nullptr;
-      return fail(OBHIP_ERR_HIP, "rocblas_create_handle failed");
-    }
-  }
-  *out = &rb;
+// f.L = Cholesky factor of H (lower triangle, row-major p x p), f.X = L^-T (pp x pp)
+int post_factor_build(const double *d_H, uint64_t p, PostFactor &f, bool want_inverse) {
+  f.p = p;
+  f.pp = pad128(p);
+  OB_TRY(f.L.alloc(p * p));
+  OB_HIP(hipMemcpyAsync(f.L.p, d_H, p * p * sizeof(double), hipMemcpyDeviceToDevice, cur_stream()));
+  DevBuf<double> rhs, th;
+  DevBuf<char> ws;
+  OB_TRY(rhs.alloc(p));
+  OB_TRY(th.alloc(p));
+  OB_HIP(hipMemsetAsync(rhs.p, 0, p * sizeof(double), cur_stream()));
+  const uint64_t wsb = newton_workspace_bytes(p);
+  OB_TRY(ws.alloc(wsb));
+  OB_TRY(launch_newton_solve(p, f.L.p, rhs.p, th.p, ws.p, wsb));  // synchronises
+  if (!want_inverse) return 0;
+  DevBuf<double> dinv;
+  OB_TRY(dinv.alloc((p + 63) / 64 * 4096));
+  OB_TRY(f.X.alloc(f.pp * f.pp));
+  OB_TRY(launch_trtri_lt(f.L.p, p, p, f.X.p, f.pp, dinv.p));
+  OB_HIP(hipStreamSynchronize(cur_stream()));  // dinv is a local
   return 0;
 }
 
-}  // namespace
-
-namespace obhip {
-int launch_colnorm2(const double *d_Z, uint64_t ld, uint64_t p, uint64_t n, double add,
-                    double *d_out);
-int launch_dot_cols(const double *d_A, const double *d_B, uint64_t ld, uint64_t p, uint64_t n,
-                    double *d_out, double *d_part);
-int launch_set_identity(double *d_A, uint64_t p);
+// d_var[i] = || L^-1 b_i ||^2 + e2sigma at the n rows of d_x (column-major n x d, device)
+int post_var_dev(const obhip_model &m, obhip_terms &t, const PostFactor &f, const double *d_x,
+                 uint64_t n, double e2sigma, double *d_var) {
+  const uint64_t p = f.p, pp = f.pp;
+  if (t.p != p) return fail(OBHIP_ERR_INVALID, "posterior factor and terms disagree on p");
+  // row chunks so that the term-major design matrix (pp x rows doubles) stays below 8 GB
+  const uint64_t cmax = std::max<uint64_t>(128, ((8ull << 30) / (pp * sizeof(double))) / 128 * 128);
+  const uint64_t ntj = pp / 128;
+  DevBuf<double> Bcm, part;
+  for (uint64_t r0 = 0; r0 < n; r0 += cmax) {
+    const uint64_t nr = std::min(cmax, n - r0), npad = pad128(nr);
+    obhip_basis *b = nullptr;
+    // the chunk's rows of x: column-major with leading dimension n -> gather into a compact copy
+    DevBuf<double> xc;
+    const double *xsrc = d_x;
+    if (r0 != 0 || nr != n) {
+      OB_TRY(xc.alloc(nr * m.d));
+      OB_HIP(hipMemcpy2DAsync(xc.p, nr * sizeof(double), d_x + r0, n * sizeof(double),
+                              nr * sizeof(double), m.d, hipMemcpyDeviceToDevice, cur_stream()));
+      xsrc = xc.p;
+    }
+    OB_TRY(obhip_basis_create_dev(&b, &m, xsrc, nr, t.maxlev.data()));
+    struct Guard {
+      obhip_basis *b;
+      ~Guard() { obhip_basis_destroy(b); }
+    } guard{b};
+    OB_TRY(Bcm.alloc(pp * npad));
+    OB_TRY(part.alloc(ntj * npad));
+    OB_HIP(hipMemsetAsync(Bcm.p, 0, pp * npad * sizeof(double), cur_stream()));
+    OB_TRY(launch_getmat(*b, t, Bcm.p, npad));  // B^T: term-major, rows contiguous
+    {
+      ProfScope ps("predict_std_gemm");
+      OB_TRY(launch_atb(1, Bcm.p, npad, npad, f.X.p, pp, pp, pp, true, part.p, npad));
+    }
+    const double *pt = part.p;
+    double *out = d_var + r0;
+    OB_TRY(vmap(nr, [=] __device__(uint64_t i) {
+      double s = e2sigma;
+      for (uint64_t j = 0; j < ntj; ++j) s += pt[j * npad + i];
+      out[i] = s;
+    }));
+    OB_HIP(hipStreamSynchronize(cur_stream()));
+  }
+  return 0;
 }
+
+}  // namespace obhip
 
 extern "C" int obhip_predict_std(const obhip_model *m, const obhip_terms *tc, const double *theta,
                                  const double *H, const double *x, uint64_t n, uint64_t ldx,
@@ -96,54 +109,32 @@ extern "C" int obhip_predict_std(const obhip_model *m, const obhip_terms *tc, co
   if (!H) return fail(OBHIP_ERR_INVALID, "predict_std: var needs the total Hessian");
   obhip_terms &t = *const_cast<obhip_terms *>(tc);
   const uint64_t p = t.p;
-  // basis at the new points up to the levels the terms use, then B row-major
-  std::vector<int64_t> cap(t.maxlev);
-  obhip_basis *b = nullptr;
-  OB_TRY(obhip_basis_create(&b, m, x, n, ldx, cap.data()));
-  struct Guard {
-    obhip_basis *b;
-    ~Guard() { obhip_basis_destroy(b); }
-  } guard{b};
-  OB_TRY(t.prepare(b->md.cap, b->md.dims_h));
-  DevBuf<double> dB, dH, drhs, dth, dvar;
-  DevBuf<char> ws;
-  OB_TRY(dB.alloc(b->n_pad * t.p_pad));
-  OB_TRY(launch_materialize_rows(*b, t, dB.p));
-  // H = L L^T with the library's Cholesky (the solve it carries along is not used)
+  DevBuf<double> dH, dx, dvar;
   OB_TRY(dH.upload(H, p * p));
-  std::vector<double> zero(p, 0.0);
-  OB_TRY(drhs.upload(zero.data(), p));
-  OB_TRY(dth.alloc(p));
-  const uint64_t wsb = newton_workspace_bytes(p);
-  OB_TRY(ws.alloc(wsb));
-  OB_TRY(launch_newton_solve(p, dH.p, drhs.p, dth.p, ws.p, wsb));
-  // Z = L^{-1} B^T.  dH is row-major with L in its lower triangle = column-major upper
-  // triangular A = L^T, so op(A) = A^T = L; dB is column-major p_pad x n_pad.
-  RocBlas *rb = nullptr;
-  OB_TRY(rocblas(&rb));
-  if (rb->set_stream(rb->h, cur_stream()) != 0) return fail(OBHIP_ERR_HIP, "rocblas_set_stream failed");
-  const double one = 1.0;
-  {
-    ProfScope ps("predict_std_trsm");
-    if (rb->dtrsm(rb->h, kSideLeft, kFillUpper, kOpTranspose, kDiagNonUnit, (int64_t)p, (int64_t)n,
-                  &one, dH.p, (int64_t)p, dB.p, (int64_t)t.p_pad) != 0)
-      return fail(OBHIP_ERR_HIP, "rocblas_dtrsm failed");
+  PostFactor f;
+  OB_TRY(post_factor_build(dH.p, p, f, true));
+  if (ldx == n) {
+    OB_TRY(dx.upload(x, n * m->d));
+  } else {
+    std::vector<double> xc(n * m->d);
+    for (uint64_t l = 0; l < m->d; ++l) std::memcpy(&xc[l * n], x + l * ldx, n * sizeof(double));
+    OB_TRY(dx.upload(xc.data(), xc.size()));
   }
   OB_TRY(dvar.alloc(n));
-  OB_TRY(launch_colnorm2(dB.p, t.p_pad, p, n, std::exp(2.0 * sigma), dvar.p));
+  OB_TRY(post_var_dev(*m, t, f, dx.p, n, std::exp(2.0 * sigma), dvar.p));
   OB_HIP(hipMemcpyAsync(var, dvar.p, n * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
   OB_HIP(hipStreamSynchronize(cur_stream()));
   return 0;
 }
 
-
 // Marginal adjustment of lpdfvec(loglik_std, logpr_gauss) with the full Hessian
 // (lpdfvec::buildhess, fit.cpp:270-299): val = -1/2 log det H and
 //   gradhyp[l] = -1/2 tr(inv(H) dH/dhyp_l),  dH/dhyp_l = e^{-2 sigma}(B^T Bge_l + Bge_l^T B) - diag(lvarge_l prec)
 // (loglik_std.cpp:180-192, logpr_gauss.cpp:165-173), likewise for the two para.  The
-// reference forms the p x p x nhyp cubes and inv(H); here tr(inv(H) B^T Bge_l) =
-// sum_i (inv(H) b_i) . bge_l,i needs Y = inv(H) B^T once (two triangular solves on the
-// design matrix) and then one streaming dot product per hyper-parameter.
+// reference forms the p x p x nhyp cubes and inv(H) through eig_sym; here
+// tr(inv(H) B^T Bge_l) = sum_{k, i} Y[k][i] Bge_l[i][k] with Y = inv(H) B^T formed once (term-
+// major, like the design matrices it is contracted with) and one streaming dot product per
+// hyper-parameter.
 extern "C" int obhip_margadj_full(const obhip_basis *bc, const obhip_terms *tc, const obhip_model *m,
                                   const double *H, double sigma, double rho, double *val,
                                   double *gradhyp, double *gradpara) {
@@ -152,60 +143,48 @@ extern "C" int obhip_margadj_full(const obhip_basis *bc, const obhip_terms *tc, 
   obhip_basis &b = *const_cast<obhip_basis *>(bc);
   obhip_terms &t = *const_cast<obhip_terms *>(tc);
   const uint64_t p = t.p, d = m->d, nh = m->nhyp();
-  // H = L L^T
-  DevBuf<double> dH, drhs, dth, dI, ddiag, dscal;
-  DevBuf<char> ws;
+  const bool grads = gradhyp || gradpara;
+  DevBuf<double> dH;
   OB_TRY(dH.upload(H, p * p));
-  std::vector<double> zero(p, 0.0);
-  OB_TRY(drhs.upload(zero.data(), p));
-  OB_TRY(dth.alloc(p));
-  const uint64_t wsb = newton_workspace_bytes(p);
-  OB_TRY(ws.alloc(wsb));
-  OB_TRY(launch_newton_solve(p, dH.p, drhs.p, dth.p, ws.p, wsb));
+  PostFactor f;
+  OB_TRY(post_factor_build(dH.p, p, f, grads));
   std::vector<double> ld(p);
-  OB_HIP(hipMemcpy2DAsync(ld.data(), sizeof(double), dH.p, (p + 1) * sizeof(double), sizeof(double), p,
+  OB_HIP(hipMemcpy2DAsync(ld.data(), sizeof(double), f.L.p, (p + 1) * sizeof(double), sizeof(double), p,
                           hipMemcpyDeviceToHost, cur_stream()));
   OB_HIP(hipStreamSynchronize(cur_stream()));
   double logdet = 0;
   for (double v : ld) logdet += 2.0 * std::log(v);
   *val = -0.5 * logdet;
-  if (!gradhyp && !gradpara) return 0;
+  if (!grads) return 0;
 
-  RocBlas *rb = nullptr;
-  OB_TRY(rocblas(&rb));
-  if (rb->set_stream(rb->h, cur_stream()) != 0) return fail(OBHIP_ERR_HIP, "rocblas_set_stream failed");
-  const double one = 1.0;
-  // diag(inv(H)) = squared column norms of L^{-1}
-  OB_TRY(dI.alloc(p * p));
-  OB_TRY(launch_set_identity(dI.p, p));
-  if (rb->dtrsm(rb->h, kSideLeft, kFillUpper, kOpTranspose, kDiagNonUnit, (int64_t)p, (int64_t)p, &one,
-                dH.p, (int64_t)p, dI.p, (int64_t)p) != 0)
-    return fail(OBHIP_ERR_HIP, "rocblas_dtrsm failed");
-  OB_TRY(ddiag.alloc(p));
-  OB_TRY(launch_colnorm2(dI.p, p, p, p, 0.0, ddiag.p));
-  std::vector<double> hinv(p);
-  OB_HIP(hipMemcpyAsync(hinv.data(), ddiag.p, p * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
-  dI.release();
-  // Y = inv(H) B^T on a copy of the design matrix (column-major p_pad x n_pad)
+  // inv(H) = L^-T L^-1 = Linv^T Linv with Linv = X^T (row-major, k slow): one Gram-shaped product
+  const uint64_t pp = f.pp, npad = pad128(b.n);
+  DevBuf<double> Linv, Hinv;
+  OB_TRY(Linv.alloc(pp * pp));
+  OB_TRY(Hinv.alloc(pp * pp));
+  OB_HIP(hipMemsetAsync(Linv.p, 0, pp * pp * sizeof(double), cur_stream()));
+  OB_TRY(launch_transpose(f.X.p, pp, Linv.p, pp, p));
+  OB_TRY(launch_atb(2, Linv.p, pp, pp, Linv.p, pp, pp, pp, false, Hinv.p, pp));
+  std::vector<double> hinv(p);  // diag(inv(H))
+  OB_HIP(hipMemcpy2DAsync(hinv.data(), sizeof(double), Hinv.p, (pp + 1) * sizeof(double),
+                          sizeof(double), p, hipMemcpyDeviceToHost, cur_stream()));
+  // B^T and Y = inv(H) B^T, both term-major pp x npad
   OB_TRY(ensure_gradbasis(b));
-  OB_TRY(ensure_bmat(b, t));
-  const uint64_t nel = b.n_pad * t.p_pad;
-  DevBuf<double> dY, dG;
-  OB_TRY(dY.alloc(nel));
-  OB_HIP(hipMemcpyAsync(dY.p, b.bmat.p, nel * sizeof(double), hipMemcpyDeviceToDevice, cur_stream()));
-  if (rb->dtrsm(rb->h, kSideLeft, kFillUpper, kOpTranspose, kDiagNonUnit, (int64_t)p, (int64_t)b.n, &one,
-                dH.p, (int64_t)p, dY.p, (int64_t)t.p_pad) != 0 ||
-      rb->dtrsm(rb->h, kSideLeft, kFillUpper, kOpNone, kDiagNonUnit, (int64_t)p, (int64_t)b.n, &one, dH.p,
-                (int64_t)p, dY.p, (int64_t)t.p_pad) != 0)
-    return fail(OBHIP_ERR_HIP, "rocblas_dtrsm failed");
+  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  DevBuf<double> Bcm, Ycm, Gcm, dscal;
+  OB_TRY(Bcm.alloc(pp * npad));
+  OB_TRY(Ycm.alloc(pp * npad));
+  OB_HIP(hipMemsetAsync(Bcm.p, 0, pp * npad * sizeof(double), cur_stream()));
+  OB_TRY(launch_getmat(b, t, Bcm.p, npad));
+  OB_TRY(launch_atb(2, Hinv.p, pp, pp, Bcm.p, npad, npad, pp, false, Ycm.p, npad));
   OB_TRY(dscal.alloc(nh + 1 + 4096));
   double *part = dscal.p + nh + 1;
-  // tr(inv(H) B^T B) and tr(inv(H) B^T Bge_l)
-  OB_TRY(launch_dot_cols(b.bmat.p, dY.p, t.p_pad, p, b.n, dscal.p + nh, part));
-  OB_TRY(dG.alloc(nel));
+  // tr(inv(H) B^T B) and tr(inv(H) B^T Bge_l): rows k < p, the n real columns of each
+  OB_TRY(launch_dot_cols(Bcm.p, Ycm.p, npad, b.n, p, dscal.p + nh, part));
+  OB_TRY(Gcm.alloc(pp * npad));
   for (uint64_t h = 0; h < nh; ++h) {
-    OB_TRY(launch_materialize_rows(*b.grad->gb, *grad_view(t, b, h), dG.p));
-    OB_TRY(launch_dot_cols(dG.p, dY.p, t.p_pad, p, b.n, dscal.p + h, part));
+    OB_TRY(launch_getmat(*b.grad->gb, *grad_view(t, b, h), Gcm.p, npad));
+    OB_TRY(launch_dot_cols(Gcm.p, Ycm.p, npad, b.n, p, dscal.p + h, part));
   }
   std::vector<double> q(nh + 1);
   OB_HIP(hipMemcpyAsync(q.data(), dscal.p, (nh + 1) * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));

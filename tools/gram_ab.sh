@@ -15,6 +15,6 @@ for set in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$tag -o p -- \
     python3 $R/tools/gram_only.py 1000000 0 > $OUT/pmc_$tag.log 2>&1 || { tail -5 $OUT/pmc_$tag.log; exit 1; }
   f=$(find $OUT/pmc_$tag -name "*counter_collection.csv" | head -1)
-  python3 $R/tools/pmc_summary.py $f k_gram_dma2 | tee -a $OUT/pmc.txt
+  python3 $R/tools/pmc_summary.py $f k_atb_dma2 | tee -a $OUT/pmc.txt
   rm -rf $OUT/pmc_$tag
 done

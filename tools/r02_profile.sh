@@ -21,7 +21,7 @@ for set in "MfmaUtil VALUBusy" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_s
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_${TAG}_$tag -o p -- \
     python3 $R/tools/gram_only.py 1000000 0 > $OUT/pmc_${TAG}_$tag.log 2>&1 || { tail -5 $OUT/pmc_${TAG}_$tag.log; exit 1; }
   f=$(find $OUT/pmc_${TAG}_$tag -name "*counter_collection.csv" | head -1)
-  grep -E "k_gram_dma2|Counter_Name" $f > $OUT/pmc_${TAG}_$tag.csv
+  grep -E "k_atb_dma2|Counter_Name" $f > $OUT/pmc_${TAG}_$tag.csv
   rm -rf $OUT/pmc_${TAG}_$tag
   echo "pmc $set ok"
 done

@@ -1,4 +1,4 @@
-"""gpurun_out/r02/ (tools/r02_profile.sh) -> profiles/r02_*: the PMC passes of k_gram_dma2 as
+"""gpurun_out/r02/ (tools/r02_profile.sh) -> profiles/r02_*: the PMC passes of k_atb_dma2 as
 two small JSON files bench.py reads for roofline.traffic / roofline.mfma_util, the per-kernel
 rocprofv3 statistics of the bench command, and the bench lines themselves."""
 import collections
@@ -18,7 +18,7 @@ def counters(name):
     rows = list(csv.DictReader(open(os.path.join(SRC, "pmc_%s_%s.csv" % (tag, name)))))
     per = collections.defaultdict(list)
     for r in rows:
-        if "k_gram_dma2" in r["Kernel_Name"]:
+        if "k_atb_dma2" in r["Kernel_Name"]:
             per[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
 
@@ -30,7 +30,7 @@ tc = counters("TCC_HIT_sum_TCC_MISS_sum")
 cfg = {"d": 20, "rows": 1000000, "p": 4096, "knots": 40}
 cmd = "rocprofv3 --kernel-trace --pmc %s --output-format csv -- python3 tools/gram_only.py 1000000 0 " \
       "(one pass per counter set, tools/r02_profile.sh)"
-json.dump({"kernel": "k_gram_dma2", "config": cfg, "command": cmd % "MfmaUtil VALUBusy",
+json.dump({"kernel": "k_atb_dma2", "config": cfg, "command": cmd % "MfmaUtil VALUBusy",
            "launches": mf["MfmaUtil"][1], "mfma_util": mf["MfmaUtil"][0] / 100.0,
            "valu_busy": mf["VALUBusy"][0] / 100.0,
            "note": "MfmaUtil / VALUBusy as rocprofv3 derives them (gfx94x formulas, "
@@ -41,7 +41,7 @@ write_kb = wr["WRITE_SIZE"][0]
 fetch_b = 2.0 * fetch_raw_kb * 1024      # gfx950: FETCH_SIZE counts 128-B requests at 64 B
 write_b = write_kb * 1024
 hit, miss = tc["TCC_HIT_sum"][0], tc["TCC_MISS_sum"][0]
-json.dump({"kernel": "k_gram_dma2", "config": cfg, "command": cmd % "FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum",
+json.dump({"kernel": "k_atb_dma2", "config": cfg, "command": cmd % "FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum",
            "launches": fe["FETCH_SIZE"][1], "FETCH_SIZE_KB_per_launch_raw": fetch_raw_kb,
            "WRITE_SIZE_KB_per_launch": write_kb, "TCC_HIT_per_launch": hit, "TCC_MISS_per_launch": miss,
            "l2_hit_rate": hit / (hit + miss),
