@@ -285,7 +285,9 @@ int obhip_fit_newton(const obhip_basis *b, const obhip_terms *t,
 /* lpdf::optcg (fit.cpp:37-96) on lpdfvec(logpr_gauss, loglik_gauss)
  * (loglik_gauss.cpp:110-157), domargadj = false.  theta is in/out (host, p);
  * iters_out receives the iteration count; diagH (p, may be NULL) the
- * preconditioner (lpdfvec::diaghess_). */
+ * preconditioner (lpdfvec::diaghess_); val_out (may be NULL) the value of the
+ * objective at the result -- asking for it costs one more evaluation (two passes
+ * over the basis) when the last iteration advanced it by the recurrence. */
 int obhip_fit_cg(const obhip_basis *b, const obhip_terms *t,
                  const obhip_model *m, const double *y, double sigma,
                  double rho, double tol, uint64_t maxit, double *theta,

@@ -7,6 +7,7 @@
 #include <limits>
 
 #include "obhip_internal.h"
+#include "vec_ops.h"
 
 using namespace obhip;
 
@@ -321,6 +322,171 @@ int obhip_fit_newton(const obhip_basis *b, const obhip_terms *t, const obhip_mod
 }
 
 // ---- PCG ----------------------------------------------------------------------------
+// lpdf::optcg (fit.cpp:37-96) for lpdfvec(logpr_gauss, loglik_gauss | loglik_std) with every
+// vector in HBM: theta, the gradient, the preconditioned gradient, the search direction and
+// the Hessian products are p-vectors on the device, the step algebra of an iteration (three
+// dot products, the break conditions, theta / gradient / direction updates) is ONE
+// single-workgroup kernel, and the host reads back five scalars per iteration to learn
+// whether the loop goes on.  With several ranks the p-vector of every B^T a pass is summed
+// on the library's stream (RCCL) before the kernel that consumes it; nothing but the five
+// scalars ever synchronises the host.
+}  // extern "C"
+
+namespace {
+
+constexpr int kCgThreads = 1024;
+enum { S_VAL = 0, S_VALDIFF, S_NUM, S_DENOM, S_ALPHA, S_DONE, S_NEXT, S_NUM0, S_GP, S_FINITE, S_VALO, S_COUNT = 16 };
+
+struct CgVecs {
+  double *theta, *grad, *rm, *pv, *q, *mdiag;
+  const double *prec;
+  uint64_t p;
+};
+
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *red /* K * kCgThreads / 64 */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = kCgThreads / 64;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+    if (lane == 0) red[k * nw + wave] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += red[k * nw + w];  // fixed order: reproducible
+    v[k] = s;
+  }
+  __syncthreads();
+}
+
+// after the two passes of update(): hv = B^T r (summed over ranks), ss = sum (yhat - y)^2:
+// grad = hv - theta prec (logpr_gauss.cpp:105), val (loglik_gauss.cpp:121 + logpr_gauss.cpp:101)
+__global__ void __launch_bounds__(kCgThreads)
+k_cg_eval(CgVecs v, const double *__restrict__ hv, double e2, double ntot_sigma, double logsd,
+          double *__restrict__ scal) {
+  __shared__ double red[kCgThreads / 64];
+  double s[1] = {0.0};
+  for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) {
+    const double c = v.theta[k];
+    v.grad[k] = hv[k] - c * v.prec[k];
+    s[0] = fma(c * c, v.prec[k], s[0]);
+  }
+  block_sum<1>(s, red);
+  if (threadIdx.x == 0) {
+    scal[S_VALO] = scal[S_VAL];
+    scal[S_VAL] = -0.5 * e2 * hv[v.p + 1] - ntot_sigma - 0.5 * s[0] - logsd;
+  }
+}
+
+// m = diaghess (e^{-2 sigma} sqcolsums + prior), rm = grad / m, pv = rm (fit.cpp:47-60)
+__global__ void __launch_bounds__(kCgThreads)
+k_cg_init(CgVecs v, const double *__restrict__ sq, double e2, double *__restrict__ scal) {
+  __shared__ double red[kCgThreads / 64];
+  double bad[1] = {0.0};
+  for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) {
+    const double md = e2 * sq[k] + v.prec[k];
+    v.mdiag[k] = md;
+    const double r = v.grad[k] / md;
+    v.rm[k] = r;
+    v.pv[k] = r;
+    if (!(isfinite(md) && isfinite(v.grad[k]))) bad[0] += 1.0;
+  }
+  block_sum<1>(bad, red);
+  if (threadIdx.x == 0) {
+    scal[S_FINITE] = bad[0] == 0.0 ? 1.0 : 0.0;
+    scal[S_VALDIFF] = 10.0;
+    scal[S_NUM0] = -1.0;
+    scal[S_DONE] = 0.0;
+    scal[S_NEXT] = 0.0;
+  }
+}
+
+// q = e^{-2 sigma} (B^T B pv) + prec pv (lpdfvec::hessmult, fit.cpp:382-392)
+__global__ void __launch_bounds__(256)
+k_cg_q(CgVecs v, const double *__restrict__ raw, double e2) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < v.p) v.q[k] = e2 * raw[k] + v.prec[k] * v.pv[k];
+}
+
+// One iteration of fit.cpp:71-85.  PART 0: the whole step with gradient and value advanced
+// by the recurrence (the objective is exactly quadratic); PART 1: up to theta += alpha pv
+// (a full update() follows); PART 2: the rest of the step after that update().
+template <int PART>
+__global__ void __launch_bounds__(kCgThreads)
+k_cg_iter(CgVecs v, double tol, double *__restrict__ scal) {
+  __shared__ double red[3 * kCgThreads / 64];
+  __shared__ double sh[4];
+  if (PART != 2) {
+    double d[3] = {0.0, 0.0, 0.0};  // num = grad . rm, denom = q . pv, gp = grad . pv
+    for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) {
+      d[0] = fma(v.grad[k], v.rm[k], d[0]);
+      d[1] = fma(v.q[k], v.pv[k], d[1]);
+      d[2] = fma(v.grad[k], v.pv[k], d[2]);
+    }
+    block_sum<3>(d, red);
+    if (threadIdx.x == 0) {
+      const double num = d[0], denom = d[1];
+      double num0 = scal[S_NUM0];
+      bool done = num < tol && scal[S_VALDIFF] < tol;  // fit.cpp:73
+      // Rounding floor: once the preconditioned gradient has dropped by 14 digits what is left
+      // of it is rounding noise and the next direction a difference of two equal numbers; an
+      // exactly vanishing gradient or a direction without curvature has no step length
+      // either.  The reference has none of these guards and divides 0 / 0 there.
+      if (!done) {
+        if (num0 < 0.0) num0 = num;
+        if (num <= 1e-28 * num0 || !(num > 0.0) || !(denom > 0.0)) done = true;
+      }
+      scal[S_NUM0] = num0;
+      scal[S_NUM] = num;
+      scal[S_DENOM] = denom;
+      scal[S_GP] = d[2];
+      scal[S_DONE] = done ? 1.0 : 0.0;
+      scal[S_ALPHA] = done ? 0.0 : num / denom;
+      sh[0] = done ? 1.0 : 0.0;
+      sh[1] = done ? 0.0 : num / denom;
+    }
+    __syncthreads();
+    if (sh[0] != 0.0) return;
+    const double alpha = sh[1];
+    for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) v.theta[k] = fma(alpha, v.pv[k], v.theta[k]);
+    if (PART == 1) return;
+    // recurrence: val += alpha g.p - alpha^2 p.q / 2, grad -= alpha q
+    if (threadIdx.x == 0) {
+      const double dv = alpha * scal[S_GP] - 0.5 * alpha * alpha * scal[S_DENOM];
+      scal[S_VALO] = scal[S_VAL];
+      scal[S_VAL] += dv;
+    }
+    for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) v.grad[k] = fma(-alpha, v.q[k], v.grad[k]);
+    __syncthreads();
+  }
+  // rm = grad / m, beta = -(alpha q) . rm / num, pv = rm + beta pv (fit.cpp:80-84); and the
+  // tolerance test the NEXT iteration opens with (fit.cpp:72-73 needs grad and rm only), so
+  // that the host can skip the Hessian product of a converged iterate
+  const double alpha = scal[S_ALPHA], num = scal[S_NUM];
+  double n2[2] = {0.0, 0.0};
+  for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) {
+    const double r = v.grad[k] / v.mdiag[k];
+    v.rm[k] = r;
+    n2[0] = fma(-(alpha * v.q[k]), r, n2[0]);
+    n2[1] = fma(v.grad[k], r, n2[1]);
+  }
+  block_sum<2>(n2, red);
+  const double beta = n2[0] / num;
+  for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) v.pv[k] = fma(beta, v.pv[k], v.rm[k]);
+  if (threadIdx.x == 0) {
+    const double vd = scal[S_VAL] - scal[S_VALO];
+    scal[S_VALDIFF] = vd;
+    scal[S_NEXT] = (n2[1] < tol && vd < tol) ? 1.0 : 0.0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
 int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_model *m,
                      const double *d_y, double sigma, double rho, double tol, uint64_t maxit,
                      double *d_theta, uint64_t *iters_out, double *d_diagH, double *val_out,
@@ -335,137 +501,119 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_mo
   double logsd = 0;  // sum(log(coeffsd * sca)), logpr_gauss.cpp:101
   for (uint64_t k = 0; k < p; ++k) logsd += std::log(std::sqrt(tv[k]) * std::exp(rho));
 
-  DevBuf<double> yhat, r, tmp, din, dpv;
+  DevBuf<double> yhat, r, tmp, dpv, vec, dprec, scal;
   OB_TRY(yhat.alloc(n));
   OB_TRY(r.alloc(n));
   OB_TRY(tmp.alloc(n));
-  OB_TRY(din.alloc(p));
   OB_TRY(dpv.alloc(p + 2));
+  OB_TRY(vec.alloc(5 * p));  // grad, rm, pv, q, mdiag
+  OB_TRY(dprec.upload(prec.data(), p));
+  OB_TRY(scal.alloc(S_COUNT));
   double *red = nullptr;
   OB_TRY(scratch(&red));
   hipStream_t st = cur_stream();
-
+  OB_HIP(hipMemsetAsync(scal.p, 0, S_COUNT * sizeof(double), st));
+  CgVecs v{d_theta, vec.p, vec.p + p, vec.p + 2 * p, vec.p + 3 * p, vec.p + 4 * p, dprec.p, p};
   const bool many = comm != nullptr;
-  auto reduce_pull = [&](double *d_buf, uint64_t count, double *host) -> int {
-    if (many) OB_TRY(comm_allreduce(comm, d_buf, count));  // stream-ordered (RCCL) or staged
-    return d2h(host, d_buf, count * sizeof(double));
-  };
 
   // total number of rows over all ranks
   double ntot = (double)n;
   if (many) {
     OB_HIP(hipMemcpyAsync(dpv.p, &ntot, sizeof(double), hipMemcpyHostToDevice, st));
-    OB_HIP(hipStreamSynchronize(st));  // ntot is about to be overwritten
-    OB_TRY(reduce_pull(dpv.p, 1, &ntot));
+    OB_HIP(hipStreamSynchronize(st));
+    OB_TRY(comm_allreduce(comm, dpv.p, 1));
+    OB_TRY(d2h(&ntot, dpv.p, sizeof(double)));
   }
-
-  std::vector<double> coeff(p), grad(p), hv(p + 2);
-  OB_TRY(d2h(coeff.data(), d_theta, p * sizeof(double)));
-
-  // lpdfvec::update with compute_val, compute_grad (fit.cpp:323-363)
-  auto update = [&](const std::vector<double> &c, double &val) -> int {
-    OB_HIP(hipMemcpyAsync(din.p, c.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
-    OB_TRY(launch_mm(*b, t, din.p, yhat.p, false));                 // loglik_gauss.cpp:117
-    OB_TRY(launch_resid(yhat.p, d_y, n, e2, r.p, tmp.p));           // :118-124
-    OB_TRY(launch_tmm(*b, t, r.p, dpv.p, false));                   // :125
+  // lpdfvec::update with compute_val, compute_grad (fit.cpp:323-363) at the theta in HBM
+  bool theta_zero = false;  // B 0 = 0 needs no pass over the basis (first update of a cold start)
+  {
+    const double *th = d_theta;
+    double *out = scal.p + S_GP;
+    OB_TRY(vsum<1>(p, [=] __device__(uint64_t k, double (&acc)[1]) { acc[0] += fabs(th[k]); }, out, red));
+    double s = 1.0;
+    OB_TRY(d2h(&s, out, sizeof(double)));
+    theta_zero = s == 0.0;
+  }
+  auto update = [&]() -> int {
+    if (theta_zero)
+      OB_TRY(launch_fill(yhat.p, n, 0.0));
+    else
+      OB_TRY(launch_mm(*b, t, v.theta, yhat.p, false));      // loglik_gauss.cpp:117
+    theta_zero = false;
+    OB_TRY(launch_resid(yhat.p, d_y, n, e2, r.p, tmp.p));    // :118-124
+    OB_TRY(launch_tmm(*b, t, r.p, dpv.p, false));            // :125
     OB_TRY(launch_sum_sumsq(tmp.p, n, dpv.p + p, red));
-    OB_TRY(reduce_pull(dpv.p, p + 2, hv.data()));
-    double pr = 0;
-    for (uint64_t k = 0; k < p; ++k) {
-      grad[k] = hv[k] - c[k] * prec[k];                             // logpr_gauss.cpp:105
-      pr += c[k] * c[k] * prec[k];
-    }
-    val = -0.5 * e2 * hv[p + 1] - ntot * sigma - 0.5 * pr - logsd;  // loglik_gauss.cpp:121
+    if (many) OB_TRY(comm_allreduce(comm, dpv.p, p + 2));
+    hipLaunchKernelGGL(k_cg_eval, dim3(1), dim3(kCgThreads), 0, st, v, dpv.p, e2, ntot * sigma, logsd,
+                       scal.p);
+    OB_HIP(hipGetLastError());
     return 0;
   };
-  // lpdfvec::hessmult (fit.cpp:382-392): loglik_gauss.cpp:137-145 + logpr_gauss.cpp:113-115
-  auto hessmult = [&](const std::vector<double> &v, std::vector<double> &out) -> int {
-    OB_HIP(hipMemcpyAsync(din.p, v.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
-    OB_TRY(launch_mm(*b, t, din.p, yhat.p, false));
-    OB_TRY(launch_scale(yhat.p, n, e2));
+  // q = lpdfvec::hessmult(pv): loglik_gauss.cpp:137-145 + logpr_gauss.cpp:113-115
+  auto hessmult = [&]() -> int {
+    OB_TRY(launch_mm(*b, t, v.pv, yhat.p, false));
     OB_TRY(launch_tmm(*b, t, yhat.p, dpv.p, false));
-    OB_TRY(reduce_pull(dpv.p, p, hv.data()));
-    for (uint64_t k = 0; k < p; ++k) out[k] = hv[k] + prec[k] * v[k];
+    if (many) OB_TRY(comm_allreduce(comm, dpv.p, p));
+    hipLaunchKernelGGL(k_cg_q, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, st, v, dpv.p, e2);
+    OB_HIP(hipGetLastError());
     return 0;
   };
 
-  double val = 0;
-  OB_TRY(update(coeff, val));
+  OB_TRY(update());
   // m = diaghess(): e^{-2 sigma} sqcolsums + prior (loglik_gauss.cpp:154-157)
-  std::vector<double> mdiag(p);
   OB_TRY(launch_fill(tmp.p, n, 1.0));
   OB_TRY(launch_tmm(*b, t, tmp.p, dpv.p, true));
-  OB_TRY(reduce_pull(dpv.p, p, hv.data()));
-  bool finite = true;
-  for (uint64_t k = 0; k < p; ++k) {
-    mdiag[k] = e2 * hv[k] + prec[k];
-    finite = finite && std::isfinite(mdiag[k]) && std::isfinite(grad[k]);
-  }
+  if (many) OB_TRY(comm_allreduce(comm, dpv.p, p));
+  hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(kCgThreads), 0, st, v, dpv.p, e2, scal.p);
+  OB_HIP(hipGetLastError());
+  double hs[S_COUNT];
+  OB_TRY(d2h(hs, scal.p, sizeof hs));
   uint64_t k = 0;
-  if (!finite) {
+  double val = hs[S_VAL];
+  if (hs[S_FINITE] == 0.0) {
     val = -std::numeric_limits<double>::infinity();  // fit.cpp:53-56
   } else {
-    std::vector<double> rm(p), pv(p), q(p);
-    for (uint64_t i = 0; i < p; ++i) pv[i] = rm[i] = grad[i] / mdiag[i];
-    OB_TRY(hessmult(pv, q));
-    double valdiff = 10;
+    OB_TRY(hessmult());
     // The objective is exactly quadratic in coeff, so the gradient and value after the step
     // follow from the Hessian product already in hand: grad -= alpha q, val += alpha g.p -
     // alpha^2 p.q / 2.  The reference re-evaluates both with a full update() (two more
     // passes over the basis) in every iteration (fit.cpp:79); here that happens every
     // `refresh` iterations and once at the end, which halves the passes and keeps the same
     // iterates up to rounding.  OBHIP_CG_REFRESH=1 restores the reference's schedule.
-    static const uint64_t refresh =
-        getenv("OBHIP_CG_REFRESH") ? std::max(1, atoi(getenv("OBHIP_CG_REFRESH"))) : 8;
+    const char *re = getenv("OBHIP_CG_REFRESH");
+    const uint64_t refresh = re ? (uint64_t)std::max(1, atoi(re)) : 8;
     bool exact = true;  // grad / val come from update(), not from the recurrence
-    double num0 = -1.0;
     for (k = 0; k < maxit; ++k) {  // fit.cpp:71-85
-      double num = 0;
-      for (uint64_t i = 0; i < p; ++i) num += grad[i] * rm[i];
-      if (num < tol && valdiff < tol) break;
-      // Rounding floor: once the preconditioned gradient has dropped by 14 digits what is
-      // left of it is rounding noise, and the next direction rm + beta pv is a difference
-      // of two equal numbers (p = 1 reaches this after one step).  The reference has no
-      // such guard and takes a step of arbitrary length along that noise.
-      if (num0 < 0.0) num0 = num;
-      if (num <= 1e-28 * num0) break;
-      // an exactly vanishing gradient (e.g. p = 1 after one step) would make the next
-      // search direction zero and alpha = 0 / 0; the reference has no guard for this
-      if (!(num > 0.0)) break;
-      double denom = 0, gp = 0;
-      for (uint64_t i = 0; i < p; ++i) {
-        denom += q[i] * pv[i];
-        gp += grad[i] * pv[i];
+      const bool full = (k + 1) % refresh == 0;
+      if (full)
+        hipLaunchKernelGGL(k_cg_iter<1>, dim3(1), dim3(kCgThreads), 0, st, v, tol, scal.p);
+      else
+        hipLaunchKernelGGL(k_cg_iter<0>, dim3(1), dim3(kCgThreads), 0, st, v, tol, scal.p);
+      OB_HIP(hipGetLastError());
+      if (full) {  // the break conditions come first: a converged iterate takes no update()
+        OB_TRY(d2h(hs, scal.p, (S_NEXT + 1) * sizeof(double)));
+        if (hs[S_DONE] != 0.0) break;
+        OB_TRY(update());
+        hipLaunchKernelGGL(k_cg_iter<2>, dim3(1), dim3(kCgThreads), 0, st, v, tol, scal.p);
+        OB_HIP(hipGetLastError());
       }
-      // a search direction that cancelled to zero (p = 1: the second direction is
-      // rm - (eps / g) g, i.e. 0 up to rounding) has no step length either
-      if (!(denom > 0.0)) break;
-      const double alpha = num / denom;
-      for (uint64_t i = 0; i < p; ++i) coeff[i] += alpha * pv[i];
-      const double valo = val;
-      if ((k + 1) % refresh == 0) {
-        OB_TRY(update(coeff, val));
-        exact = true;
-      } else {
-        val += alpha * gp - 0.5 * alpha * alpha * denom;
-        for (uint64_t i = 0; i < p; ++i) grad[i] -= alpha * q[i];
-        exact = false;
+      OB_TRY(d2h(hs, scal.p, (S_NEXT + 1) * sizeof(double)));  // the host sync of an iteration
+      if (hs[S_DONE] != 0.0) break;
+      exact = full;
+      if (hs[S_NEXT] != 0.0) {  // the next iteration would stop at once: k + 1 iterations made,
+        ++k;                    // and its Hessian product is not needed
+        break;
       }
-      valdiff = val - valo;
-      double num2 = 0;
-      for (uint64_t i = 0; i < p; ++i) {
-        rm[i] = grad[i] / mdiag[i];
-        num2 -= (alpha * q[i]) * rm[i];
-      }
-      const double beta = num2 / num;
-      for (uint64_t i = 0; i < p; ++i) pv[i] = rm[i] + beta * pv[i];
-      OB_TRY(hessmult(pv, q));
+      OB_TRY(hessmult());
     }
-    if (!exact) OB_TRY(update(coeff, val));  // the value reported is a true evaluation
+    // the value reported is a true evaluation (callers that re-evaluate anyway pass
+    // val_out = NULL and save the two passes)
+    if (!exact && val_out) OB_TRY(update());
+    OB_TRY(d2h(hs, scal.p, sizeof(double)));
+    val = hs[S_VAL];
   }
-  OB_HIP(hipMemcpyAsync(d_theta, coeff.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
   if (d_diagH)
-    OB_HIP(hipMemcpyAsync(d_diagH, mdiag.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
+    OB_HIP(hipMemcpyAsync(d_diagH, v.mdiag, p * sizeof(double), hipMemcpyDeviceToDevice, st));
   OB_HIP(hipStreamSynchronize(st));
   if (iters_out) *iters_out = k;
   if (val_out) *val_out = val;

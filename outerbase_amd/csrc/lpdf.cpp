@@ -887,9 +887,9 @@ struct LpdfVec : obhip_lpdf {
     DevBuf<double> dth, ddiag;
     OB_TRY(dth.upload(coeff.data(), p));
     OB_TRY(ddiag.alloc(p));
-    double v = 0;
+    // (no value asked for: the update() below evaluates the fit anyway)
     OB_TRY(obhip_fit_cg_dev(lik->ob, lik->t, om, lik->y.p, lik->para[0], pr->para[0], tol, maxepch,
-                            dth.p, &cgiters, ddiag.p, &v, nullptr));
+                            dth.p, &cgiters, ddiag.p, nullptr, nullptr));
     std::vector<double> c(p);
     OB_TRY(d2h(c.data(), dth.p, p * sizeof(double)));
     compute_gradhyp = compute_gradpara = true;  // fit.cpp:87-93

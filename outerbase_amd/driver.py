@@ -229,13 +229,13 @@ class HotPath:
         else:
             self.standardise()
             self.theta.zero_()
-            iters, val = C.c_uint64(0), C.c_double(0)
+            iters = C.c_uint64(0)
             maxit = self.cg_maxit
             if maxit is None:
                 maxit = getsteps(self.p, self.n_total, 1.0 / math.exp(2 * self.sigma))
             call("obhip_fit_cg_dev", self.basis, self.t._h, self.om._h, self.y.data_ptr(),
                  self.sigma, self.rho, self.cg_tol, int(maxit), self.theta.data_ptr(),
-                 C.byref(iters), self.diagH.data_ptr(), C.byref(val), self.comm)
+                 C.byref(iters), self.diagH.data_ptr(), None, self.comm)
             self.cg_iters = iters.value
 
     def standardised_targets(self):
