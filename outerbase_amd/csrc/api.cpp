@@ -57,12 +57,8 @@ int basis_setup(obhip_basis *b, const obhip_model *m, const int64_t *levelcap) {
   return launch_build_basis(*b);
 }
 
-double *g_scratch = nullptr;  // 2048 doubles for two-stage reductions (never freed)
-int scratch(double **p) {
-  if (!g_scratch) OB_HIP(hipMalloc((void **)&g_scratch, 2048 * sizeof(double)));
-  *p = g_scratch;
-  return 0;
-}
+constexpr size_t kScratch = 2048;  // doubles of scratch of the two-stage reductions: taken from
+                                   // the pool per call (keyed by device and stream)
 
 int d2h(void *dst, const void *src, size_t bytes) {
   OB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cur_stream()));
@@ -85,6 +81,7 @@ int obhip_basis_create(obhip_basis **out, const obhip_model *m, const double *x,
   b->n = n;
   b->n_pad = (n + kTileRows - 1) / kTileRows * kTileRows;
   b->d = m->d;
+  (void)hipGetDevice(&b->device);
   int rc = 0;
   if (ldx == n) {
     rc = b->x.upload(x, n * m->d);
@@ -112,6 +109,7 @@ int obhip_basis_create_dev(obhip_basis **out, const obhip_model *m, const double
   b->n = n;
   b->n_pad = (n + kTileRows - 1) / kTileRows * kTileRows;
   b->d = m->d;
+  (void)hipGetDevice(&b->device);
   int rc = b->x.alloc(n * m->d);
   if (!rc && hipMemcpyAsync(b->x.p, d_x, n * m->d * sizeof(double), hipMemcpyDeviceToDevice,
                             cur_stream()) != hipSuccess)
@@ -509,8 +507,9 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_mo
   OB_TRY(vec.alloc(5 * p));  // grad, rm, pv, q, mdiag
   OB_TRY(dprec.upload(prec.data(), p));
   OB_TRY(scal.alloc(S_COUNT));
-  double *red = nullptr;
-  OB_TRY(scratch(&red));
+  DevBuf<double> redbuf;
+  OB_TRY(redbuf.alloc(kScratch));
+  double *red = redbuf.p;
   hipStream_t st = cur_stream();
   OB_HIP(hipMemsetAsync(scal.p, 0, S_COUNT * sizeof(double), st));
   CgVecs v{d_theta, vec.p, vec.p + p, vec.p + 2 * p, vec.p + 3 * p, vec.p + 4 * p, dprec.p, p};
@@ -578,10 +577,11 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_mo
     // follow from the Hessian product already in hand: grad -= alpha q, val += alpha g.p -
     // alpha^2 p.q / 2.  The reference re-evaluates both with a full update() (two more
     // passes over the basis) in every iteration (fit.cpp:79); here that happens every
-    // `refresh` iterations and once at the end, which halves the passes and keeps the same
-    // iterates up to rounding.  OBHIP_CG_REFRESH=1 restores the reference's schedule.
+    // `refresh` (16) iterations and, when the caller asks for the value, once at the end, which
+    // halves the passes and keeps the same iterates up to rounding.  OBHIP_CG_REFRESH=1
+    // restores the reference's schedule.
     const char *re = getenv("OBHIP_CG_REFRESH");
-    const uint64_t refresh = re ? (uint64_t)std::max(1, atoi(re)) : 8;
+    const uint64_t refresh = re ? (uint64_t)std::max(1, atoi(re)) : 16;
     bool exact = true;  // grad / val come from update(), not from the recurrence
     for (k = 0; k < maxit; ++k) {  // fit.cpp:71-85
       const bool full = (k + 1) % refresh == 0;
@@ -689,9 +689,9 @@ int obhip_synth_xy_dev(uint64_t seed, uint64_t row0, uint64_t n, uint64_t d, con
 
 int obhip_sum_sumsq_dev(const double *d_v, uint64_t n, double *d_out2) {
   if (!d_v || !d_out2) return fail(OBHIP_ERR_INVALID, "null argument");
-  double *red = nullptr;
-  OB_TRY(scratch(&red));
-  return launch_sum_sumsq(d_v, n, d_out2, red);
+  DevBuf<double> red;  // back to the pool on return: handed out again to this stream only
+  OB_TRY(red.alloc(kScratch));
+  return launch_sum_sumsq(d_v, n, d_out2, red.p);
 }
 
 int obhip_affine_dev(double *d_v, uint64_t n, double cent, double sca) {

@@ -2,6 +2,7 @@
 // per-kernel hipEvent profiling, the device view of a model (ModelDev) and the
 // device tables of a `terms` matrix.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -93,7 +94,7 @@ int pool_alloc(void **p, size_t bytes) {
   return 0;
 }
 
-void pool_free(void *p, size_t bytes) {
+void pool_free(void *p, size_t bytes, hipStream_t stream) {
   if (!p) return;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -102,7 +103,7 @@ void pool_free(void *p, size_t bytes) {
     (void)hipFree(p);
     return;
   }
-  g_pool.emplace(bytes, PoolBlock{p, dev, cur_stream()});
+  g_pool.emplace(bytes, PoolBlock{p, dev, stream});
   g_pool_bytes += bytes;
   while (g_pool_bytes > pool_cap() && !g_pool.empty()) {  // largest first
     auto it = std::prev(g_pool.end());
@@ -179,25 +180,34 @@ int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
     ccol += (uint64_t)c;
     const double *hy = &m.hyp[m.hypst[l]];
     const double a = 2.0, b = 0.25;  // covfuncs.h:42,53-54,66
-    if (D.kind == OBHIP_COV_MAT25) {
-      D.p0 = std::exp(a * hy[0]);  // expLS, covfuncs.cpp:114
-      D.p1 = D.p2 = 0;
-      for (uint64_t j = 0; j < ml; ++j) {
-        const double t = m.knotpt[o + j] / D.p0;
-        hka[o + j] = t;
-        hkb[o + j] = std::exp(t);
-        hkc[o + j] = std::exp(-t);
+    if (D.kind == OBHIP_COV_MAT25 || D.kind == OBHIP_COV_MAT25POW) {
+      if (D.kind == OBHIP_COV_MAT25) {
+        D.p0 = std::exp(a * hy[0]);  // expLS, covfuncs.cpp:114
+        D.p1 = 0;
+      } else {
+        D.p0 = std::exp(b * hy[1]);              // powv, covfuncs.cpp:198
+        D.p1 = std::exp(a * hy[0] + b * hy[1]);  // expLS, :199
       }
-    } else if (D.kind == OBHIP_COV_MAT25POW) {
-      D.p0 = std::exp(b * hy[1]);              // powv, covfuncs.cpp:198
-      D.p1 = std::exp(a * hy[0] + b * hy[1]);  // expLS, :199
-      D.p2 = 0;
+      // t_j, centred on the middle of the knots (device_common.h): u_j = t_j - c
+      double tmin = 0, tmax = 0;
       for (uint64_t j = 0; j < ml; ++j) {
-        const double t = std::pow(m.knotpt[o + j], D.p0) / D.p1;
+        const double t = D.kind == OBHIP_COV_MAT25 ? m.knotpt[o + j] / D.p0
+                                                   : std::pow(m.knotpt[o + j], D.p0) / D.p1;
         hka[o + j] = t;
-        hkb[o + j] = std::exp(t);
-        hkc[o + j] = std::exp(-t);
+        tmin = j == 0 ? t : std::min(tmin, t);
+        tmax = j == 0 ? t : std::max(tmax, t);
       }
+      D.p2 = 0.5 * (tmin + tmax);
+      bool safe = std::isfinite(D.p2);
+      for (uint64_t j = 0; j < ml; ++j) {
+        const double u = hka[o + j] - D.p2;
+        hka[o + j] = u;
+        hkb[o + j] = std::exp(u);
+        hkc[o + j] = std::exp(-u);
+        safe = safe && std::fabs(u) < 150.0;
+      }
+      // knots spread too far for the separable exponentials: one exp per knot on the device
+      if (!safe) D.kind = D.kind == OBHIP_COV_MAT25 ? 3 : 4;  // kCovMat25Direct / kCovMat25PowDirect
     } else {
       D.p0 = std::exp(a * hy[0]);  // expLSs, covfuncs.cpp:290
       D.p1 = std::exp(a * hy[1]);  // expLSc, :291
@@ -367,7 +377,7 @@ int obhip_terms_create(obhip_terms **out, const obhip_model *m,
   if (!out || !m || !terms || p == 0) return fail(OBHIP_ERR_INVALID, "terms_create: bad argument");
   if (!m->knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
   obhip_terms *t = new obhip_terms();
-  static uint64_t next_uid = 1;
+  static std::atomic<uint64_t> next_uid{1};
   t->uid = next_uid++;
   t->p = p;
   t->d = m->d;

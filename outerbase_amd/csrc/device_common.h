@@ -12,25 +12,30 @@ namespace obhip {
 // mat25 / mat25pow: h = |t(x) - t(knot_j)| with t(x) = x / expLS (mat25,
 // covfuncs.cpp:114-120) or x^powv / expLS (mat25pow, :198-206).  exp(-h) is
 // separable around the sign of t(x) - t_j, so a row needs two exponentials
-// (exp(+t(x)), exp(-t(x))) instead of one per knot; the knot factors
-// exp(+-t_j) are precomputed on the host (ModelDev::build: ka = t_j,
-// kb = exp(t_j), kc = exp(-t_j)).  |t| <= 1/exp(2*hyplb) ~ 90, far from
-// overflow.
+// (exp(+u(x)), exp(-u(x))) instead of one per knot; the knot factors exp(+-u_j) are
+// precomputed on the host (ModelDev::build).  u = t - c is centred on the middle of the
+// dimension's knots (D.p2 = c), which keeps |u_j| at half the knot range: the dimension
+// takes this path while max |u_j| < 150 (the product of the decaying pair then never
+// meets inf * 0, wherever x lies: exp(-|u(x)|) underflows to an honest 0 far outside).
+// Hyper-parameters so small that the knots themselves spread beyond that (the reference's
+// updatehyp accepts them; only the hyper-prior penalises them) switch the dimension to
+// the DIRECT kinds below: one exp(-h) per knot like the reference.
 //
 // mat25ang: h = sqrt((sin x/ls_s - sin k_j/ls_s)^2 + (cos x/ls_c - cos k_j/ls_c)^2)
 // (covfuncs.cpp:285-305): not separable, one exp per knot; ka = sin k_j/ls_s,
 // kb = cos k_j/ls_c.
+constexpr int kCovMat25Direct = 3, kCovMat25PowDirect = 4;  // DimDesc.kind on the device only
 template <int KIND>
 __device__ __forceinline__ void kernel_pre(const DimDesc &D, double xv, double &a0, double &a1,
                                            double &a2) {
-  if (KIND == OBHIP_COV_MAT25) {
-    a0 = xv / D.p0;
-    a1 = exp(a0);
-    a2 = exp(-a0);
-  } else if (KIND == OBHIP_COV_MAT25POW) {
-    a0 = pow(xv, D.p0) / D.p1;
-    a1 = exp(a0);
-    a2 = exp(-a0);
+  if (KIND == OBHIP_COV_MAT25 || KIND == kCovMat25Direct) {
+    a0 = xv / D.p0 - D.p2;
+    a1 = KIND == OBHIP_COV_MAT25 ? exp(a0) : 0.0;
+    a2 = KIND == OBHIP_COV_MAT25 ? exp(-a0) : 0.0;
+  } else if (KIND == OBHIP_COV_MAT25POW || KIND == kCovMat25PowDirect) {
+    a0 = pow(xv, D.p0) / D.p1 - D.p2;
+    a1 = KIND == OBHIP_COV_MAT25POW ? exp(a0) : 0.0;
+    a2 = KIND == OBHIP_COV_MAT25POW ? exp(-a0) : 0.0;
   } else {
     a0 = sin(xv) / D.p0;
     a1 = cos(xv) / D.p1;
@@ -45,6 +50,9 @@ __device__ __forceinline__ double kernel_value(double ka, double kb, double kc, 
   if (KIND == OBHIP_COV_MAT25ANG) {
     const double hs = a0 - ka, hc = a1 - kb;
     h = sqrt(hs * hs + hc * hc);
+    eh = exp(-h);
+  } else if (KIND == kCovMat25Direct || KIND == kCovMat25PowDirect) {
+    h = fabs(a0 - ka);
     eh = exp(-h);
   } else {
     const double dlt = a0 - ka;
@@ -135,6 +143,9 @@ __device__ __forceinline__ double build_dim_any(const DimDesc &D, const double *
   if (D.kind == OBHIP_COV_MAT25) return build_dim<OBHIP_COV_MAT25>(D, ka, kb, kc, rot, xv, store);
   if (D.kind == OBHIP_COV_MAT25POW)
     return build_dim<OBHIP_COV_MAT25POW>(D, ka, kb, kc, rot, xv, store);
+  if (D.kind == kCovMat25Direct) return build_dim<kCovMat25Direct>(D, ka, kb, kc, rot, xv, store);
+  if (D.kind == kCovMat25PowDirect)
+    return build_dim<kCovMat25PowDirect>(D, ka, kb, kc, rot, xv, store);
   return build_dim<OBHIP_COV_MAT25ANG>(D, ka, kb, kc, rot, xv, store);
 }
 

@@ -44,13 +44,7 @@ k_build_basis(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
     // padded rows evaluate at the first knot-free point of the domain; their
     // scale is forced to zero below so they never contribute.
     const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
-    double cl;
-    if (D.kind == OBHIP_COV_MAT25)
-      cl = build_dim<OBHIP_COV_MAT25>(D, ka, kb, kc, rot, xv, StoreGlobal{tile_out});
-    else if (D.kind == OBHIP_COV_MAT25POW)
-      cl = build_dim<OBHIP_COV_MAT25POW>(D, ka, kb, kc, rot, xv, StoreGlobal{tile_out});
-    else
-      cl = build_dim<OBHIP_COV_MAT25ANG>(D, ka, kb, kc, rot, xv, StoreGlobal{tile_out});
+    const double cl = build_dim_any(D, ka, kb, kc, rot, xv, StoreGlobal{tile_out});
     sc *= cl;  // modandbase.cpp:573
   }
   part[wave][lane] = sc;
@@ -90,6 +84,10 @@ k_getbase(DimDesc D, const double *__restrict__ ka, const double *__restrict__ k
     getbase_dim<OBHIP_COV_MAT25>(D, ka, kb, kc, rot, xv, n, row, out);
   else if (D.kind == OBHIP_COV_MAT25POW)
     getbase_dim<OBHIP_COV_MAT25POW>(D, ka, kb, kc, rot, xv, n, row, out);
+  else if (D.kind == kCovMat25Direct)
+    getbase_dim<kCovMat25Direct>(D, ka, kb, kc, rot, xv, n, row, out);
+  else if (D.kind == kCovMat25PowDirect)
+    getbase_dim<kCovMat25PowDirect>(D, ka, kb, kc, rot, xv, n, row, out);
   else
     getbase_dim<OBHIP_COV_MAT25ANG>(D, ka, kb, kc, rot, xv, n, row, out);
 }

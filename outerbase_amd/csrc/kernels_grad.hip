@@ -62,8 +62,9 @@ __device__ __forceinline__ void kernel_value_grad(const DimDesc &D, double ka, d
     const double h2 = h * (1.0 + ah) * e;
     g0 = a / 3 * (h * h2);
     g1 = 0.0;
-    if (KIND == OBHIP_COV_MAT25POW)
-      g1 = (lx * a0 - kd) * (-(b * D.p0 / 3) * h2) + b / 3 * (h * h2);  // D.p0 = powv
+    if (KIND == OBHIP_COV_MAT25POW || KIND == kCovMat25PowDirect)
+      // D.p0 = powv; a0 and ka are centred on D.p2 (device_common.h), t(x) itself is a0 + D.p2
+      g1 = (lx * (a0 + D.p2) - kd) * (-(b * D.p0 / 3) * h2) + b / 3 * (h * h2);
   }
 }
 
@@ -79,7 +80,7 @@ __device__ __forceinline__ double build_dim_grad(const DimDesc &D, const GradHyp
                                                  double *__restrict__ tile_out) {
   double a0, a1, a2;
   kernel_pre<KIND>(D, xv, a0, a1, a2);
-  const double lx = KIND == OBHIP_COV_MAT25POW ? log(xv) : 0.0;
+  const double lx = (KIND == OBHIP_COV_MAT25POW || KIND == kCovMat25PowDirect) ? log(xv) : 0.0;
   double cl = 1.0, g00 = 0.0, g10 = 0.0;  // level-0 gradient columns of the two hyper-parameters
   for (int c0 = 0; c0 < D.ncolp; c0 += 8) {
     double r[8], t0[8], t1[8];
@@ -98,7 +99,7 @@ __device__ __forceinline__ double build_dim_grad(const DimDesc &D, const GradHyp
         const double rc = rp[o + c];
         r[c] = fma(kv, rc, r[c]);
         t0[c] = fma(d0, rc, fma(kv, g0p[o + c], t0[c]));
-        if (KIND != OBHIP_COV_MAT25) t1[c] = fma(d1, rc, fma(kv, g1p[o + c], t1[c]));
+        if (KIND != OBHIP_COV_MAT25 && KIND != kCovMat25Direct) t1[c] = fma(d1, rc, fma(kv, g1p[o + c], t1[c]));
       }
     }
     if (c0 == 0) {
@@ -112,11 +113,11 @@ __device__ __forceinline__ double build_dim_grad(const DimDesc &D, const GradHyp
       if (col < D.ncol) {
         const double bv = r[c] / cl, ge0 = t0[c] / cl, ge1 = t1[c] / cl;
         tile_out[(size_t)(hy[0].gecol + col) * kTileRows] = ge0;
-        if (KIND != OBHIP_COV_MAT25) tile_out[(size_t)(hy[1].gecol + col) * kTileRows] = ge1;
+        if (KIND != OBHIP_COV_MAT25 && KIND != kCovMat25Direct) tile_out[(size_t)(hy[1].gecol + col) * kTileRows] = ge1;
         if (col >= 1) {
           tile_out[(size_t)(D.ccol0 + col - 1) * kTileRows] = bv;
           tile_out[(size_t)(hy[0].dcol + col - 1) * kTileRows] = fma(-bv, g00, ge0);
-          if (KIND != OBHIP_COV_MAT25)
+          if (KIND != OBHIP_COV_MAT25 && KIND != kCovMat25Direct)
             tile_out[(size_t)(hy[1].dcol + col - 1) * kTileRows] = fma(-bv, g10, ge1);
         }
       }
@@ -146,10 +147,11 @@ k_build_basis_grad(const DimDesc *__restrict__ dims, const GradHyp *__restrict__
     const int nh = hypst[l + 1] - hypst[l];
     const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
     double cl;
-    if (D.kind == OBHIP_COV_MAT25)
-      cl = build_dim_grad<OBHIP_COV_MAT25>(D, hy, nh, ka, kb, kd, rot, rotg, xv, tile_out);
-    else if (D.kind == OBHIP_COV_MAT25POW)
-      cl = build_dim_grad<OBHIP_COV_MAT25POW>(D, hy, nh, ka, kb, kd, rot, rotg, xv, tile_out);
+    // (the gradient kernel takes one exp per knot anyway: the DIRECT kinds are the plain ones)
+    if (D.kind == OBHIP_COV_MAT25 || D.kind == kCovMat25Direct)
+      cl = build_dim_grad<kCovMat25Direct>(D, hy, nh, ka, kb, kd, rot, rotg, xv, tile_out);
+    else if (D.kind == OBHIP_COV_MAT25POW || D.kind == kCovMat25PowDirect)
+      cl = build_dim_grad<kCovMat25PowDirect>(D, hy, nh, ka, kb, kd, rot, rotg, xv, tile_out);
     else
       cl = build_dim_grad<OBHIP_COV_MAT25ANG>(D, hy, nh, ka, kb, kd, rot, rotg, xv, tile_out);
     sc *= cl;
@@ -197,7 +199,7 @@ int ensure_gradbasis(obhip_basis &b) {
         for (int cc = 0; cc < D.ncol; ++cc)
           hrotg[G.rotgoff + j * D.ncolp + cc] = m.rotmat_gradhyp[(m.gest[h] + cc) * m.mmax + j];
     }
-    if (D.kind == OBHIP_COV_MAT25POW)
+    if (m.kinds[l] == OBHIP_COV_MAT25POW)
       for (uint64_t j = 0; j < ml; ++j) {
         const double t = std::pow(m.knotpt[o + j], D.p0) / D.p1;
         hkd[o + j] = std::log(m.knotpt[o + j]) * t;  // covfuncs.cpp:234

@@ -28,6 +28,8 @@
 // (acc[t], lane = row mod 64) across all its row tiles and reduces across lanes
 // once at the end; the next tile's global loads are in flight while the current tile
 // is consumed.
+#include <atomic>
+
 #include "obhip_internal.h"
 #include "device_common.h"
 
@@ -812,13 +814,15 @@ int launch_getmat(const obhip_basis &b, obhip_terms &t, double *d_out, uint64_t 
 }
 
 int device_cus(int device) {
-  static int ncu = 0;
-  if (!ncu) {
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-        ncu <= 0)
-      ncu = 256;
+  static std::atomic<int> ncu[64];  // per device
+  const int slot = device >= 0 && device < 64 ? device : 0;
+  int v = ncu[slot].load();
+  if (!v) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0)
+      v = 256;
+    ncu[slot].store(v);
   }
-  return ncu;
+  return v;
 }
 
 template <int W2, bool SQ, int NG>

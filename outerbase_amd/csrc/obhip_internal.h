@@ -48,7 +48,8 @@ struct ProfScope {
 // OBHIP_POOL_MB (default 8192) of cached memory; larger blocks and the overflow go back to
 // the driver, and a failed hipMalloc empties the pool and retries.
 int pool_alloc(void **p, size_t bytes);
-void pool_free(void *p, size_t bytes);
+// stream: the one the block was allocated for (the tag under which it may be handed out again)
+void pool_free(void *p, size_t bytes, hipStream_t stream);
 void pool_trim();
 
 // ---- device buffer ----------------------------------------------------------
@@ -56,12 +57,18 @@ template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
+  hipStream_t s = nullptr;  // stream current at allocation
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) pool_free(p, n * sizeof(T));
+    if (p) {
+      // used on another stream since (obhip_set_stream between allocation and release): let
+      // that work finish, the block goes back under the stream it was allocated for
+      if (cur_stream() != s) (void)hipStreamSynchronize(cur_stream());
+      pool_free(p, n * sizeof(T), s);
+    }
     p = nullptr;
     n = 0;
   }
@@ -72,6 +79,7 @@ struct DevBuf {
     int rc = pool_alloc((void **)&p, count * sizeof(T));
     if (rc) return rc;
     n = count;
+    s = cur_stream();
     return 0;
   }
   int upload(const T *src, size_t count) {

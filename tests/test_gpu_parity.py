@@ -58,6 +58,55 @@ def test_getbase_all_kernels(mixed_pair):
         assert np.all(np.abs(got - want) <= 1e-13 * bound + 1e-300), "dim %d" % k
 
 
+@pytest.mark.parametrize("scale_hyp", ["lower bound", -3.3, -3.5])
+def test_extreme_length_scales_and_inputs_outside_the_domain(scale_hyp):
+    """mat25 / mat25pow evaluate exp(-|t(x) - t_j|) as a product of per-row and per-knot
+    exponentials (device_common.h).  At the hyper-parameter lower bound, below it (updatehyp
+    accepts that, only the hyper-prior penalises it) and for inputs outside [0, 1] the factors
+    must not overflow into inf * 0: centred exponents up to a knot spread of 300, one exp per
+    knot beyond.  The oracle evaluates exp(-h) directly like the reference."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25", "mat25pow", "mat25"]
+    knots = knots_for(kinds, 20)
+    lb = [O.COV_INFO[k]["hyplb"] for k in kinds]
+    hyp = np.concatenate([np.asarray(O.COV_INFO[k]["hyp0"], dtype=float) for k in kinds])
+    sc = lb[0][0] if scale_hyp == "lower bound" else scale_hyp
+    hyp[0] = sc                      # mat25 scale
+    hyp[1] = sc                      # mat25pow scale
+    om_o, om_d = make_pair(kinds, knots, hyp=hyp)
+    rng = np.random.default_rng(12)
+    x = sample_x(rng, 200, kinds)
+    if scale_hyp != -3.5:
+        # outside the kernel's domain (at -3.5 every kernel value of such a row underflows to
+        # zero and the reference's own R[:, 1:] / R[:, 0] is 0 / 0, modandbase.cpp:297)
+        x[:5, 0] = [-0.02, 1.03, 0.0, 1.0, 1.3]
+    x[:3, 2] = [-0.5, 2.0, 1.0001]
+    bo = O.OuterBase(om_o, x)
+    bd = ob.outerbase(om_d, x)
+    for k in (1, 2, 3):
+        got, want = bd.getbase(k), bo.getbase(k)
+        assert np.all(np.isfinite(got))
+        o, m = om_o.knotptst[k - 1], om_o.knotptst[k] - om_o.knotptst[k - 1]
+        K = O.cov(kinds[k - 1], x[:, k - 1], om_o.knots_of(k - 1), om_o.hyp_of(k - 1))
+        bound = np.abs(K) @ np.abs(om_o.rotmat[:m, o:o + m])
+        assert np.all(np.abs(got - want) <= 1e-12 * bound + 1e-290), "dim %d" % k
+    terms = om_o.selectterms(40)
+    a = rng.standard_normal(40)
+    B = O.ob_getmat(bo, terms)
+    assert np.all(np.isfinite(bd.matmul(terms, a)))
+    assert relerr(bd.matmul(terms, a), B @ a) < 1e-9
+    # the fused predictor evaluates the same kernels in LDS
+    lik = ob.loglik_gauss(om_d, terms, rng.standard_normal(200), x)
+    lik.update(a)
+    pred = ob.predictor(lik)
+    pred.update(x)
+    assert relerr(pred.mean(), B @ a) < 1e-9
+    # and the gradient basis (its kernel takes one exp per knot) stays finite and consistent
+    g = bd.matmul_gradhyp(terms, a)
+    assert np.all(np.isfinite(g))
+
+
 @pytest.mark.parametrize("hyp_shift", [0.0, 0.3])
 def test_getmat_matmul_tmatmul(hyp_shift):
     import ob_oracle as O
@@ -968,7 +1017,10 @@ def test_term_per_lane_variants(max_nnz, p, maxlev):
         # high levels lose digits in cov x rotmat on both sides (see test_gram_backends), so
         # the oracle pins the result loosely and the device's own design matrix (getmat, the
         # lane = row kernel) pins the contraction tightly
-        tol = 1e-6 if maxlev >= 5 else 1e-9
+        # (levels 12-14 of 16 knots lie beyond `maxlevel`, where lambda_j / lambda_0 < 1e-11 and
+        # the eigenpairs are rounding noise amplified by rotmat ~ 1 / lambda: kernel variants
+        # are what this case is for, not parity)
+        tol = 1e-5 if maxlev >= 12 else (1e-6 if maxlev >= 5 else 1e-9)
         Bd = bd.getmat(terms)
         got, gotsq = bd.tmatmul(terms, v), bd.sqtmm(terms, v)
         assert relerr(got, B.T @ v) < tol
