@@ -22,11 +22,22 @@ def borehole8d(x):
 
 
 import outerbase_amd as ob
+from outerbase_amd import fitting
+_calls = {"n": 0, "t": 0.0}
+_orig = fitting._lpdfwrapper
+def _counted(*a, **k):
+    t0 = time.time()
+    r = _orig(*a, **k)
+    _calls["n"] += 1
+    _calls["t"] += time.time() - t0
+    return r
+fitting._lpdfwrapper = _counted
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 numb = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 rng = np.random.default_rng(42)
 x = rng.random((n, 8)); y = borehole8d(x)
 t0=time.time(); m = ob.obfit(x, y, numb=numb, seed=1, verbose=1); t1=time.time()
 xt = rng.random((200, 8)); pred = ob.obpred(m, xt); yt = borehole8d(xt)
+print("function evaluations (updatehyp + updateom + updatepara + optcg + gradients): %d, %.1f ms each, %.2f s of the fit" % (_calls["n"], 1e3 * _calls["t"] / max(1, _calls["n"]), _calls["t"]))
 print("fit s", t1-t0, "rmse/sd", math.sqrt(np.mean((pred["mean"]-yt)**2))/np.std(yt), "hyp", ob.gethyp(m["om"]), "para", ob.getpara(m["logpdf"]))
 z=(pred["mean"]-yt)/np.sqrt(pred["var"]); print("rms z", np.sqrt(np.mean(z**2)))
