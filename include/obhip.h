@@ -339,6 +339,12 @@ int obhip_comm_allreduce_dev(obhip_comm *c, double *d_buf, uint64_t count);
  * (device, 3 doubles).  comm may be NULL (one rank: only the standardisation happens and the
  * triangle part of the buffer is never touched, so d_buf may point count - tail doubles
  * before a tail-sized allocation). */
+/* Exact sample quantiles (R's quantile(), type 7) of every column of a row-sharded x: what
+ * obfit's knot placement needs of the data (.genknotlist, R/fitting.R:177-185).  d_x: this
+ * rank's n x d rows, column-major (device); probs: q values in [0, 1] (host); out: d x q,
+ * out[l * q + j] (host), identical on every rank.  comm may be NULL (one rank). */
+int obhip_quantiles_dev(obhip_comm *comm, const double *d_x, uint64_t n, uint64_t d,
+                        const double *probs, uint64_t q, double *out);
 int obhip_normal_eq_count(uint64_t p, int nranks, uint64_t *count);
 int obhip_normal_eq_exchange_dev(obhip_comm *comm, uint64_t p, uint64_t n_local, double *d_G,
                                  double *d_g, const double *d_b1, const double *d_sum2,
@@ -437,6 +443,14 @@ int obhip_lpdf_terms(const obhip_lpdf *l, uint64_t *terms_out);
 /* the outerbase a likelihood owns (member `ob`, fit.h:185,237,273) and the device form of
  * its terms; borrowed handles, valid until the next updateterms / destroy */
 int obhip_lpdf_basis(obhip_lpdf *l, obhip_basis **b, obhip_terms **t);
+/* Rows sharded over the ranks of comm (no reference counterpart): the
+ * likelihood (loglik_gauss | loglik_std; given an lpdfvec, its likelihood) holds this
+ * rank's rows, and every sum over rows -- val, grad, gradhyp, gradpara, hessmult,
+ * diaghess*, hess, optcg, optnewton -- is summed over the ranks, so that all ranks see the
+ * numbers of the whole data set; para0 = log(0.01 var(y)) takes var(y) over all rows.
+ * Collective: every rank calls it, and afterwards the same methods in the same order.
+ * loglik_gda refuses (obfit runs it on a subsample every rank holds); NULL detaches. */
+int obhip_lpdf_set_comm(obhip_lpdf *l, obhip_comm *comm);
 /* lpdf$setnthreads (interfaceR.cpp:710): accepted and ignored on the device */
 int obhip_lpdf_setnthreads(obhip_lpdf *l, int nthreads);
 /* lpdf$update(coeff): loglik_gauss.cpp:110-130, loglik_std.cpp:100-120, loglik_gda.cpp:117-153,

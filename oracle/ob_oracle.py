@@ -900,9 +900,24 @@ def predict_var_gauss(om, terms, diagH, sigma, xnew):
 # R harness pieces                                        R/fitting.R
 # ----------------------------------------------------------------------------
 def quantile7(x, probs):
-    """R quantile(type=7) (used by .genknotlist, R/fitting.R:177-185)."""
-    return np.quantile(np.asarray(x, dtype=np.float64), probs,
-                       method="linear")
+    """R's stats::quantile.default, type = 7 (what .genknotlist calls, R/fitting.R:177-185;
+    base R, not part of the reference checkout): index = (n - 1) p, lo = floor(index + fuzz)
+    with fuzz = 4 eps, h = index - lo (set to 0 below fuzz), (1 - h) x[lo] + h x[lo + 1] on the
+    sorted sample.  Agrees with numpy's method="linear" to the last bit or two."""
+    xs = np.sort(np.asarray(x, dtype=np.float64))
+    n = len(xs)
+    probs = np.asarray(probs, dtype=np.float64)
+    fuzz = 4 * np.finfo(np.float64).eps
+    nppm = (n - 1) * probs
+    lo = np.floor(nppm + fuzz).astype(np.int64)
+    h = nppm - lo
+    h[np.abs(h) < fuzz] = 0.0
+    hi = np.minimum(lo + 1, n - 1)
+    lo = np.minimum(lo, n - 1)
+    out = xs[lo].copy()
+    nz = h != 0
+    out[nz] = (1 - h[nz]) * xs[lo[nz]] + h[nz] * xs[hi[nz]]
+    return out
 
 
 def genknotlist(bassize, x):

@@ -17,6 +17,7 @@
 //         stages through a pinned buffer.
 #include <dlfcn.h>
 
+#include <cmath>
 #include <cstring>
 
 #include "obhip_internal.h"
@@ -293,3 +294,97 @@ int obhip_normal_eq_exchange_dev(obhip_comm *comm, uint64_t p, uint64_t n_local,
 }
 
 }  // extern "C"
+
+// ---- exact sample quantiles of row-sharded columns -----------------------------------------
+// obfit places its knots at quantiles of every input column (.genknotlist, R/fitting.R:177-185:
+// quantile(x, probs), R's default type 7).  With the rows sharded over ranks no rank can sort
+// the column; the order statistics are found by bisection on the (order-preserving) bit
+// pattern instead: 64 rounds of "how many elements, over all ranks, are <= this midpoint",
+// for all columns and all wanted order statistics at once.  Exact: the result is the element
+// a sort of the whole column would put at that position, and the interpolation is R's.
+namespace obhip {
+int quantile_max_targets();
+int launch_count_le(const double *d_x, uint64_t n, uint64_t d, const uint64_t *d_mids, int T,
+                    unsigned long long *d_counts);
+int launch_u64_to_f64(const unsigned long long *d_in, uint64_t n, double *d_out);
+}  // namespace obhip
+
+namespace {
+
+double key_to_double(uint64_t k) {
+  const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  double v;
+  std::memcpy(&v, &b, sizeof v);
+  return v;
+}
+
+}  // namespace
+
+extern "C" int obhip_quantiles_dev(obhip_comm *comm, const double *d_x, uint64_t n, uint64_t d,
+                                   const double *probs, uint64_t q, double *out) {
+  if (!d_x || !probs || !out || d == 0 || q == 0) return fail(OBHIP_ERR_INVALID, "quantiles_dev: bad argument");
+  OB_TRY(require_device());
+  const int T = (int)(2 * q);
+  if (T > quantile_max_targets()) return fail(OBHIP_ERR_INVALID, "quantiles_dev: too many quantiles");
+  hipStream_t st = cur_stream();
+  // rows of all ranks
+  double ntot = (double)n;
+  DevBuf<double> dsum;
+  OB_TRY(dsum.alloc(d * T));
+  if (comm) {
+    OB_HIP(hipMemcpyAsync(dsum.p, &ntot, sizeof(double), hipMemcpyHostToDevice, st));
+    OB_HIP(hipStreamSynchronize(st));
+    OB_TRY(comm_allreduce(comm, dsum.p, 1));
+    OB_HIP(hipMemcpyAsync(&ntot, dsum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    OB_HIP(hipStreamSynchronize(st));
+  }
+  const uint64_t N = (uint64_t)ntot;
+  if (N == 0) return fail(OBHIP_ERR_INVALID, "quantiles_dev: no rows");
+  // type 7 as stats::quantile.default computes it: index = (N - 1) p, lo = floor(index + fuzz),
+  // h = index - lo (0 below fuzz = 4 eps), Q = (1 - h) x_(lo) + h x_(lo + 1); targets 2 j, 2 j + 1
+  std::vector<uint64_t> want(T);
+  std::vector<double> frac(q);
+  const double fuzz = 4.0 * 2.220446049250313e-16;
+  for (uint64_t j = 0; j < q; ++j) {
+    if (!(probs[j] >= 0.0 && probs[j] <= 1.0)) return fail(OBHIP_ERR_INVALID, "quantiles_dev: probs outside [0, 1]");
+    const double nppm = (double)(N - 1) * probs[j];
+    const uint64_t lo = std::min<uint64_t>((uint64_t)std::floor(nppm + fuzz), N - 1);
+    double h = nppm - (double)lo;
+    if (std::fabs(h) < fuzz) h = 0.0;
+    want[2 * j] = lo;
+    want[2 * j + 1] = std::min<uint64_t>(lo + 1, N - 1);
+    frac[j] = h;
+  }
+  std::vector<uint64_t> lo(d * T, 0), hi(d * T, ~0ull), mid(d * T);
+  std::vector<double> cnt(d * T);
+  DevBuf<uint64_t> dmid;
+  DevBuf<unsigned long long> dcnt;
+  OB_TRY(dmid.alloc(d * T));
+  OB_TRY(dcnt.alloc(d * T));
+  for (int it = 0; it < 64; ++it) {
+    for (uint64_t e = 0; e < d * T; ++e) mid[e] = lo[e] + (hi[e] - lo[e]) / 2;
+    OB_HIP(hipMemcpyAsync(dmid.p, mid.data(), d * T * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    OB_HIP(hipMemsetAsync(dcnt.p, 0, d * T * sizeof(unsigned long long), st));
+    OB_TRY(launch_count_le(d_x, n, d, dmid.p, T, dcnt.p));
+    // the counts travel as doubles (exact below 2^53) so that the one transport sums them
+    OB_TRY(launch_u64_to_f64(dcnt.p, d * T, dsum.p));
+    if (comm) OB_TRY(comm_allreduce(comm, dsum.p, d * T));
+    OB_HIP(hipMemcpyAsync(cnt.data(), dsum.p, d * T * sizeof(double), hipMemcpyDeviceToHost, st));
+    OB_HIP(hipStreamSynchronize(st));
+    bool open = false;
+    for (uint64_t e = 0; e < d * T; ++e) {
+      if (lo[e] == hi[e]) continue;
+      // smallest key with count(<= key) >= k + 1 is the k-th order statistic (0-based)
+      if ((uint64_t)cnt[e] >= want[e % T] + 1) hi[e] = mid[e];
+      else lo[e] = mid[e] + 1;
+      open = open || lo[e] != hi[e];
+    }
+    if (!open) break;
+  }
+  for (uint64_t l = 0; l < d; ++l)
+    for (uint64_t j = 0; j < q; ++j) {
+      const double a = key_to_double(lo[l * T + 2 * j]), b = key_to_double(lo[l * T + 2 * j + 1]);
+      out[l * q + j] = frac[j] == 0.0 ? a : (1.0 - frac[j]) * a + frac[j] * b;
+    }
+  return 0;
+}

@@ -254,3 +254,80 @@ int launch_fill(double *d_v, uint64_t n, double c) {
 }
 
 }  // namespace obhip
+
+// ---- exact order statistics of row-sharded columns (sharded obfit's quantile knots) -------
+// Keys: doubles mapped to uint64 so that unsigned order = numeric order.  One bisection step
+// of the selection counts, for every (column, target) pair, the local elements whose key is
+// <= the target's midpoint: a wave takes 64 rows of one column, a ballot per target gives
+// the count of the wave, one lane accumulates it in LDS.  Integer counts: order-independent.
+namespace obhip {
+
+namespace {
+
+__device__ __forceinline__ uint64_t order_key(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+constexpr int kQMaxT = 512;  // targets per column
+
+__global__ void __launch_bounds__(256)
+k_count_le(const double *__restrict__ x, uint64_t n, const uint64_t *__restrict__ mids, int T,
+           unsigned long long *__restrict__ counts) {
+  __shared__ uint64_t sm[kQMaxT];
+  __shared__ unsigned int cnt[4][kQMaxT];
+  const int l = blockIdx.y, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int t = threadIdx.x; t < T; t += 256) {
+    sm[t] = mids[(size_t)l * T + t];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cnt[w][t] = 0;
+  }
+  __syncthreads();
+  const double *col = x + (uint64_t)l * n;
+  for (uint64_t r0 = ((uint64_t)blockIdx.x * 4 + wave) * 64; r0 < n; r0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t r = r0 + lane;
+    const bool live = r < n;
+    const uint64_t key = live ? order_key(col[r]) : ~0ull;
+    for (int t = 0; t < T; ++t) {
+      const unsigned long long m = __ballot(live && key <= sm[t]);
+      if (lane == 0) cnt[wave][t] += (unsigned int)__popcll(m);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const unsigned long long c = (unsigned long long)cnt[0][t] + cnt[1][t] + cnt[2][t] + cnt[3][t];
+    if (c) atomicAdd(&counts[(size_t)l * T + t], c);
+  }
+}
+
+}  // namespace
+
+__global__ void k_u64_to_f64(const unsigned long long *__restrict__ in, uint64_t n, double *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (double)in[i];
+}
+
+int launch_u64_to_f64(const unsigned long long *d_in, uint64_t n, double *d_out) {
+  hipLaunchKernelGGL(k_u64_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cur_stream(), d_in, n,
+                     d_out);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+int quantile_max_targets() { return kQMaxT; }
+
+// counts[l * T + t] += #{ i : key(x[i, l]) <= mids[l * T + t] } (counts zeroed by the caller)
+int launch_count_le(const double *d_x, uint64_t n, uint64_t d, const uint64_t *d_mids, int T,
+                    unsigned long long *d_counts) {
+  if (T > kQMaxT) return fail(OBHIP_ERR_INVALID, "too many quantiles per column");
+  if (n == 0) return 0;
+  // each wave's counter is 32 bits: at most 2^32 rows per block
+  const unsigned gx = (unsigned)std::min<uint64_t>(1024, (n + 255) / 256);
+  hipLaunchKernelGGL(k_count_le, dim3(gx, (unsigned)d), dim3(256), 0, cur_stream(), d_x, n, d_mids, T,
+                     d_counts);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace obhip

@@ -329,6 +329,11 @@ struct Loglik : obhip_lpdf {
   obhip_basis *ob = nullptr;  // owned (class member `outerbase ob` of the reference)
   obhip_terms *t = nullptr;   // owned device form of `terms`
   uint64_t n = 0;
+  // rows sharded over ranks (obhip_lpdf_set_comm; no reference counterpart): every sum over
+  // the rows -- value, gradients, Hessian products, diagonals -- is summed over the ranks
+  obhip_comm *comm = nullptr;
+  double n_total = 0;  // rows of all ranks
+  DevBuf<double> xch;  // staging of the host-side results that are summed
   DevBuf<double> y, yhat, r, tmp, ones, dcoeff, dpv;
   DevBuf<double> yhatge;      // n x nhyp, kept for gradhyp
   DevBuf<double> red;         // scratch of the two-stage sums
@@ -375,8 +380,32 @@ struct Loglik : obhip_lpdf {
     OB_TRY(launch_fill(ones.p, n, 1.0));
     OB_TRY(launch_fill(yhat.p, n, 0.0));
     OB_TRY(red.alloc(64 + kSumBlocks * 8));
+    n_total = (double)n;
     return 0;
   }
+  // in-place sum of host values over the ranks (no-op without a communicator)
+  int sum_ranks(double *v, uint64_t count) {
+    if (!comm || count == 0) return 0;
+    OB_TRY(xch.alloc(std::max<uint64_t>(count, xch.n)));
+    OB_HIP(hipMemcpyAsync(xch.p, v, count * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+    OB_HIP(hipStreamSynchronize(cur_stream()));
+    OB_TRY(comm_allreduce(comm, xch.p, count));
+    return d2h(v, xch.p, count * sizeof(double));
+  }
+  virtual int set_comm(obhip_comm *c) {
+    comm = c;
+    double v[3];
+    // sum y, sum y^2, n over all rows: para0 = log(0.01 var(y)) must be the same on every rank
+    OB_TRY(launch_sum_sumsq(y.p, n, red.p, red.p + 64));
+    OB_TRY(d2h(v, red.p, 2 * sizeof(double)));
+    v[2] = (double)n;
+    OB_TRY(sum_ranks(v, 3));
+    n_total = v[2];
+    const double cent = v[0] / v[2];
+    yvar_total = std::max(v[1] - v[2] * cent * cent, 0.0) / (v[2] - 1.0);
+    return 0;
+  }
+  double yvar_total = 0;
   int updateom() override { return obhip_basis_rebuild(ob); }
   int updateterms(const uint64_t *tt, uint64_t p) override {
     // new terms may use other levels: the basis is rebuilt with their caps (the reference
@@ -404,10 +433,12 @@ struct Loglik : obhip_lpdf {
     OB_TRY(dpv.alloc(p));
     OB_TRY(launch_tmm(*ob, *t, r.p, dpv.p, false));
     grad.resize(p);
+    if (comm) OB_TRY(comm_allreduce(comm, dpv.p, p));
     OB_TRY(d2h(grad.data(), dpv.p, p * sizeof(double)));
     if (compute_gradhyp) {
       gradhyp.assign(nhyp(), 0.0);
       OB_TRY(grad_wdot_dev(yhatge.p, r.p, n, nhyp(), gradhyp.data()));
+      OB_TRY(sum_ranks(gradhyp.data(), nhyp()));
     }
     return 0;
   }
@@ -415,6 +446,7 @@ struct Loglik : obhip_lpdf {
   int tmm_host(const double *d_v, bool squared, double *out) {
     OB_TRY(dpv.alloc(nterms));
     OB_TRY(launch_tmm(*ob, *t, d_v, dpv.p, squared));
+    if (comm) OB_TRY(comm_allreduce(comm, dpv.p, nterms));
     return d2h(out, dpv.p, nterms * sizeof(double));
   }
 };
@@ -439,6 +471,13 @@ struct LoglikGauss : Loglik {
     para = {pp[0]};
     return 0;
   }
+  int set_comm(obhip_comm *c) override {
+    const bool at_default = para == para0;
+    OB_TRY(Loglik::set_comm(c));
+    para0 = {std::log(0.01 * yvar_total)};  // var(y) over ALL rows (loglik_gauss.cpp:48)
+    if (at_default) para = para0;
+    return 0;
+  }
   int update(const double *c) override {  // loglik_gauss.cpp:110-130, loglik_std.cpp:100-120
     OB_TRY(forward(c));
     const double e2 = std::exp(-2.0 * para[0]);
@@ -446,10 +485,11 @@ struct LoglikGauss : Loglik {
     double ss[2];
     OB_TRY(launch_sum_sumsq(tmp.p, n, red.p, red.p + 64));
     OB_TRY(d2h(ss, red.p, 2 * sizeof(double)));
-    if (compute_val) val = -0.5 * e2 * ss[1] - (double)n * para[0];
+    OB_TRY(sum_ranks(ss, 2));
+    if (compute_val) val = -0.5 * e2 * ss[1] - n_total * para[0];
     if (compute_grad) {
       OB_TRY(backward());
-      if (compute_gradpara) gradpara = {e2 * ss[1] - (double)n};
+      if (compute_gradpara) gradpara = {e2 * ss[1] - n_total};
     }
     return 0;
   }
@@ -467,6 +507,7 @@ struct LoglikGauss : Loglik {
   }
   int diaghessgradhyp(double *out) override {  // loglik_gauss.cpp:158-161
     OB_TRY(grad_tmm_host(*ob, *t, true, ones.p, out));
+    OB_TRY(sum_ranks(out, nterms * nhyp()));
     const double e2 = std::exp(-2.0 * para[0]);
     for (uint64_t k = 0; k < nterms * nhyp(); ++k) out[k] *= e2;
     return 0;
@@ -483,11 +524,13 @@ struct LoglikGauss : Loglik {
     const double e2 = std::exp(-2.0 * para[0]);
     if (!add) {
       OB_TRY(launch_gram(*ob, *t, d_H));
+      if (comm) OB_TRY(comm_allreduce(comm, d_H, p * p));
       return launch_scale(d_H, p * p, e2);
     }
     DevBuf<double> G;
     OB_TRY(G.alloc(p * p));
     OB_TRY(launch_gram(*ob, *t, G.p));
+    if (comm) OB_TRY(comm_allreduce(comm, G.p, p * p));
     const double *g = G.p;
     OB_TRY(vmap(p * p, [=] __device__(uint64_t e) { d_H[e] += e2 * g[e]; }));
     OB_HIP(hipStreamSynchronize(cur_stream()));
@@ -514,6 +557,12 @@ struct LoglikGda : Loglik {
     OB_TRY(rterms.alloc(n));
     OB_TRY(r2s.alloc(n));
     OB_TRY(obssd_gradpara.alloc(2 * n));
+    return 0;
+  }
+  int set_comm(obhip_comm *c) override {
+    if (c) return fail(OBHIP_ERR_INVALID, "loglik_gda is not sharded: obfit runs it on a row subsample "
+                                          "that every rank holds in full");
+    comm = nullptr;
     return 0;
   }
   int updateom() override {  // :84-87
@@ -889,7 +938,7 @@ struct LpdfVec : obhip_lpdf {
     OB_TRY(ddiag.alloc(p));
     // (no value asked for: the update() below evaluates the fit anyway)
     OB_TRY(obhip_fit_cg_dev(lik->ob, lik->t, om, lik->y.p, lik->para[0], pr->para[0], tol, maxepch,
-                            dth.p, &cgiters, ddiag.p, nullptr, nullptr));
+                            dth.p, &cgiters, ddiag.p, nullptr, lik->comm));
     std::vector<double> c(p);
     OB_TRY(d2h(c.data(), dth.p, p * sizeof(double)));
     compute_gradhyp = compute_gradpara = true;  // fit.cpp:87-93
@@ -1176,6 +1225,18 @@ int obhip_lpdf_basis(obhip_lpdf *l, obhip_basis **b, obhip_terms **t) {
 
 // ---- methods ----------------------------------------------------------------------------------
 int obhip_lpdf_setnthreads(obhip_lpdf *l, int) { return l ? 0 : fail(OBHIP_ERR_INVALID, "null lpdf"); }
+
+int obhip_lpdf_set_comm(obhip_lpdf *l, obhip_comm *comm) {
+  if (!l) return fail(OBHIP_ERR_INVALID, "null lpdf");
+  if (l->kind == OBHIP_LPDF_VEC) {
+    Loglik *lik = static_cast<LpdfVec *>(l)->loglik();
+    if (!lik) return fail(OBHIP_ERR_INVALID, "this lpdfvec holds no likelihood");
+    static_cast<LpdfVec *>(l)->redohess = true;
+    return lik->set_comm(comm);
+  }
+  if (l->kind > OBHIP_LPDF_LOGLIK_GDA) return 0;  // the prior holds no rows
+  return static_cast<Loglik *>(l)->set_comm(comm);
+}
 
 int obhip_lpdf_update(obhip_lpdf *l, const double *coeff, uint64_t ncoeff) {
   if (!l || !coeff) return fail(OBHIP_ERR_INVALID, "lpdf_update: null argument");

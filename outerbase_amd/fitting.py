@@ -7,12 +7,14 @@ Everything data-sized runs on the GPU through libobhip (basis builds, B a, B^T a
 their hyper-parameter gradients, the PCG solves); this file only holds the scalar
 optimisation logic the reference keeps in R.
 """
+import ctypes as C
 import math
 import warnings
 
 import numpy as np
 
-from . import obmod
+from . import _lib, obmod
+from ._lib import call
 from .obmod import (gethyp, getpara, loglik_gauss, loglik_gda, logpr_gauss, lpdfvec, outermod,
                     predictor, setcovfs, setknot)
 
@@ -183,13 +185,67 @@ def _checkcov(covname, xcol):
                          "try rescaling" % (lo, hi))
 
 
-def _genknotlist(bassize, x):
-    out = []
-    for k, b in enumerate(bassize):
-        b = int(b)
-        probs = np.linspace(0, 1, b) * b / (b + 1) + 0.5 / (b + 1)
-        out.append(np.quantile(x[:, k], probs))     # R's default type 7 = numpy's "linear"
+class _DeviceCopy:
+    """x (n x d, column-major) in HBM for the calls below that take device pointers."""
+
+    def __init__(self, x):
+        xf = np.asfortranarray(x, dtype=np.float64)
+        self.n, self.d = xf.shape
+        self.ptr = C.c_void_p()
+        call("obhip_malloc", C.byref(self.ptr), max(8, xf.nbytes))
+        call("obhip_memcpy_h2d", self.ptr, xf.ctypes.data, xf.nbytes)
+
+    def close(self):
+        if self.ptr:
+            _lib.lib.obhip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
+
+
+def _quantiles(dx, probs, comm):
+    """d x q exact type-7 quantiles of the columns of x over the rows of ALL ranks
+    (obhip_quantiles_dev: bisection on counts, no rank ever sorts)."""
+    probs = np.ascontiguousarray(probs, dtype=np.float64)
+    out = np.empty((dx.d, len(probs)))
+    call("obhip_quantiles_dev", comm, dx.ptr, dx.n, dx.d, probs.ctypes.data, len(probs),
+         out.ctypes.data)
     return out
+
+
+def _sum_over_ranks(vals, comm):
+    """element-wise sum of a few host numbers over the ranks (identity without a communicator)"""
+    v = np.ascontiguousarray(vals, dtype=np.float64)
+    if comm is None:
+        return v
+    d = C.c_void_p()
+    call("obhip_malloc", C.byref(d), v.nbytes)
+    try:
+        call("obhip_memcpy_h2d", d, v.ctypes.data, v.nbytes)
+        call("obhip_comm_allreduce_dev", comm, d, len(v))
+        call("obhip_memcpy_d2h", v.ctypes.data, d, v.nbytes)
+    finally:
+        _lib.lib.obhip_free(d)
+    return v
+
+
+def _genknotlist(bassize, x, comm=None, dx=None):
+    """.genknotlist (R/fitting.R:177-185): quantile(x_k, seq(0,1,len=b)*b/(b+1)+0.5/(b+1)),
+    R's default type 7, over the rows of all ranks, evaluated on the device."""
+    own = dx is None
+    if own:
+        dx = _DeviceCopy(x)
+    try:
+        bs = [int(b) for b in bassize]
+        qs = {}
+        for b in sorted(set(bs)):
+            probs = np.linspace(0, 1, b) * b / (b + 1) + 0.5 / (b + 1)
+            qs[b] = _quantiles(dx, probs, comm)
+        return [qs[b][k].copy() for k, b in enumerate(bs)]
+    finally:
+        if own:
+            dx.close()
 
 
 def _getsteps(numb, sampsize, sigtonoiseratio=1e-3, tol=0.001):
@@ -201,15 +257,25 @@ def _getsteps(numb, sampsize, sigtonoiseratio=1e-3, tol=0.001):
 
 # ---- obfit / obpred (R/fitting.R:27-155) ---------------------------------------------------
 def obfit(x, y, numb=100, verbose=0, covnames=None, hyp=None, numberopts=2, nthreads=None,
-          seed=None):
+          seed=None, comm=None, row0=0):
     """Fit an outerbase model with hyper-parameter learning.  `seed` drives the row subsample
     of the first stage (R's sample(), R/fitting.R:81); nthreads is accepted and ignored (the
-    work runs on the GPU)."""
+    work runs on the GPU).
+
+    Row-sharded fits (no reference counterpart): every rank passes its
+    own contiguous rows x, y, its obhip_comm (driver.make_comm) and row0, the index of its
+    first row in the whole data set; all ranks pass the same seed.  y is standardised, the
+    knots are placed at quantiles and the first stage's rows are drawn over ALL rows, every
+    rank ends with the same model, and obpred predicts at whatever rows a rank holds."""
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64).reshape(-1)
-    n, d = x.shape
-    if n != len(y):
+    n_local, d = x.shape
+    if n_local != len(y):
         raise ValueError("x and y dims do not align")
+    if comm is not None and seed is None:
+        raise ValueError("a row-sharded fit needs the same seed on every rank")
+    # sums over all rows: n, sum y, then sum (y - mean)^2 (two passes like R's sd())
+    n = int(round(_sum_over_ranks([n_local], comm)[0]))
     if n < d:
         raise ValueError("dimension larger than sample size has not been tested")
     if n > 10 ** 6:
@@ -238,26 +304,49 @@ def obfit(x, y, numb=100, verbose=0, covnames=None, hyp=None, numberopts=2, nthr
             raise ValueError("nthreads must be bigger than 1")
         if math.ceil(nthreads) > 100:
             raise ValueError("nthreads should be small than 100 (for now).")
-    y_cent, y_sca = float(y.mean()), float(y.std(ddof=1))
+    y_cent = float(_sum_over_ranks([y.sum()], comm)[0]) / n
+    y_sca = math.sqrt(float(_sum_over_ranks([np.sum((y - y_cent) ** 2)], comm)[0]) / (n - 1))
     y = (y - y_cent) / y_sca
     if covnames is not None and len(covnames) != d:
         raise ValueError("cov names must be same size as columns in x")
     if covnames is None:
         covnames = [_COVS[0]] * d
+    for c in covnames:
+        if c not in _COVS:
+            raise ValueError("covariances must be from listcov()")
+    if comm is None:                                  # argument guards, as the R code makes them
+        xrange_ = np.stack([x.min(axis=0), x.max(axis=0)], axis=1)
+        dx = None
+    else:
+        dx = _DeviceCopy(x)
+        xrange_ = _quantiles(dx, [0.0, 1.0], comm)    # min and max of every column, all ranks
     for k in range(d):
-        _checkcov(covnames[k], x[:, k])
+        _checkcov(covnames[k], xrange_[k])
+    if dx is None:
+        dx = _DeviceCopy(x)
     om = outermod()
     setcovfs(om, covnames)
     if hyp is not None and len(hyp) == len(gethyp(om)):
         om.updatehyp(hyp)
-    setknot(om, _genknotlist([40] * d, x))            # 40 knot points for each dim
-    numbr = min(len(y) // 2, numb, 80 * d)
+    setknot(om, _genknotlist([40] * d, x, comm, dx))  # 40 knot points for each dim
+    numbr = min(n // 2, numb, 80 * d)
     terms = om.selectterms(numbr)                     # small number of terms
-    ssr = min(len(y), 3 * numbr)
+    ssr = min(n, 3 * numbr)
     logpr = logpr_gauss(om, terms)
     rng = np.random.default_rng(seed)
-    subsetinds = rng.choice(len(y), size=ssr, replace=False)
-    yr, xr = y[subsetinds], x[subsetinds, :]
+    subsetinds = rng.choice(n, size=ssr, replace=False)
+    if comm is None:
+        yr, xr = y[subsetinds], x[subsetinds, :]
+    else:
+        # the drawn rows live on different ranks: every rank fills in the ones it holds and
+        # the buffer is summed, so that all ranks run the first stage on the same rows
+        buf = np.zeros((ssr, d + 1))
+        mine = (subsetinds >= row0) & (subsetinds < row0 + n_local)
+        loc = subsetinds[mine] - row0
+        buf[mine, :d] = x[loc, :]
+        buf[mine, d] = y[loc]
+        buf = _sum_over_ranks(buf.ravel(), comm).reshape(ssr, d + 1)
+        yr, xr = buf[:, d].copy(), buf[:, :d].copy()
     loglik = loglik_gda(om, terms, yr, xr)
     loglik.dodiag = True
     logpdf = lpdfvec(logpr, loglik)
@@ -267,16 +356,20 @@ def obfit(x, y, numb=100, verbose=0, covnames=None, hyp=None, numberopts=2, nthr
 
     terms = om.selectterms(numb)
     bassize = np.ceil(np.maximum(16, np.minimum(70, 2 * terms.max(axis=0))))
-    setknot(om, _genknotlist(bassize, x))
+    setknot(om, _genknotlist(bassize, x, comm, dx))
+    dx.close()
     loglik_faster = loglik_gauss(om, terms, y, x)
+    if comm is not None:
+        loglik_faster.set_comm(comm)
     logpdf_faster = lpdfvec(logpr, loglik_faster)
     logpdf_faster.domarg = True
     Bm = optinfo["B"][:-1, :-1]                       # one fewer para: strip the last one off
-    Bm = len(yr) / len(y) * Bm                        # decrease scale
+    Bm = len(yr) / n * Bm                             # decrease scale
     logpdf_faster.updatepara(getpara(logpdf)[:2])
     lr = optinfo["lr"]
     for k in range(numberopts):
-        nsteps = _getsteps(numb, len(y), rvar_ratio(y, getpara(logpdf_faster)[1]))
+        # var(y) of the standardised y over all rows is 1 (R/fitting.R:115-116)
+        nsteps = _getsteps(numb, n, 1.0 / math.exp(2 * getpara(logpdf_faster)[1]))
         if verbose > 0:
             print("doing optimization", k + 1, "(max number of cg steps", nsteps, ")")
         terms = om.selectterms(numb)

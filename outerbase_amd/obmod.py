@@ -165,6 +165,15 @@ class outermod:
         lv = _f64(logbasisvar_gradhyp)
         call("obhip_model_set_rotation_grad", self._h, ptr(rg), ptr(lv))
 
+    def knots(self):
+        """the knot points as set (list of one array per dimension)"""
+        d, M, _, _ = self.dims()
+        st = np.empty(d + 1, dtype=np.uint64)
+        kp = np.empty(M)
+        call("obhip_model_get_knots", self._h, ptr(st), ptr(kp))
+        st = st.astype(np.int64)
+        return [kp[st[l]:st[l + 1]].copy() for l in range(d)]
+
     @property
     def maxlevel(self):
         return self.rotation()[2]
@@ -530,6 +539,12 @@ class lpdf:
     # -- methods (interfaceR.cpp:710-722) ---------------------------------------------------
     def setnthreads(self, k):  # fit.h:57 (no meaning on the device)
         call("obhip_lpdf_setnthreads", self._h, int(k))
+
+    def set_comm(self, comm):
+        """Rows sharded over the ranks of `comm` (an obhip_comm handle, driver.make_comm):
+        every sum over rows is summed over the ranks.  No reference counterpart."""
+        call("obhip_lpdf_set_comm", self._h, comm)
+        self._comm = comm
 
     def update(self, coeff):
         c = _f64(coeff)

@@ -32,16 +32,19 @@ def _free_port():
     return port
 
 
-def _run_ranks(out_dir, world, backend, n_total, p, extra=()):
+def _run_ranks(out_dir, world, backend, n_total, p, extra=(), worker=None):
     os.makedirs(out_dir, exist_ok=True)
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        argv = [sys.executable, WORKER, str(out_dir), backend, str(n_total), str(p), str(KNOTS),
+                ",".join(KINDS)] + [str(e) for e in extra]
+        if worker is not None:
+            argv = [sys.executable, worker, str(out_dir)] + [str(e) for e in extra]
         procs.append(subprocess.Popen(
-            [sys.executable, WORKER, str(out_dir), backend, str(n_total), str(p), str(KNOTS),
-             ",".join(KINDS)] + [str(e) for e in extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+            argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for pr in procs:
         try:
@@ -116,3 +119,28 @@ def test_two_rank_device_path_equals_single_process_and_oracle(tmp_path, backend
         # not pinned in the flat directions of the posterior, the predictions are
         assert np.array_equal(two[0]["theta"], two[1]["theta"])
         assert 0 < int(two[0]["iters"]) == int(two[1]["iters"]) < 5000
+
+
+@pytest.mark.timeout(1500)
+def test_row_sharded_obfit_equals_single_process(tmp_path):
+    """obfit with the rows of the 8-d Borehole example sharded over two rank processes
+    (ragged: 1000 + 1001 rows): y standardised, knots placed at quantiles and the first
+    stage's rows drawn over ALL rows, every row sum of the second stage summed over ranks.
+    Both ranks end with the same model, and it is the single-process model up to what the
+    BFGS loop makes of the different summation order."""
+    wk = os.path.join(ROOT, "tests", "obfit_worker.py")
+    two = _run_ranks(tmp_path / "o2", 2, None, None, None, extra=(2001, 60), worker=wk)
+    one = _run_ranks(tmp_path / "o1", 1, None, None, None, extra=(2001, 60), worker=wk)[0]
+    for r in two:
+        assert abs(r["y_cent"] - one["y_cent"]) < 1e-12 * abs(one["y_cent"])
+        assert abs(r["y_sca"] - one["y_sca"]) < 1e-12 * one["y_sca"]
+        assert np.array_equal(r["knots0"], one["knots0"])          # exact order statistics
+    # the ranks agree with each other to the last bit (same sums on both)
+    for k in ("hyp", "para", "coeff", "mean", "var"):
+        assert np.array_equal(two[0][k], two[1][k]), k
+    # and with the single process to optimisation accuracy
+    assert np.max(np.abs(two[0]["hyp"] - one["hyp"])) < 1e-3
+    sd = np.std(one["truth"])
+    assert np.max(np.abs(two[0]["mean"] - one["mean"])) < 1e-4 * sd
+    assert np.sqrt(np.mean((two[0]["mean"] - one["truth"]) ** 2)) < 0.03 * sd      # 60 terms only
+    assert np.all(two[0]["var"] > 0)

@@ -684,6 +684,33 @@ def test_loglik_gda_matches_oracle():
     assert lp.gradhyp.shape == (4,) and lp.gradpara.shape == (3,)
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 200, 100003])
+def test_device_quantiles_are_r_type_7(n):
+    """.genknotlist (R/fitting.R:177-185): quantile(x, probs), R's default type 7 -- exact
+    order statistics by bisection on counts (obhip_quantiles_dev), against the oracle's
+    restatement and numpy's 'linear' method, ties, negative values and +-0 included."""
+    import ob_oracle as O
+    from outerbase_amd import fitting as F
+    rng = np.random.default_rng(n)
+    x = rng.random((n, 4))
+    x[:, 1] = np.round(x[:, 1], 1)                  # heavy ties
+    x[:, 2] = rng.standard_normal(n) * 1e3          # negative values, wide range
+    x[::3, 3] = 0.0
+    x[1::3, 3] = -0.0
+    if n >= 200:
+        kn = F._genknotlist([40, 16, 70, 5], x)
+        ref = O.genknotlist([40, 16, 70, 5], x)
+        assert all(np.array_equal(a, b) for a, b in zip(kn, ref))
+    dx = F._DeviceCopy(x)
+    probs = np.array([0.0, 1e-9, 0.1, 0.25, 1 / 3, 0.5, 0.9, 1 - 1e-12, 1.0])
+    got = F._quantiles(dx, probs, None)
+    dx.close()
+    want = np.stack([O.quantile7(x[:, k], probs) for k in range(4)])
+    assert np.array_equal(got, want)
+    lin = np.stack([np.quantile(x[:, k], probs) for k in range(4)])
+    assert np.allclose(got, lin, rtol=1e-14, atol=1e-300)
+
+
 def test_obfit_and_obpred_end_to_end():
     """obfit / obpred (R/fitting.R:27-155) on the Borehole function (R/testfuncs.R:32-46) as
     the package's own examples use it: hyper-parameters move, predictions on fresh points

@@ -274,9 +274,7 @@ def test_fitting_helpers_and_argument_checks():
     from outerbase_amd import fitting as F
     rng = np.random.default_rng(0)
     x = rng.random((200, 4))
-    kn = F._genknotlist([40, 16, 70, 5], x)
-    ref = O.genknotlist([40, 16, 70, 5], x)
-    assert all(np.allclose(a, b) for a, b in zip(kn, ref))
+    # (.genknotlist evaluates its quantiles on the device: tests/test_gpu_parity.py)
     assert F._getsteps(4096, 1e6, 1e4) == O.getsteps(4096, 1e6, 1e4) == 35
     with pytest.raises(ValueError, match="do not align"):
         F.obfit(x, np.zeros(10))
