@@ -34,6 +34,8 @@
 //   fallback: k_tmm on the full views, one pass per hyper-parameter
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <set>
+
 #include "obhip_internal.h"
 #include "device_common.h"
 
@@ -746,27 +748,56 @@ static void build_sparse_views(obhip_terms &t, const obhip_basis &b) {
       (delta ? t.ge_dviews : t.ge_sviews)[hh] = std::move(v);
     }
   }
-  // the gradient views of all hyper-parameters as one term list
-  t.ge_sall_off.assign(nh + 1, 0);
-  for (uint64_t hh = 0; hh < nh; ++hh)
-    t.ge_sall_off[hh + 1] = t.ge_sall_off[hh] + t.ge_sidx[hh].size();
-  t.ge_sall.reset();
-  if (t.ge_sall_off[nh] > 0) {
+  // The gradient views are contracted a few hyper-parameters at a time: their term lists
+  // concatenated into groups whose used columns (the value columns of the other dimensions
+  // plus the groups' own gradient columns) stay within what the term-per-lane kernel can
+  // prefetch and keep two workgroups per CU on (128 columns).  One list of all of them
+  // (round 1) put ~300 columns and 3 p terms into a single pass: one workgroup per CU, no
+  // prefetch, 16.5 ms per call at p = 4096, 16 hyper-parameters.
+  const char *ge = getenv("OBHIP_GRAD_GROUP_MU");
+  const size_t mu_cap = ge ? (size_t)std::max(1, atoi(ge)) : 128;
+  t.ge_sgroups.clear();
+  std::set<std::pair<uint32_t, uint32_t>> used;  // (dimension of the view, level > 0)
+  auto close_group = [&](obhip_terms::GeGroup &g) {
+    if (g.hyps.empty()) return;
     auto v = std::make_unique<obhip_terms>();
-    v->p = t.ge_sall_off[nh];
+    v->p = g.off.back();
     v->d = de;
     v->lev.resize(v->p * de);
     v->maxlev.assign(de, 0);
-    for (uint64_t hh = 0; hh < nh; ++hh) {
-      const obhip_terms *sv = t.ge_sviews[hh].get();
-      if (!sv) continue;
-      std::copy(sv->lev.begin(), sv->lev.end(), v->lev.begin() + t.ge_sall_off[hh] * de);
+    for (size_t j = 0; j < g.hyps.size(); ++j) {
+      const obhip_terms *sv = t.ge_sviews[g.hyps[j]].get();
+      std::copy(sv->lev.begin(), sv->lev.end(), v->lev.begin() + g.off[j] * de);
       for (uint64_t q = 0; q < de; ++q) v->maxlev[q] = std::max(v->maxlev[q], sv->maxlev[q]);
       v->nnz_total += sv->nnz_total;
       v->max_nnz = std::max(v->max_nnz, sv->max_nnz);
     }
-    t.ge_sall = std::move(v);
+    g.v = std::move(v);
+    t.ge_sgroups.push_back(std::move(g));
+  };
+  obhip_terms::GeGroup cur;
+  cur.off.push_back(0);
+  for (uint64_t hh = 0; hh < nh; ++hh) {
+    const obhip_terms *sv = t.ge_sviews[hh].get();
+    if (!sv) continue;
+    std::set<std::pair<uint32_t, uint32_t>> mine;
+    for (uint64_t j = 0; j < sv->p; ++j)
+      for (uint64_t q = 0; q < de; ++q)
+        if (sv->lev[j * de + q] > 0) mine.insert({(uint32_t)q, sv->lev[j * de + q]});
+    std::set<std::pair<uint32_t, uint32_t>> both = used;
+    both.insert(mine.begin(), mine.end());
+    if (!cur.hyps.empty() && both.size() + 1 > mu_cap) {
+      close_group(cur);
+      cur = obhip_terms::GeGroup();
+      cur.off.push_back(0);
+      used = mine;
+    } else {
+      used.swap(both);
+    }
+    cur.hyps.push_back(hh);
+    cur.off.push_back(cur.off.back() + sv->p);
   }
+  close_group(cur);
 }
 
 obhip_terms *grad_view_sparse(obhip_terms &t, const obhip_basis &b, uint64_t h,
@@ -1064,32 +1095,35 @@ static int tmm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const d
   else
     OB_TRY(launch_bt_times_ge0(b, t, squared, d_a, dout.p));
   OB_TRY(d2h(out_gradhyp, dout.p, p * nh * sizeof(double)));
-  // the terms that have the hyper-parameter's dimension: one pass over the concatenated
-  // restricted views when their columns fit one LDS tile, else one pass per hyper-parameter
+  // the terms that have the hyper-parameter's dimension: one pass per group of restricted
+  // views (build_sparse_views)
   std::vector<double> tmp;
   const std::vector<uint32_t> *idx = nullptr;
   grad_view_sparse(t, b, 0, &idx);  // builds the views
-  obhip_terms *all = t.ge_sall.get();
-  if (all && all->prepare(src.md.cap, src.md.dims_h) == 0 && all->Mu <= 296) {
-    DevBuf<double> dall;
-    OB_TRY(dall.alloc(all->p));
-    OB_TRY(launch_tmm(src, *all, d_a, dall.p, false));
-    tmp.resize(all->p);
-    OB_TRY(d2h(tmp.data(), dall.p, tmp.size() * sizeof(double)));
-    for (uint64_t h = 0; h < nh; ++h) {
-      const std::vector<uint32_t> &ix = t.ge_sidx[h];
-      const double *src_h = tmp.data() + t.ge_sall_off[h];
-      for (size_t j = 0; j < ix.size(); ++j) out_gradhyp[h * p + ix[j]] = src_h[j];
+  for (obhip_terms::GeGroup &g : t.ge_sgroups) {
+    obhip_terms *all = g.v.get();
+    if (all->prepare(src.md.cap, src.md.dims_h) == 0 && all->Mu <= 296) {
+      DevBuf<double> dall;
+      OB_TRY(dall.alloc(all->p));
+      OB_TRY(launch_tmm(src, *all, d_a, dall.p, false));
+      tmp.resize(all->p);
+      OB_TRY(d2h(tmp.data(), dall.p, tmp.size() * sizeof(double)));
+      for (size_t j = 0; j < g.hyps.size(); ++j) {
+        const uint64_t h = g.hyps[j];
+        const std::vector<uint32_t> &ix = t.ge_sidx[h];
+        const double *src_h = tmp.data() + g.off[j];
+        for (size_t q = 0; q < ix.size(); ++q) out_gradhyp[h * p + ix[q]] = src_h[q];
+      }
+      continue;
     }
-    return 0;
-  }
-  for (uint64_t h = 0; h < nh; ++h) {
-    obhip_terms *v = grad_view_sparse(t, b, h, &idx);
-    if (!v) continue;
-    OB_TRY(launch_tmm(src, *v, d_a, dout.p, false));
-    tmp.resize(idx->size());
-    OB_TRY(d2h(tmp.data(), dout.p, tmp.size() * sizeof(double)));
-    for (size_t j = 0; j < tmp.size(); ++j) out_gradhyp[h * p + (*idx)[j]] = tmp[j];
+    for (uint64_t h : g.hyps) {  // beyond one LDS tile: hyper-parameter by hyper-parameter
+      obhip_terms *v = grad_view_sparse(t, b, h, &idx);
+      if (!v) continue;
+      OB_TRY(launch_tmm(src, *v, d_a, dout.p, false));
+      tmp.resize(idx->size());
+      OB_TRY(d2h(tmp.data(), dout.p, tmp.size() * sizeof(double)));
+      for (size_t q = 0; q < tmp.size(); ++q) out_gradhyp[h * p + (*idx)[q]] = tmp[q];
+    }
   }
   return 0;
 }

@@ -195,8 +195,11 @@ struct obhip_terms {
   // restricted likewise, the dimension's factor replaced by the delta column (products B a)
   std::vector<std::unique_ptr<obhip_terms>> ge_dviews;
   // all ge_sviews concatenated (one B^T a pass for every hyper-parameter), offsets per h
-  std::unique_ptr<obhip_terms> ge_sall;
-  std::vector<uint64_t> ge_sall_off;
+  struct GeGroup {
+    std::unique_ptr<obhip_terms> v;  // the ge_sviews of `hyps`, concatenated
+    std::vector<uint64_t> hyps, off; // off[j]: first term of hyps[j] in v (off.size() = hyps.size() + 1)
+  };
+  std::vector<GeGroup> ge_sgroups;
   // device view of the model capped at maxlev, for the fused predictor
   obhip::ModelDev pred_md;
   const obhip_model *pred_model = nullptr;

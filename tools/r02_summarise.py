@@ -67,8 +67,11 @@ for f in os.listdir(st) if os.path.isdir(st) else []:
             o.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 "
                     "--no-cpu-baseline --no-alt-backend --no-config3\n")
             for r in rows[:22]:
-                o.write("%-60s calls %5s  avg %10.3f ms  total %9.3f ms  %5.1f %%\n" % (
-                    r["Name"].split("(")[0][-60:], r["Calls"], float(r["AverageNs"]) / 1e6,
+                nm = r["Name"].replace("(anonymous namespace)::", "").replace("obhip::", "")
+                nm = nm[5:] if nm.startswith("void ") else nm
+                nm = nm.split("(")[0]
+                o.write("%-44s calls %5s  avg %10.3f ms  total %9.3f ms  %5.1f %%\n" % (
+                    nm[:44], r["Calls"], float(r["AverageNs"]) / 1e6,
                     float(r["TotalDurationNs"]) / 1e6, float(r["Percentage"])))
 print("mfma_util %.4f  traffic %.1f GB/launch (fetch %.1f, write %.1f)  L2 hit %.3f" % (
     mf["MfmaUtil"][0] / 100.0, (fetch_b + write_b) / 1e9, fetch_b / 1e9, write_b / 1e9, hit / (hit + miss)))
