@@ -6,7 +6,10 @@
 // H is p x p, row-major, full symmetric storage on entry; on exit its lower
 // triangle holds L (H = L L^T), the strict upper triangle is scratch.
 //
-// Per 64-column block step j:
+// Two 64-column panels per trailing update (rank 128): panel j, a strip update of the next 64
+// columns only, panel j + 1, then ONE pass over the trailing matrix with both panels (k = 128
+// in two LDS-staged halves).  The trailing update is HBM-bound from p ~ 4096 up (it reads and
+// writes the whole trailing triangle); this halves that traffic.
 //   k_chol_panel2: every workgroup re-factorises the 64 x 64 diagonal block itself
 //                  (cheaper than a launch boundary) and solves its 64 panel rows against
 //                  L_jj^T on the matrix cores (details at the kernel).  One extra "row" is
@@ -14,8 +17,9 @@
 //                  into part of the panel solve.  The solved rows also go to a k-major
 //                  scratch copy Wt[k][row] for the update.
 //   k_chol_update: trailing update A22 -= L21 L21^T (lower tiles only) on
-//                  v_mfma_f64_16x16x4_f64, 128 x 128 tiles, K = 64, operands straight from
-//                  Wt in 128-byte segments; plus the matching update of z.
+//                  v_mfma_f64_16x16x4_f64, 128 x 128 tiles, K = 64 per staged half, operands
+//                  straight from Wt in 128-byte segments; plus the matching update of z.
+//                  Strip form: the 64 columns of the next panel only.
 // Backward: k_chol_back per block from the last to the first: theta_j =
 // L_jj^-T z_j, then z[0:j) -= L[j, 0:j)^T theta_j.
 #include <utility>
@@ -121,7 +125,7 @@ __device__ __forceinline__ void potrf_cols(std::integer_sequence<int, Cs...>, do
 
 __global__ void __launch_bounds__(256)
 k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict__ Wt, int pw, int p,
-              int j0, int *__restrict__ info, double *__restrict__ Ljj) {
+              int j0, int *__restrict__ info, double *__restrict__ Ljj, int wt_row0) {
   __shared__ __attribute__((aligned(16))) double Lt[NB * LT];  // Lt[c][k] = L[k][c], 0 for k < c
   __shared__ double P[NB * LDP];    // diagonal block; later X (solved rows), per wave 16 rows
   __shared__ double Ap[NB * LDP];   // panel rows
@@ -250,7 +254,7 @@ k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
         const int k = 4 * kk + kq;
-        Wt[(size_t)k * pw + r0 + wave * 16 + m] = X[m * LDP + k];
+        Wt[(size_t)(wt_row0 + k) * pw + r0 + wave * 16 + m] = X[m * LDP + k];
       }
     }
   }
@@ -266,52 +270,50 @@ constexpr int UP = 128 + 16;  // LDS pitch of a staged panel row (doubles)
 
 __global__ void __launch_bounds__(256)
 k_chol_update(double *__restrict__ H, double *__restrict__ z, const double *__restrict__ Wt, int pw,
-              int p, int j0, int nt, int npairs, const double *__restrict__ Ljj) {
+              int p, int t0 /* first trailing row / column */, int kparts /* staged halves of 64 k */,
+              int strip /* 1: only the columns [t0, t0 + 64) */, int ntiles,
+              int ljj_j0 /* where the panel's L_jj goes */, int zj0 /* panel whose z part is applied */,
+              int zk0 /* its first row in Wt */, const double *__restrict__ Ljj) {
   __shared__ __attribute__((aligned(16))) double Sa[NB * UP];
   __shared__ __attribute__((aligned(16))) double Sb[NB * UP];
-  const int t0 = j0 + NB;
-  if ((int)blockIdx.x >= npairs) {
-    if ((int)blockIdx.x == npairs)  // L_jj from the panel step's scratch block into place
+  if ((int)blockIdx.x >= ntiles) {
+    if ((int)blockIdx.x == ntiles)  // L_jj from the panel step's scratch block into place
       for (int e = threadIdx.x; e < NB * NB; e += 256)
-        if ((e & 63) <= (e >> 6)) H[(size_t)(j0 + (e >> 6)) * p + j0 + (e & 63)] = Ljj[e];
-    // z[c] -= sum_k z[j0 + k] * L[c][j0 + k], all 64 loads in flight at once
-    const int c = t0 + ((int)blockIdx.x - npairs) * 256 + (int)threadIdx.x;
+        if ((e & 63) <= (e >> 6) && ljj_j0 + (e >> 6) < p && ljj_j0 + (e & 63) < p)
+          H[(size_t)(ljj_j0 + (e >> 6)) * p + ljj_j0 + (e & 63)] = Ljj[e];
+    // z[c] -= sum_k z[zj0 + k] * L[c][zj0 + k] for c >= zj0 + 64, all 64 loads in flight at once
+    const int c = zj0 + NB + ((int)blockIdx.x - ntiles) * 256 + (int)threadIdx.x;
     if (c < p) {
       double w[NB];
 #pragma unroll
-      for (int k = 0; k < NB; ++k) w[k] = Wt[(size_t)k * pw + c];
+      for (int k = 0; k < NB; ++k) w[k] = Wt[(size_t)(zk0 + k) * pw + c];
       double s = z[c];
 #pragma unroll
-      for (int k = 0; k < NB; ++k) s = fma(-z[j0 + k], w[k], s);
+      for (int k = 0; k < NB; ++k) s = fma(-z[zj0 + k], w[k], s);
       z[c] = s;
     }
     return;
   }
-  // lower-triangular tile pair (bi >= bj)
-  int bi = 0, rem = blockIdx.x;
-  while (rem > bi) {
-    rem -= bi + 1;
-    ++bi;
+  // lower-triangular tile pair (bi >= bj); strip form: the tiles (bi, 0)
+  int bi = 0, bj = 0;
+  if (strip) {
+    bi = blockIdx.x;
+  } else {
+    int rem = blockIdx.x;
+    while (rem > bi) {
+      rem -= bi + 1;
+      ++bi;
+    }
+    bj = rem;
   }
-  const int bj = rem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const bool active = !(bi == bj && wn > wm);  // strictly upper 64 x 64 quadrant: no work
+  // strictly upper 64 x 64 quadrant of a diagonal tile: no work; strip: the left half only
+  const bool active = strip ? (wn == 0) : !(bi == bj && wn > wm);
   const int t16 = lane & 15, q = lane >> 4;
   const int rbase = t0 + bi * 128 + wm * 64, cbase = t0 + bj * 128 + wn * 64;
 
-  // panels: 64 k x 128 rows each = 4096 16-byte pieces per panel, 16 per thread
-  d2v ga[16], gb[16];
-  {
-    const double *srca = Wt + t0 + bi * 128, *srcb = Wt + t0 + bj * 128;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e = tid + 256 * u, k = e >> 6, c2 = e & 63;
-      ga[u] = *(const d2v *)(srca + (size_t)k * pw + 2 * c2);
-      gb[u] = *(const d2v *)(srcb + (size_t)k * pw + 2 * c2);
-    }
-  }
   // H tile into the accumulators (rows / columns beyond p or above the diagonal: zero)
   d4 acc[4][4];
 #pragma unroll
@@ -323,30 +325,47 @@ k_chol_update(double *__restrict__ H, double *__restrict__ z, const double *__re
         const int row = rbase + i * 16 + q + 4 * r, col = cbase + j * 16 + t16;
         acc[i][j][r] = (active && row < p && col <= row) ? H[(size_t)row * p + col] : 0.0;
       }
+  for (int part = 0; part < kparts; ++part) {
+    // panels: 64 k x 128 rows each = 4096 16-byte pieces per panel, 16 per thread
+    d2v ga[16], gb[16];
+    {
+      const double *srca = Wt + (size_t)part * NB * pw + t0 + bi * 128;
+      const double *srcb = Wt + (size_t)part * NB * pw + t0 + bj * 128;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int e = tid + 256 * u, k = e >> 6, c2 = e & 63;
-    *(d2v *)&Sa[k * UP + 2 * c2] = ga[u];
-    *(d2v *)&Sb[k * UP + 2 * c2] = gb[u];
-  }
-  __syncthreads();
-  if (!active) return;
-  const double *pa = Sa + q * UP + wm * 64 + t16;
-  const double *pb = Sb + q * UP + wn * 64 + t16;
-#pragma unroll 4
-  for (int s = 0; s < 16; ++s) {
-    double a[4], b[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      a[f] = -pa[4 * s * UP + 16 * f];
-      b[f] = pb[4 * s * UP + 16 * f];
+      for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u, k = e >> 6, c2 = e & 63;
+        ga[u] = *(const d2v *)(srca + (size_t)k * pw + 2 * c2);
+        gb[u] = *(const d2v *)(srcb + (size_t)k * pw + 2 * c2);
+      }
     }
+    if (part > 0) __syncthreads();  // the previous half has been consumed
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u, k = e >> 6, c2 = e & 63;
+      *(d2v *)&Sa[k * UP + 2 * c2] = ga[u];
+      *(d2v *)&Sb[k * UP + 2 * c2] = gb[u];
+    }
+    __syncthreads();
+    if (active) {
+      const double *pa = Sa + q * UP + wm * 64 + t16;
+      const double *pb = Sb + q * UP + wn * 64 + t16;
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        double a[4], b[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int f = 0; f < 4; ++f) {
+          a[f] = -pa[4 * s * UP + 16 * f];
+          b[f] = pb[4 * s * UP + 16 * f];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
   }
+  if (!active) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -423,11 +442,11 @@ __global__ void k_form_hessian(double *__restrict__ G, const double *__restrict_
 
 }  // namespace
 
-// z (p), info (64 doubles reserved), k-major panel copy Wt (64 rows of chol_pitch(p)
-// doubles), scratch block for L_jj (64 x 64)
+// z (p), info (64 doubles reserved), k-major copies of two panels Wt (128 rows of
+// chol_pitch(p) doubles), scratch block for L_jj (64 x 64)
 static uint64_t chol_pitch(uint64_t p) { return (p + 127) / 128 * 128 + 128; }
 uint64_t newton_workspace_bytes(uint64_t p) {
-  return (p + 64 + NB * chol_pitch(p) + NB * NB) * sizeof(double);
+  return (p + 64 + 2 * NB * chol_pitch(p) + NB * NB) * sizeof(double);
 }
 
 int launch_form_hessian(uint64_t p, double *d_G, const double *d_prec, double e2, double *d_diagH) {
@@ -448,31 +467,62 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
   int *info = (int *)(z + p);
   double *Wt = z + p + 64;
   const int pw = (int)chol_pitch(p64);
-  double *Ljj = Wt + (size_t)NB * pw;
+  double *Ljj = Wt + (size_t)2 * NB * pw;
   hipStream_t st = cur_stream();
-  OB_HIP(hipMemsetAsync(Wt, 0, sizeof(double) * NB * pw, st));  // rows beyond p stay zero
+  OB_HIP(hipMemsetAsync(Wt, 0, sizeof(double) * 2 * NB * pw, st));  // rows beyond p stay zero
   OB_HIP(hipMemcpyAsync(z, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, st));
   OB_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
   {
     ProfScope ps("cholesky");
-    for (int j0 = 0; j0 < p; j0 += NB) {
+    // L_jj of the last panel of a pass: nothing follows that would move it into place
+    auto place_ljj = [&](int j0) -> int {
+      const int jb = std::min(NB, p - j0);
+      OB_HIP(hipMemcpy2DAsync(d_H + (size_t)j0 * p + j0, (size_t)p * sizeof(double), Ljj,
+                              NB * sizeof(double), jb * sizeof(double), jb, hipMemcpyDeviceToDevice,
+                              st));
+      return 0;
+    };
+    auto panel = [&](int j0, int wt_row0) {
       const int nrowblk = (p - j0 + NB - 1) / NB;  // block 0 = diagonal block
       hipLaunchKernelGGL(k_chol_panel2, dim3((unsigned)(nrowblk + 1)), dim3(256), 0, st, d_H, z, Wt,
-                         pw, p, j0, info, Ljj);
+                         pw, p, j0, info, Ljj, wt_row0);
+    };
+    // Two panels per trailing pass pay off once the update is HBM-bound (63.6 -> 52.7 ms at
+    // p = 16384); at p = 4096 the steps are latency-bound and the extra strip launch costs 5 %.
+    const bool two = p >= 8192;
+    for (int j0 = 0; !two && j0 < p; j0 += NB) {
+      panel(j0, 0);
       const int m = p - (j0 + NB);
-      if (m > 0) {
-        const int nt = (m + 127) / 128;
-        const int npairs = nt * (nt + 1) / 2;
-        const int nz = (m + 255) / 256;
+      if (m <= 0) {
+        OB_TRY(place_ljj(j0));
+        break;
+      }
+      const int nt = (m + 127) / 128, npairs = nt * (nt + 1) / 2, nz = (m + 255) / 256;
+      hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(npairs + nz)), dim3(256), 0, st, d_H, z, Wt, pw,
+                         p, j0 + NB, 1, 0, npairs, j0, j0, 0, Ljj);
+    }
+    for (int j0 = 0; two && j0 < p; j0 += 2 * NB) {
+      panel(j0, 0);
+      const int m1 = p - (j0 + NB);
+      if (m1 <= 0) {
+        OB_TRY(place_ljj(j0));
+        break;
+      }
+      {  // the next panel's 64 columns (all rows below), z for everything below, L_jj of panel j0
+        const int nt = (m1 + 127) / 128, nz = (m1 + 255) / 256;
+        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(nt + nz)), dim3(256), 0, st, d_H, z, Wt, pw,
+                           p, j0 + NB, 1, 1, nt, j0, j0, 0, Ljj);
+      }
+      panel(j0 + NB, NB);
+      const int m2 = p - (j0 + 2 * NB);
+      if (m2 <= 0) {
+        OB_TRY(place_ljj(j0 + NB));
+        break;
+      }
+      {  // the trailing matrix once with both panels (k = 128), z with the second panel
+        const int nt = (m2 + 127) / 128, npairs = nt * (nt + 1) / 2, nz = (m2 + 255) / 256;
         hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(npairs + nz)), dim3(256), 0, st, d_H, z, Wt,
-                           pw, p, j0, nt, npairs, Ljj);
-      } else {
-        // last block column: nothing to update, only L_jj to put in place (its zero upper
-        // part lands in H's scratch triangle)
-        const int jb = p - j0;
-        OB_HIP(hipMemcpy2DAsync(d_H + (size_t)j0 * p + j0, (size_t)p * sizeof(double), Ljj,
-                                NB * sizeof(double), jb * sizeof(double), jb,
-                                hipMemcpyDeviceToDevice, st));
+                           pw, p, j0 + 2 * NB, 2, 0, npairs, j0 + NB, j0 + NB, NB, Ljj);
       }
     }
     OB_HIP(hipGetLastError());
