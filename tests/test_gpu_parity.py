@@ -506,12 +506,19 @@ def test_gradhyp_with_more_hyperparameters_than_one_pass_holds():
     assert relerr(bd.sqcolsums_gradhyp(terms), O.ob_sqcolsums_gradhyp(bo, terms)) < 1e-9
 
 
-def test_gradhyp_follows_the_reference_finite_difference_test():
-    """test-obomgrad.R:21-67 on the device: the gradient along a random direction equals the
-    difference quotient of two rebuilt bases (updatehyp + build)."""
+@pytest.mark.parametrize("ss,nterms", [(400, 100),        # testmultgrad's defaults
+                                        (200, 100),        # "short, skinny" (test-obomgrad.R:72)
+                                        (10000, 100),      # "tall, skinny"  (:81)
+                                        (200, 1000),       # "short, wide"   (:90)
+                                        (10000, 2000)])    # "tall, wide"    (:99)
+def test_gradhyp_follows_the_reference_finite_difference_test(ss, nterms):
+    """testmultgrad of test-obomgrad.R:21-67 on the device at the reference's four shapes: the
+    gradient along a random direction equals the difference quotient of two rebuilt bases
+    (updatehyp + build).  Central differences and 1e-3 of the largest entry here; the
+    reference takes a forward difference and accepts a relative difference of 1."""
     import outerbase_amd as ob
     from conftest import KNOTS_REF
-    d, ss, nterms = 8, 400, 100
+    d = 8
     kinds = ["mat25pow"] + ["mat25"] * (d - 1)
     rng = np.random.default_rng(42)
     x = rng.random((ss, d))
@@ -525,7 +532,9 @@ def test_gradhyp_follows_the_reference_finite_difference_test():
     y = rng.standard_normal(ss)
     mge = obp.matmul_gradhyp(terms, theta)
     gge = obp.tmatmul_gradhyp(terms, y)
-    eps, hypp = 1e-6, rng.random(len(hyp0)) - 0.5
+    # (eps: the eigenvectors of the rebuilt bases carry ~1e-9 of solver noise at the high
+    # levels wide term sets reach, so the quotient is only good to ~1e-9 / eps)
+    eps, hypp = 1e-4, rng.random(len(hyp0)) - 0.5
     vals = []
     for sgn in (1.0, -1.0):
         om.updatehyp(hyp0 + sgn * eps * hypp)
@@ -1202,3 +1211,98 @@ def test_device_memory_pool_recycles_and_trims():
     _lib.call("obhip_trim_pool")
     assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)   # ... and went back on request
     assert relerr(first[0][:2000], O.ob_mm(O.OuterBase(om_o, x[:2000]), terms, a)) < 1e-9
+
+
+# ---- tests/testthat/test-lpdf.R on the device objects -------------------------------------
+def _lpdf_getvals(ob, om, obj, coeff, hyp, para):
+    """getvals (test-lpdf.R:21-37)."""
+    obj.compute_gradhyp = True
+    obj.compute_gradpara = True
+    om.updatehyp(hyp)
+    obj.updateom()
+    obj.updatepara(para)
+    obj.update(coeff)
+    return dict(val=obj.val, grad=obj.grad, gradhyp=obj.gradhyp, gradpara=obj.gradpara,
+                diaghess=obj.diaghess(), diaghessgradhyp=obj.diaghessgradhyp(),
+                diaghessgradpara=obj.diaghessgradpara())
+
+
+def _lpdf_perturbvals(ob, om, obj, coeff, coeffp, hyp, hypp, para, parap, ep):
+    """perturbvals (test-lpdf.R:39-72): differences of the value and of the Hessian diagonal
+    along random directions against ep times the analytic directional derivatives."""
+    gv = lambda c, h, q: _lpdf_getvals(ob, om, obj, c, h, q)
+    L = gv(coeff, hyp, para)
+    L_coeff = gv(coeff + ep * coeffp, hyp, para)
+    L_para = gv(coeff, hyp, para + ep * parap)
+    L_hyp = gv(coeff, hyp + ep * hypp, para)
+    L2 = gv(coeff, hyp, para)
+    grad = (L["grad"] + L2["grad"] + L_coeff["grad"]) / 3
+    gradhyp = (L["gradhyp"] + L2["gradhyp"] + L_para["gradhyp"]) / 3
+    gradpara = (L["gradpara"] + L2["gradpara"] + L_para["gradpara"]) / 3
+    chk = {}
+    chk["coeff"] = (L_coeff["val"] - L["val"], ep * float(np.sum(grad * coeffp)))
+    chk["hyp"] = (L_hyp["val"] - L["val"], ep * float(np.sum(gradhyp * hypp)))
+    chk["para"] = (L_para["val"] - L["val"], ep * float(np.sum(gradpara * parap)))
+    chk["rep"] = (L["val"], L2["val"])
+    chk["dhcoeff"] = (L_hyp["diaghess"] - L["diaghess"], ep * (L["diaghessgradhyp"] @ hypp))
+    chk["dhpara"] = (L_para["diaghess"] - L["diaghess"], ep * (L["diaghessgradpara"] @ parap))
+    return chk
+
+
+def _all_equal(target, current, tolerance):
+    """testthat::expect_equal / all.equal.numeric: mean relative difference
+    sum|target - current| / sum|target| below the tolerance (absolute when target is ~0)."""
+    target, current = np.atleast_1d(target).astype(float), np.atleast_1d(current).astype(float)
+    xy = float(np.sum(np.abs(target - current)))
+    xn = float(np.sum(np.abs(target)))
+    if np.isfinite(xn) and xn > np.finfo(float).eps ** 0.5 * target.size:
+        xy /= xn
+    else:
+        xy /= target.size
+    return xy < tolerance
+
+
+@pytest.mark.parametrize("ss,nterms", [(200, 100),       # "short, skinny" (test-lpdf.R:132-168)
+                                        (10000, 100),     # "tall, skinny"  (:171-206)
+                                        (200, 1000)])     # "short, wide"   (:209-245)
+def test_reference_lpdf_perturbation_suite(ss, nterms):
+    """fulltest of tests/testthat/test-lpdf.R:76-126 on the device: the prior, the Gaussian
+    likelihood and their lpdfvec at the reference's three shapes; values move along random
+    coeff / hyp / para directions by ep times the analytic directional derivative, the
+    Hessian diagonal moves by ep times diaghessgradhyp / diaghessgradpara, and a repeated
+    evaluation reproduces the value -- every expectation of the reference's file, with its
+    tolerance (0.01 relative), none of them downgraded to a warning."""
+    import outerbase_amd as ob
+    import ob_oracle as O
+    d, ep = 8, 1e-4
+    rng = np.random.default_rng(42)
+    xo = rng.uniform(size=(ss, d))
+    yo = O.borehole8d(xo) + 77.0                                  # test-lpdf.R:1-15 (no offset)
+    y = (yo - yo.mean()) / yo.std(ddof=1)
+    om = ob.outermod()
+    ob.setcovfs(om, ["mat25"] * d)
+    ob.setknot(om, [np.arange(0.001, 0.999, 0.05)] * d)           # :89
+    hyp = ob.gethyp(om)
+    om.updatehyp(hyp)
+    terms = om.selectterms(nterms)
+    logpr = ob.logpr_gauss(om, terms)
+    loglik = ob.loglik_gauss(om, terms, y, xo)
+    sdy = y.std(ddof=1)
+    coeff = sdy / 100 * rng.standard_normal(nterms)
+    coeffp = sdy / 100 * rng.standard_normal(nterms)
+    hypp = rng.uniform(size=hyp.size) - 0.5
+    prpara, likpara = np.array([math.log(1.0)]), np.array([math.log(0.1)])
+    prinfo = _lpdf_perturbvals(ob, om, logpr, coeff, coeffp, hyp, hypp, prpara,
+                               rng.standard_normal(1), ep)
+    likinfo = _lpdf_perturbvals(ob, om, loglik, coeff, coeffp, hyp, hypp, likpara,
+                                rng.standard_normal(1), ep)
+    logpdf = ob.lpdfvec(loglik, logpr)
+    vecpara = ob.getpara(logpdf)
+    vecinfo = _lpdf_perturbvals(ob, om, logpdf, coeff, coeffp, hyp, hypp, vecpara,
+                                rng.standard_normal(vecpara.size), ep)
+    for name, info in (("pr", prinfo), ("lik", likinfo), ("vec", vecinfo)):
+        for what in ("coeff", "hyp", "para"):
+            assert _all_equal(info[what][0], info[what][1], 0.01), (name, what, info[what])
+    assert _all_equal(likinfo["dhcoeff"][0], likinfo["dhcoeff"][1], 0.01)
+    assert _all_equal(likinfo["dhpara"][0], likinfo["dhpara"][1], 0.01)
+    assert _all_equal(likinfo["rep"][0], likinfo["rep"][1], 1e-12)
