@@ -384,6 +384,15 @@ k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__rest
   __shared__ double Ld[NB * LDP];
   __shared__ double th[NB];
   const int jb = min(NB, p - j0);
+  // This thread's column c of the 64 rows of L it will need for z[c] -= L[j0 + k][c] theta_k:
+  // they do not depend on theta, so they are fetched now and arrive under the serial solve.
+  const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  double lc[NB], zc = 0.0;
+  if (c < j0) {
+    zc = z[c];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) lc[k] = L[(size_t)(j0 + min(k, jb - 1)) * p + c];
+  }
   {
     double t[NB * NB / 256];
 #pragma unroll
@@ -394,8 +403,8 @@ k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__rest
 #pragma unroll
     for (int i = 0; i < NB * NB / 256; ++i) {
       const int e = threadIdx.x + i * 256;
-      const int r = e / NB, c = e % NB;
-      Ld[r * LDP + c] = (r < jb && c < jb && c <= r) ? t[i] : ((r == c) ? 1.0 : 0.0);
+      const int r = e / NB, cc = e % NB;
+      Ld[r * LDP + cc] = (r < jb && cc < jb && cc <= r) ? t[i] : ((r == cc) ? 1.0 : 0.0);
     }
   }
   __syncthreads();
@@ -404,26 +413,26 @@ k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__rest
     double zk = lane < jb ? z[j0 + lane] : 0.0;
     // L_jj^T theta = z, from the last unknown to the first.  The 64 divisions happen up
     // front in parallel (one Newton-corrected reciprocal per lane), so that the serial chain
-    // per unknown is readlane - multiply - fma.
+    // per unknown is readlane - multiply - fma.  (With the 16 x 16 inverses of the panel
+    // step the chain would be 4 x 32 dependent FMAs instead of 64 x 3 operations: ~0.4 of
+    // the ~1 us this loop takes out of the step's 7; not done.)
     const double dl = Ld[lane * LDP + lane];
     double rinv = 1.0 / dl;
     rinv = fma(fma(-dl, rinv, 1.0), rinv, rinv);
 #pragma unroll 8
-    for (int c = NB - 1; c >= 0; --c) {
-      const double tc = readlane_d(zk, c) * readlane_d(rinv, c);
-      if (lane == c) zk = tc;
-      if (lane < c) zk = fma(-Ld[c * LDP + lane], tc, zk);
+    for (int cc = NB - 1; cc >= 0; --cc) {
+      const double tc = readlane_d(zk, cc) * readlane_d(rinv, cc);
+      if (lane == cc) zk = tc;
+      if (lane < cc) zk = fma(-Ld[cc * LDP + lane], tc, zk);
     }
-    th[lane] = zk;
+    th[lane] = lane < jb ? zk : 0.0;  // rows past the end (ragged last block) add nothing
     if (blockIdx.x == 0 && lane < jb) theta[j0 + lane] = zk;
   }
   __syncthreads();
-  const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (c < j0) {
-    double s = z[c];
-#pragma unroll 8
-    for (int k = 0; k < jb; ++k) s = fma(-L[(size_t)(j0 + k) * p + c], th[k], s);
-    z[c] = s;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) zc = fma(-lc[k], th[k], zc);
+    z[c] = zc;
   }
 }
 
