@@ -67,60 +67,136 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   return y;
 }
 
-// column C of the in-register factorisation (lane = row); a template so that every index
-// below is a compile-time constant (a[] must stay in registers)
-template <int C>
-__device__ __forceinline__ void potrf_col(double (&a)[NB], double &piv, bool &bad, double *Lt,
-                                          double *dinv, int lane) {
-  if (!(piv > 0.0)) bad = true;
-  const double rs = rsqrt_nr(piv);
-  double sq = piv * rs;
-  sq = fma(fma(-sq, sq, piv), 0.5 * rs, sq);
-  const double lc = lane < C ? 0.0 : (lane == C ? sq : a[C] * rs);
-  if (lane == C) dinv[C] = rs;
-  if constexpr (C + 1 < NB) {
-    // the next pivot depends on this column only through L[C+1][C]: register path
-    a[C + 1] = fma(-lc, readlane_d(lc, C + 1), a[C + 1]);
-    piv = readlane_d(a[C + 1], C + 1);
-  }
-  Lt[C * LT + lane] = lc;
-  // rest of the rank-1 update; L[k][C] comes back from LDS as broadcast reads, in groups
-  // of 8 values one group ahead of the FMAs (sched_barrier: left alone, the scheduler
-  // hoists every read of the column and spills ~2000 registers)
-  constexpr int K0 = C + 2, G0 = K0 / 8;
-  if constexpr (K0 < NB) {
-    d2v cur[4], nxt[4];
+// Column C0 + C of the in-register factorisation of the 16 columns [C0, C0 + 16) (lane =
+// row); a template so that every index below is a compile-time constant (a[] must stay in
+// registers).  The columns stay UNNORMALISED while the block is being eliminated (u = the
+// column as the earlier columns left it, w = u / pivot, a[k] -= w u_k): the chain from one
+// pivot to the next is then a reciprocal with its two Newton steps, one multiply, one FMA and
+// the v_readlane of the next diagonal element; the square roots wait for potrf_block.
+constexpr int PB = 16;  // columns per in-register block of the diagonal-block factorisation
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+// the part of a column's rank-1 update that goes through LDS, applied one column later
+struct PotrfPending {
+  double w;      // u / pivot of that column, lane = row
+  double v[PB];  // its u[C0 .. C0 + 16), broadcast
+};
+// ties the listed registers to this point of the instruction stream: what uses them cannot be
+// scheduled above it (left alone, the scheduler hoists the first delayed FMA above the
+// reciprocal of the next column, and with it the wait for the LDS read it depends on)
+template <int K0>
+__device__ __forceinline__ void potrf_pin(double &w, double (&v)[PB]) {
+  if constexpr (K0 + 8 <= PB)
+    asm volatile("" : "+v"(w), "+v"(v[K0]), "+v"(v[K0 + 1]), "+v"(v[K0 + 2]), "+v"(v[K0 + 3]),
+                      "+v"(v[K0 + 4]), "+v"(v[K0 + 5]), "+v"(v[K0 + 6]), "+v"(v[K0 + 7]));
+  else if constexpr (K0 + 4 <= PB)
+    asm volatile("" : "+v"(w), "+v"(v[K0]), "+v"(v[K0 + 1]), "+v"(v[K0 + 2]), "+v"(v[K0 + 3]));
+  else if constexpr (K0 + 2 <= PB)
+    asm volatile("" : "+v"(w), "+v"(v[K0]), "+v"(v[K0 + 1]));
+  else if constexpr (K0 + 1 <= PB)
+    asm volatile("" : "+v"(w), "+v"(v[K0]));
+  if constexpr (K0 + 8 <= PB) potrf_pin<K0 + 8>(w, v);
+  else if constexpr (K0 + 4 <= PB) potrf_pin<K0 + 4>(w, v);
+  else if constexpr (K0 + 2 <= PB) potrf_pin<K0 + 2>(w, v);
+}
+template <int C, int C0>
+__device__ __forceinline__ void potrf_col(double (&a)[PB], double &piv, double &pv, bool &bad,
+                                          double *Lt, int lane, PotrfPending &pin, PotrfPending &pout) {
+  constexpr int c = C0 + C;
+  const double u = lane < c ? 0.0 : a[C];
+  a[C] = u;
+  // The column goes to LDS and its 16 block entries are requested back as broadcast reads
+  // right away; they are consumed a column later (pout), when the round trip is long over.
+  if constexpr (C + 2 < PB) {
+    Lt[c * LT + lane] = u;  // (potrf_block overwrites the row with the normalised column)
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (8 * G0 + 2 * u + 1 >= K0) cur[u] = *(const d2v *)&Lt[C * LT + 8 * G0 + 2 * u];
-#pragma unroll
-    for (int g = G0; g < NB / 8; ++g) {
-      if (g + 1 < NB / 8) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) nxt[u] = *(const d2v *)&Lt[C * LT + 8 * (g + 1) + 2 * u];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = 8 * g + 2 * u;
-        if (k >= K0) a[k] = fma(-lc, cur[u].x, a[k]);
-        if (k + 1 >= K0) a[k + 1] = fma(-lc, cur[u].y, a[k + 1]);
-      }
-      // pin the group: the "+v" operands order the FMAs, the memory clobber the reads
-      asm volatile(""
-                   : "+v"(a[8 * g]), "+v"(a[8 * g + 1]), "+v"(a[8 * g + 2]), "+v"(a[8 * g + 3]),
-                     "+v"(a[8 * g + 4]), "+v"(a[8 * g + 5]), "+v"(a[8 * g + 6]), "+v"(a[8 * g + 7])
-                   :
-                   : "memory");
-#pragma unroll
-      for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+    for (int i = (C + 2) / 2; i < PB / 2; ++i) {
+      const d2v t = *(const d2v *)&Lt[c * LT + C0 + 2 * i];
+      pout.v[2 * i] = t.x;
+      pout.v[2 * i + 1] = t.y;
     }
   }
+  // (the reads are on their way before the reciprocal starts)
+  asm volatile("" : "+s"(piv) : : "memory");
+  if (!(piv > 0.0)) bad = true;
+  pv = lane == c ? piv : pv;
+  const double r = rcp_nr(piv);
+  double w = u * r;
+  pout.w = w;
+  // Column C - 1 updated a[C] (register path) before it handed over the pivot; what it owes
+  // the columns to the right of this one is in pin, and is consumed only now that this
+  // column's reciprocal is through (left alone, the scheduler hoists these FMAs, and the wait
+  // for their LDS reads, into the pivot chain).
+  if constexpr (C >= 1 && C + 1 < PB) {
+    potrf_pin<C + 1>(w, pin.v);
+    a[C + 1] = fma(-pin.w, pin.v[C + 1], a[C + 1]);
+  }
+  if constexpr (C + 1 < PB) {
+    // the next pivot depends on this column only through u[c+1]: register path
+    a[C + 1] = fma(-w, readlane_d(u, c + 1), a[C + 1]);
+    piv = readlane_d(a[C + 1], c + 1);
+  }
+  if constexpr (C >= 1) {
+#pragma unroll
+    for (int k = C + 2; k < PB; ++k) a[k] = fma(-pin.w, pin.v[k], a[k]);
+  }
 }
-template <int... Cs>
-__device__ __forceinline__ void potrf_cols(std::integer_sequence<int, Cs...>, double (&a)[NB],
-                                           double &piv, bool &bad, double *Lt, double *dinv,
-                                           int lane) {
-  (potrf_col<Cs>(a, piv, bad, Lt, dinv, lane), ...);
+template <int C0, int... Cs>
+__device__ __forceinline__ void potrf_cols(std::integer_sequence<int, Cs...>, double (&a)[PB],
+                                           double &piv, double &pv, bool &bad, double *Lt, int lane) {
+  PotrfPending p0, p1;  // written by the even / odd columns, read by the next one
+  (potrf_col<Cs, C0>(a, piv, pv, bad, Lt, lane, (Cs & 1) ? p0 : p1, (Cs & 1) ? p1 : p0), ...);
+}
+template <int C0, int... Cs>
+__device__ __forceinline__ void potrf_store(std::integer_sequence<int, Cs...>, const double (&a)[PB],
+                                            double rsv, double sqv, double *Lt, int lane) {
+  // L[lane][C0 + C] = u / sqrt(pivot) below the diagonal, sqrt(pivot) on it, 0 above (u is)
+  ((Lt[(C0 + Cs) * LT + lane] = lane == C0 + Cs ? sqv : a[Cs] * readlane_d(rsv, C0 + Cs)), ...);
+}
+// wave 0: columns [C0, C0 + 16) of the 64 x 64 block P (rows >= C0 matter), L -> Lt, 1/diag -> dinv
+template <int C0>
+__device__ __forceinline__ void potrf_block(const double *P, bool &bad, double *Lt, double *dinv,
+                                            int lane) {
+  double a[PB];
+#pragma unroll
+  for (int k = 0; k < PB; ++k) a[k] = P[lane * LDP + C0 + k];
+  double piv = readlane_d(a[0], C0), pv = 1.0;  // pv: lane c keeps the pivot of column c
+  potrf_cols<C0>(std::make_integer_sequence<int, PB>{}, a, piv, pv, bad, Lt, lane);
+  // the 16 square roots at once, lane = column
+  const double rsv = rsqrt_nr(pv);
+  double sqv = pv * rsv;
+  sqv = fma(fma(-sqv, sqv, pv), 0.5 * rsv, sqv);
+  if (lane >= C0 && lane < C0 + PB) dinv[lane] = rsv;
+  potrf_store<C0>(std::make_integer_sequence<int, PB>{}, a, rsv, sqv, Lt, lane);
+}
+// all four waves: P[r][c] -= sum_{k in [C0, C0 + 16)} L[r][k] L[c][k] for the 16 x 16 tiles
+// (rt >= ct) right of and below the block, on v_mfma_f64_16x16x4_f64, operands from Lt
+template <int C0>
+__device__ __forceinline__ void potrf_trailing(double *P, const double *Lt, int wave, int lane) {
+  constexpr int B1 = C0 / 16 + 1, NT = 4 - B1;  // tiles per side
+  const int t16 = lane & 15, q = lane >> 4;
+  int t = 0;
+#pragma unroll
+  for (int rt = B1; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = B1; ct <= rt; ++ct, ++t) {
+      if ((t & 3) != wave) continue;
+      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double av = Lt[(C0 + 4 * s + q) * LT + 16 * rt + t16];  // L[16 rt + m][C0 + k]
+        const double bv = Lt[(C0 + 4 * s + q) * LT + 16 * ct + t16];  // L[16 ct + n][C0 + k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(16 * rt + q + 4 * r) * LDP + 16 * ct + t16] -= acc[r];
+    }
+  (void)NT;
 }
 
 __global__ void __launch_bounds__(256)
@@ -154,30 +230,49 @@ k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict
   const int r0 = j0 + NB * (int)blockIdx.x;
   const int nrows = is_z ? 1 : min(NB, p - r0);
 
-  if (wave == 0) {
-    double a[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) a[k] = P[lane * LDP + k];
-    bool bad = false;
-    double piv = readlane_d(a[0], 0);
-    potrf_cols(std::make_integer_sequence<int, NB>{}, a, piv, bad, Lt, dinv, lane);
-    if (bad && blockIdx.x == 0 && lane == 0) atomicMax(info, j0 + 1);
-  } else if (blockIdx.x != 0) {
-    // panel rows of this workgroup -> Ap (coalesced rows, zero padding), waves 1-3
-    const int lc = min(lane, jb - 1);
-    const double *src = is_z ? z + j0 + lc : H + (size_t)min(r0, p - 1) * p + j0 + lc;
+  // The diagonal block in four blocks of 16 columns: wave 0 factorises a block in registers
+  // (the serial part: a pivot chain of ~170 cycles per column), then all four waves apply it to
+  // the columns to its right on the matrix cores.  (One wave doing the whole rank-1 update of
+  // every column, 64 columns wide, took 555 cycles per column: 36 of the step's 52 thousand.)
+  // Waves 1-3 meanwhile fetch the workgroup's panel rows: the loads go out now, the values
+  // are parked in registers and written to Ap before the last barrier.
+  bool bad = false;
+  double stage[24];
+  const int lcs = min(lane, jb - 1);
+  if (wave != 0 && blockIdx.x != 0) {
+    const double *src = is_z ? z + j0 + lcs : H + (size_t)min(r0, p - 1) * p + j0 + lcs;
     const size_t pitch = is_z ? 0 : (size_t)p;
     const int rmax = max(nrows - 1, 0);
-    for (int rb = (wave - 1) * 8; rb < NB; rb += 24) {
-      double t[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = src[(size_t)min(rb + i, rmax) * pitch];
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        stage[it * 8 + i] = src[(size_t)min((wave - 1) * 8 + it * 24 + i, rmax) * pitch];
+  }
+  if (wave == 0) potrf_block<0>(P, bad, Lt, dinv, lane);
+  __syncthreads();
+  potrf_trailing<0>(P, Lt, wave, lane);
+  __syncthreads();
+  if (wave == 0) potrf_block<16>(P, bad, Lt, dinv, lane);
+  __syncthreads();
+  potrf_trailing<16>(P, Lt, wave, lane);
+  __syncthreads();
+  if (wave == 0) potrf_block<32>(P, bad, Lt, dinv, lane);
+  __syncthreads();
+  potrf_trailing<32>(P, Lt, wave, lane);
+  __syncthreads();
+  if (wave == 0) {
+    potrf_block<48>(P, bad, Lt, dinv, lane);
+    if (bad && blockIdx.x == 0 && lane == 0) atomicMax(info, j0 + 1);
+  } else if (blockIdx.x != 0) {
+    // panel rows of this workgroup -> Ap (zero padding), waves 1-3
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int r = rb + i;
-        if (r < NB) Ap[r * LDP + lane] = (r < nrows && lane < jb) ? t[i] : 0.0;
+        const int r = (wave - 1) * 8 + it * 24 + i;
+        if (r < NB) Ap[r * LDP + lane] = (r < nrows && lane < jb) ? stage[it * 8 + i] : 0.0;
       }
-    }
   }
   __syncthreads();  // Lt, dinv, Ap complete; P (diagonal block) is free
 
@@ -260,22 +355,27 @@ k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict
   }
 }
 
-// Trailing update of one 128 x 128 lower tile: D = H - L21_i L21_j^T.  Latency-shaped: the
-// panel was written by the previous kernel (other XCDs' L2s), so every dependent global
-// access is a trip to Infinity Cache / HBM.  Everything the block needs is therefore
-// requested up front -- both 128 x 64 operand panels (16-byte pieces of the k-major copy,
-// staged in LDS) and the H tile itself, straight into the accumulators -- so the block pays
-// one memory round trip, 256 MFMAs per wave from LDS, and a store.
-constexpr int UP = 128 + 16;  // LDS pitch of a staged panel row (doubles)
-
-__global__ void __launch_bounds__(256)
+// Trailing update of one TS x TS lower tile (TS = 128, or 64 once the trailing matrix has too
+// few 128-tiles to go round the CUs): D = H - L21_i L21_j^T.  Latency-shaped: the panel was
+// written by the previous kernel (other XCDs' L2s), so every dependent global access is a trip
+// to Infinity Cache / HBM.  Everything the block needs is therefore requested up front -- both
+// TS x KH operand panels (16-byte pieces of the k-major copy, staged in LDS) and the H tile
+// itself, straight into the accumulators -- so the block pays one memory round trip, its MFMAs
+// from LDS (256 per wave at TS = 128, k = 64: 16 thousand cycles of the CU's matrix pipe), and
+// a store.
+// KH = k per staged part.  Workgroups per CU by LDS: TS 128, KH 64 -> 1; 128, 32 -> 2; 64, 32 -> 3.
+template <int TS, int KH>
+__global__ void __launch_bounds__(256, TS == 64 ? 3 : (KH == 32 ? 2 : 1))
 k_chol_update(double *__restrict__ H, double *__restrict__ z, const double *__restrict__ Wt, int pw,
               int p, int t0 /* first trailing row / column */, int kparts /* staged halves of 64 k */,
               int strip /* 1: only the columns [t0, t0 + 64) */, int ntiles,
               int ljj_j0 /* where the panel's L_jj goes */, int zj0 /* panel whose z part is applied */,
               int zk0 /* its first row in Wt */, const double *__restrict__ Ljj) {
-  __shared__ __attribute__((aligned(16))) double Sa[NB * UP];
-  __shared__ __attribute__((aligned(16))) double Sb[NB * UP];
+  constexpr int UP = TS + 16;   // LDS pitch of a staged panel row (doubles)
+  constexpr int HW = TS / 2;    // wave tile edge; also the 16-byte pieces per staged row
+  constexpr int F = TS / 32;    // 16 x 16 MFMA tiles per wave-tile edge
+  __shared__ __attribute__((aligned(16))) double Sa[KH * UP];
+  __shared__ __attribute__((aligned(16))) double Sb[KH * UP];
   if ((int)blockIdx.x >= ntiles) {
     if ((int)blockIdx.x == ntiles)  // L_jj from the panel step's scratch block into place
       for (int e = threadIdx.x; e < NB * NB; e += 256)
@@ -309,67 +409,68 @@ k_chol_update(double *__restrict__ H, double *__restrict__ z, const double *__re
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // strictly upper 64 x 64 quadrant of a diagonal tile: no work; strip: the left half only
-  const bool active = strip ? (wn == 0) : !(bi == bj && wn > wm);
+  // strictly upper quadrant of a diagonal tile: no work; strip: the first 64 columns only
+  const bool active = strip ? (wn * HW < NB) : !(bi == bj && wn > wm);
   const int t16 = lane & 15, q = lane >> 4;
-  const int rbase = t0 + bi * 128 + wm * 64, cbase = t0 + bj * 128 + wn * 64;
+  const int rbase = t0 + bi * TS + wm * HW, cbase = t0 + bj * TS + wn * HW;
 
   // H tile into the accumulators (rows / columns beyond p or above the diagonal: zero)
-  d4 acc[4][4];
+  d4 acc[F][F];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < F; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < F; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rbase + i * 16 + q + 4 * r, col = cbase + j * 16 + t16;
         acc[i][j][r] = (active && row < p && col <= row) ? H[(size_t)row * p + col] : 0.0;
       }
-  for (int part = 0; part < kparts; ++part) {
-    // panels: 64 k x 128 rows each = 4096 16-byte pieces per panel, 16 per thread
-    d2v ga[16], gb[16];
+  constexpr int NU = KH * HW / 256;  // 16-byte pieces per thread and panel part
+  for (int part = 0; part < kparts * (NB / KH); ++part) {
+    // panels: KH k x TS rows each, in 16-byte pieces
+    d2v ga[NU], gb[NU];
     {
-      const double *srca = Wt + (size_t)part * NB * pw + t0 + bi * 128;
-      const double *srcb = Wt + (size_t)part * NB * pw + t0 + bj * 128;
+      const double *srca = Wt + (size_t)part * KH * pw + t0 + bi * TS;
+      const double *srcb = Wt + (size_t)part * KH * pw + t0 + bj * TS;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int e = tid + 256 * u, k = e >> 6, c2 = e & 63;
+      for (int u = 0; u < NU; ++u) {
+        const int e = tid + 256 * u, k = e / HW, c2 = e % HW;
         ga[u] = *(const d2v *)(srca + (size_t)k * pw + 2 * c2);
         gb[u] = *(const d2v *)(srcb + (size_t)k * pw + 2 * c2);
       }
     }
-    if (part > 0) __syncthreads();  // the previous half has been consumed
+    if (part > 0) __syncthreads();  // the previous part has been consumed
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e = tid + 256 * u, k = e >> 6, c2 = e & 63;
+    for (int u = 0; u < NU; ++u) {
+      const int e = tid + 256 * u, k = e / HW, c2 = e % HW;
       *(d2v *)&Sa[k * UP + 2 * c2] = ga[u];
       *(d2v *)&Sb[k * UP + 2 * c2] = gb[u];
     }
     __syncthreads();
     if (active) {
-      const double *pa = Sa + q * UP + wm * 64 + t16;
-      const double *pb = Sb + q * UP + wn * 64 + t16;
+      const double *pa = Sa + q * UP + wm * HW + t16;
+      const double *pb = Sb + q * UP + wn * HW + t16;
 #pragma unroll 4
-      for (int s = 0; s < 16; ++s) {
-        double a[4], b[4];
+      for (int s = 0; s < KH / 4; ++s) {
+        double a[F], b[F];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < F; ++f) {
           a[f] = -pa[4 * s * UP + 16 * f];
           b[f] = pb[4 * s * UP + 16 * f];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < F; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < F; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
   }
   if (!active) return;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < F; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < F; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rbase + i * 16 + q + 4 * r;
@@ -499,40 +600,53 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
     // Two panels per trailing pass pay off once the update is HBM-bound (63.6 -> 52.7 ms at
     // p = 16384); at p = 4096 the steps are latency-bound and the extra strip launch costs 5 %.
     const bool two = p >= 8192;
+    // staged k per part: 32 leaves room for two workgroups per CU, which pays when the update
+    // is bandwidth-bound (p = 16384: 50.8 -> 43.5 ms) and costs 5 % when it is not (p = 4096)
+    const int kh = getenv("OBHIP_CHOL_KH") ? atoi(getenv("OBHIP_CHOL_KH")) : (two ? 32 : 64);
+    // 64 x 64 tiles (a quarter of the MFMAs and loads per workgroup, three workgroups per CU)
+    // unless there are thousands of 128 x 128 ones: p = 4096 2.67 -> 2.27 ms with them
+    // throughout, p = 16384 43.8 -> 41.0 ms with them below 5000 tiles
+    const int t64_below = getenv("OBHIP_CHOL_T64") ? atoi(getenv("OBHIP_CHOL_T64")) : 5000;
+    // trailing rows / columns from t0 on with the panel(s) in Wt; strip: the next 64 columns only
+    auto update = [&](int t0, int kparts, int strip, int ljj_j0, int zj0, int zk0) {
+      const int m = p - t0;
+      const int nt128 = (m + 127) / 128, work128 = strip ? nt128 : nt128 * (nt128 + 1) / 2;
+      const int nz = (m + 255) / 256;
+      if (work128 < t64_below) {
+        const int nt = (m + 63) / 64, work = strip ? nt : nt * (nt + 1) / 2;
+        hipLaunchKernelGGL((k_chol_update<64, 32>), dim3((unsigned)(work + nz)), dim3(256), 0, st, d_H, z,
+                           Wt, pw, p, t0, kparts, strip, work, ljj_j0, zj0, zk0, Ljj);
+      } else if (kh == 32) {
+        hipLaunchKernelGGL((k_chol_update<128, 32>), dim3((unsigned)(work128 + nz)), dim3(256), 0, st, d_H,
+                           z, Wt, pw, p, t0, kparts, strip, work128, ljj_j0, zj0, zk0, Ljj);
+      } else {
+        hipLaunchKernelGGL((k_chol_update<128, 64>), dim3((unsigned)(work128 + nz)), dim3(256), 0, st, d_H,
+                           z, Wt, pw, p, t0, kparts, strip, work128, ljj_j0, zj0, zk0, Ljj);
+      }
+    };
     for (int j0 = 0; !two && j0 < p; j0 += NB) {
       panel(j0, 0);
-      const int m = p - (j0 + NB);
-      if (m <= 0) {
+      if (p - (j0 + NB) <= 0) {
         OB_TRY(place_ljj(j0));
         break;
       }
-      const int nt = (m + 127) / 128, npairs = nt * (nt + 1) / 2, nz = (m + 255) / 256;
-      hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(npairs + nz)), dim3(256), 0, st, d_H, z, Wt, pw,
-                         p, j0 + NB, 1, 0, npairs, j0, j0, 0, Ljj);
+      update(j0 + NB, 1, 0, j0, j0, 0);
     }
     for (int j0 = 0; two && j0 < p; j0 += 2 * NB) {
       panel(j0, 0);
-      const int m1 = p - (j0 + NB);
-      if (m1 <= 0) {
+      if (p - (j0 + NB) <= 0) {
         OB_TRY(place_ljj(j0));
         break;
       }
-      {  // the next panel's 64 columns (all rows below), z for everything below, L_jj of panel j0
-        const int nt = (m1 + 127) / 128, nz = (m1 + 255) / 256;
-        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(nt + nz)), dim3(256), 0, st, d_H, z, Wt, pw,
-                           p, j0 + NB, 1, 1, nt, j0, j0, 0, Ljj);
-      }
+      // the next panel's 64 columns (all rows below), z for everything below, L_jj of panel j0
+      update(j0 + NB, 1, 1, j0, j0, 0);
       panel(j0 + NB, NB);
-      const int m2 = p - (j0 + 2 * NB);
-      if (m2 <= 0) {
+      if (p - (j0 + 2 * NB) <= 0) {
         OB_TRY(place_ljj(j0 + NB));
         break;
       }
-      {  // the trailing matrix once with both panels (k = 128), z with the second panel
-        const int nt = (m2 + 127) / 128, npairs = nt * (nt + 1) / 2, nz = (m2 + 255) / 256;
-        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(npairs + nz)), dim3(256), 0, st, d_H, z, Wt,
-                           pw, p, j0 + 2 * NB, 2, 0, npairs, j0 + NB, j0 + NB, NB, Ljj);
-      }
+      // the trailing matrix once with both panels (k = 128), z with the second panel
+      update(j0 + 2 * NB, 2, 0, j0 + NB, j0 + NB, NB);
     }
     OB_HIP(hipGetLastError());
   }
