@@ -6,20 +6,21 @@
 // H is p x p, row-major, full symmetric storage on entry; on exit its lower
 // triangle holds L (H = L L^T), the strict upper triangle is scratch.
 //
-// Two 64-column panels per trailing update (rank 128): panel j, a strip update of the next 64
-// columns only, panel j + 1, then ONE pass over the trailing matrix with both panels (k = 128
-// in two LDS-staged halves).  The trailing update is HBM-bound from p ~ 4096 up (it reads and
-// writes the whole trailing triangle); this halves that traffic.
+// Two 64-column panels per trailing update (rank 128) from p = 4096 up: panel j, a strip update
+// of the next 64 columns only, panel j + 1, then ONE pass over the trailing matrix with both
+// panels (k = 128, staged through LDS in parts).  The trailing update reads and writes the whole
+// trailing triangle; this halves that traffic.
 //   k_chol_panel2: every workgroup re-factorises the 64 x 64 diagonal block itself
-//                  (cheaper than a launch boundary) and solves its 64 panel rows against
-//                  L_jj^T on the matrix cores (details at the kernel).  One extra "row" is
-//                  the right-hand side z, which turns the forward substitution L z = rhs
-//                  into part of the panel solve.  The solved rows also go to a k-major
-//                  scratch copy Wt[k][row] for the update.
+//                  (cheaper than a launch boundary) -- four 16-column blocks, wave 0 in
+//                  registers, the columns to the right on the matrix cores by all waves --
+//                  and solves its 64 panel rows against L_jj^T on the matrix cores (details at
+//                  the kernel).  One extra "row" is the right-hand side z, which turns the
+//                  forward substitution L z = rhs into part of the panel solve.  The solved
+//                  rows also go to a k-major scratch copy Wt[k][row] for the update.
 //   k_chol_update: trailing update A22 -= L21 L21^T (lower tiles only) on
-//                  v_mfma_f64_16x16x4_f64, 128 x 128 tiles, K = 64 per staged half, operands
-//                  straight from Wt in 128-byte segments; plus the matching update of z.
-//                  Strip form: the 64 columns of the next panel only.
+//                  v_mfma_f64_16x16x4_f64, 64 x 64 tiles (three workgroups per CU; 128 x 128
+//                  only beyond 5000 tiles), operands straight from Wt in 16-byte pieces; plus
+//                  the matching update of z.  Strip form: the 64 columns of the next panel only.
 // Backward: k_chol_back per block from the last to the first: theta_j =
 // L_jj^-T z_j, then z[0:j) -= L[j, 0:j)^T theta_j.
 #include <utility>
@@ -597,9 +598,10 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
       hipLaunchKernelGGL(k_chol_panel2, dim3((unsigned)(nrowblk + 1)), dim3(256), 0, st, d_H, z, Wt,
                          pw, p, j0, info, Ljj, wt_row0);
     };
-    // Two panels per trailing pass pay off once the update is HBM-bound (63.6 -> 52.7 ms at
-    // p = 16384); at p = 4096 the steps are latency-bound and the extra strip launch costs 5 %.
-    const bool two = p >= 8192;
+    // Two panels per trailing pass: half the passes over the trailing matrix for one more (strip)
+    // launch per pair of panels.  p = 16384: 60.1 -> 41.2 ms; p = 4096: 2.26 -> 2.17 ms (with the
+    // 128 x 128 update tiles and the slower panel step of before it cost 5 % there).
+    const bool two = p >= (getenv("OBHIP_CHOL_TWO_FROM") ? atoi(getenv("OBHIP_CHOL_TWO_FROM")) : 4096);
     // staged k per part: 32 leaves room for two workgroups per CU, which pays when the update
     // is bandwidth-bound (p = 16384: 50.8 -> 43.5 ms) and costs 5 % when it is not (p = 4096)
     const int kh = getenv("OBHIP_CHOL_KH") ? atoi(getenv("OBHIP_CHOL_KH")) : (two ? 32 : 64);
