@@ -21,8 +21,9 @@
 //                  v_mfma_f64_16x16x4_f64, 64 x 64 tiles (three workgroups per CU; 128 x 128
 //                  only beyond 5000 tiles), operands straight from Wt in 16-byte pieces; plus
 //                  the matching update of z.  Strip form: the 64 columns of the next panel only.
-// Backward: k_chol_back per block from the last to the first: theta_j =
-// L_jj^-T z_j, then z[0:j) -= L[j, 0:j)^T theta_j.
+// Backward: k_chol_back per block from the last to the first: theta_j = L_jj^-T z_j with the
+// inverses of the 16 x 16 diagonal sub-blocks the panel step kept, then
+// z[0:j) -= L[j, 0:j)^T theta_j.
 #include <utility>
 
 #include "obhip_internal.h"
@@ -202,7 +203,8 @@ __device__ __forceinline__ void potrf_trailing(double *P, const double *Lt, int 
 
 __global__ void __launch_bounds__(256)
 k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict__ Wt, int pw, int p,
-              int j0, int *__restrict__ info, double *__restrict__ Ljj, int wt_row0) {
+              int j0, int *__restrict__ info, double *__restrict__ Ljj, int wt_row0,
+              double *__restrict__ Iinv) {
   __shared__ __attribute__((aligned(16))) double Lt[NB * LT];  // Lt[c][k] = L[k][c], 0 for k < c
   __shared__ double P[NB * LDP];    // diagonal block; later X (solved rows), per wave 16 rows
   __shared__ double Ap[NB * LDP];   // panel rows
@@ -305,6 +307,10 @@ k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict
     }
   }
   __syncthreads();
+  // the four 16 x 16 inverses are kept for the backward substitution (k_chol_back*)
+  if (is_z)
+    for (int e = tid; e < 4 * 256; e += 256)
+      Iinv[(size_t)(j0 / NB) * 1024 + e] = Iw[(e >> 8) * 16 * SP + ((e >> 4) & 15) * SP + (e & 15)];
 
   // blocked solve, wave w owns rows 16 w .. 16 w + 15; everything below is wave-local
   const int t16 = lane & 15, q = lane >> 4;
@@ -480,14 +486,42 @@ k_chol_update(double *__restrict__ H, double *__restrict__ z, const double *__re
       }
 }
 
+// L^T theta = z for one 64 x 64 diagonal block (Ld, LDS) from the last 16 unknowns to the first,
+// with the inverses of its four 16 x 16 diagonal sub-blocks as the panel step left them (Iv:
+// [4][16][16] in LDS): theta_b = inv(L_bb)^T z_b, then z[i] -= sum_k L[16 b + k][i] theta_b[k] for
+// the unknowns above.  Lane = unknown.  Two groups of 16 v_readlane pairs and 16 FMAs (in four
+// partial sums) per sub-block instead of 64 dependent readlane - multiply - FMA steps.
+__device__ __forceinline__ double back_solve64(const double *Ld, const double *Iv, double zk, int lane) {
+  double th = 0.0;
+  const int il = lane & 15;
+#pragma unroll
+  for (int b = 3; b >= 0; --b) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      acc[r & 3] = fma(Iv[b * 256 + r * 16 + il], readlane_d(zk, 16 * b + r), acc[r & 3]);
+    const double tb = (acc[0] + acc[1]) + (acc[2] + acc[3]);  // theta_b[il] in every 16-lane row
+    if ((lane >> 4) == b) th = tb;
+    if (b > 0) {
+      double upd[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        upd[k & 3] = fma(Ld[(16 * b + k) * LDP + lane], readlane_d(tb, k), upd[k & 3]);
+      if (lane < 16 * b) zk -= (upd[0] + upd[1]) + (upd[2] + upd[3]);
+    }
+  }
+  return th;
+}
+
 __global__ void __launch_bounds__(256)
 k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__restrict__ theta, int p,
-            int j0) {
+            int j0, const double *__restrict__ Iinv) {
   __shared__ double Ld[NB * LDP];
+  __shared__ double Iv[4 * 256];
   __shared__ double th[NB];
   const int jb = min(NB, p - j0);
   // This thread's column c of the 64 rows of L it will need for z[c] -= L[j0 + k][c] theta_k:
-  // they do not depend on theta, so they are fetched now and arrive under the serial solve.
+  // they do not depend on theta, so they are fetched now and arrive under the solve.
   const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
   double lc[NB], zc = 0.0;
   if (c < j0) {
@@ -496,37 +530,27 @@ k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__rest
     for (int k = 0; k < NB; ++k) lc[k] = L[(size_t)(j0 + min(k, jb - 1)) * p + c];
   }
   {
-    double t[NB * NB / 256];
+    double t[NB * NB / 256], ti[4];
 #pragma unroll
     for (int i = 0; i < NB * NB / 256; ++i) {
       const int e = threadIdx.x + i * 256;
       t[i] = L[(size_t)(j0 + min(e / NB, jb - 1)) * p + j0 + min(e % NB, jb - 1)];
     }
 #pragma unroll
+    for (int i = 0; i < 4; ++i) ti[i] = Iinv[(size_t)(j0 / NB) * 1024 + threadIdx.x + i * 256];
+#pragma unroll
     for (int i = 0; i < NB * NB / 256; ++i) {
       const int e = threadIdx.x + i * 256;
       const int r = e / NB, cc = e % NB;
       Ld[r * LDP + cc] = (r < jb && cc < jb && cc <= r) ? t[i] : ((r == cc) ? 1.0 : 0.0);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Iv[threadIdx.x + i * 256] = ti[i];
   }
   __syncthreads();
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
-    double zk = lane < jb ? z[j0 + lane] : 0.0;
-    // L_jj^T theta = z, from the last unknown to the first.  The 64 divisions happen up
-    // front in parallel (one Newton-corrected reciprocal per lane), so that the serial chain
-    // per unknown is readlane - multiply - fma.  (With the 16 x 16 inverses of the panel
-    // step the chain would be 4 x 32 dependent FMAs instead of 64 x 3 operations: ~0.4 of
-    // the ~1 us this loop takes out of the step's 7; not done.)
-    const double dl = Ld[lane * LDP + lane];
-    double rinv = 1.0 / dl;
-    rinv = fma(fma(-dl, rinv, 1.0), rinv, rinv);
-#pragma unroll 8
-    for (int cc = NB - 1; cc >= 0; --cc) {
-      const double tc = readlane_d(zk, cc) * readlane_d(rinv, cc);
-      if (lane == cc) zk = tc;
-      if (lane < cc) zk = fma(-Ld[cc * LDP + lane], tc, zk);
-    }
+    const double zk = back_solve64(Ld, Iv, lane < jb ? z[j0 + lane] : 0.0, lane);
     th[lane] = lane < jb ? zk : 0.0;  // rows past the end (ragged last block) add nothing
     if (blockIdx.x == 0 && lane < jb) theta[j0 + lane] = zk;
   }
@@ -554,10 +578,11 @@ __global__ void k_form_hessian(double *__restrict__ G, const double *__restrict_
 }  // namespace
 
 // z (p), info (64 doubles reserved), k-major copies of two panels Wt (128 rows of
-// chol_pitch(p) doubles), scratch block for L_jj (64 x 64)
+// chol_pitch(p) doubles), scratch block for L_jj (64 x 64), the inverses of the 16 x 16
+// diagonal sub-blocks (1024 doubles per 64 columns)
 static uint64_t chol_pitch(uint64_t p) { return (p + 127) / 128 * 128 + 128; }
 uint64_t newton_workspace_bytes(uint64_t p) {
-  return (p + 64 + 2 * NB * chol_pitch(p) + NB * NB) * sizeof(double);
+  return (p + 64 + 2 * NB * chol_pitch(p) + NB * NB + ((p + NB - 1) / NB) * 1024) * sizeof(double);
 }
 
 int launch_form_hessian(uint64_t p, double *d_G, const double *d_prec, double e2, double *d_diagH) {
@@ -579,6 +604,7 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
   double *Wt = z + p + 64;
   const int pw = (int)chol_pitch(p64);
   double *Ljj = Wt + (size_t)2 * NB * pw;
+  double *Iinv = Ljj + NB * NB;  // [p / 64][4][16][16]: inverses of the 16 x 16 diagonal sub-blocks
   hipStream_t st = cur_stream();
   OB_HIP(hipMemsetAsync(Wt, 0, sizeof(double) * 2 * NB * pw, st));  // rows beyond p stay zero
   OB_HIP(hipMemcpyAsync(z, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, st));
@@ -596,7 +622,7 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
     auto panel = [&](int j0, int wt_row0) {
       const int nrowblk = (p - j0 + NB - 1) / NB;  // block 0 = diagonal block
       hipLaunchKernelGGL(k_chol_panel2, dim3((unsigned)(nrowblk + 1)), dim3(256), 0, st, d_H, z, Wt,
-                         pw, p, j0, info, Ljj, wt_row0);
+                         pw, p, j0, info, Ljj, wt_row0, Iinv);
     };
     // Two panels per trailing pass: half the passes over the trailing matrix for one more (strip)
     // launch per pair of panels.  p = 16384: 60.1 -> 41.2 ms; p = 4096: 2.26 -> 2.17 ms (with the
@@ -654,10 +680,12 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
   }
   {
     ProfScope ps("backsolve");
-    const int last = (p - 1) / NB * NB;
-    for (int j0 = last; j0 >= 0; j0 -= NB) {
+    // blocks of 64 columns from the last to the first.  (Two blocks per launch, with the
+    // hand-over inside the workgroup, was measured: 0.43 instead of 0.39 ms at p = 4096 -- the
+    // launches are not what a step costs.)
+    for (int j0 = (p - 1) / NB * NB; j0 >= 0; j0 -= NB) {
       const int nblk = std::max(1, (j0 + 255) / 256);
-      hipLaunchKernelGGL(k_chol_back, dim3((unsigned)nblk), dim3(256), 0, st, d_H, z, d_theta, p, j0);
+      hipLaunchKernelGGL(k_chol_back, dim3((unsigned)nblk), dim3(256), 0, st, d_H, z, d_theta, p, j0, Iinv);
     }
     OB_HIP(hipGetLastError());
   }
