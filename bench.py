@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-backend", action="store_true")
     ap.add_argument("--no-config3", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=200000)
+    ap.add_argument("--cpu-sample", type=int, default=400000)
     return ap.parse_args()
 
 
