@@ -370,9 +370,10 @@ k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict
 // itself, straight into the accumulators -- so the block pays one memory round trip, its MFMAs
 // from LDS (256 per wave at TS = 128, k = 64: 16 thousand cycles of the CU's matrix pipe), and
 // a store.
-// KH = k per staged part.  Workgroups per CU by LDS: TS 128, KH 64 -> 1; 128, 32 -> 2; 64, 32 -> 3.
+// KH = k per staged part (32).  Workgroups per CU by LDS: TS 128 -> 2, TS 64 -> 3 (with KH = 64 and
+// one 128-tile workgroup per CU the update of p = 16384 took 50.8 instead of 43.5 ms).
 template <int TS, int KH>
-__global__ void __launch_bounds__(256, TS == 64 ? 3 : (KH == 32 ? 2 : 1))
+__global__ void __launch_bounds__(256, TS == 64 ? 3 : 2)
 k_chol_update(double *__restrict__ H, double *__restrict__ z, const double *__restrict__ Wt, int pw,
               int p, int t0 /* first trailing row / column */, int kparts /* staged halves of 64 k */,
               int strip /* 1: only the columns [t0, t0 + 64) */, int ntiles,
@@ -628,9 +629,6 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
     // launch per pair of panels.  p = 16384: 60.1 -> 41.2 ms; p = 4096: 2.26 -> 2.17 ms (with the
     // 128 x 128 update tiles and the slower panel step of before it cost 5 % there).
     const bool two = p >= (getenv("OBHIP_CHOL_TWO_FROM") ? atoi(getenv("OBHIP_CHOL_TWO_FROM")) : 4096);
-    // staged k per part: 32 leaves room for two workgroups per CU, which pays when the update
-    // is bandwidth-bound (p = 16384: 50.8 -> 43.5 ms) and costs 5 % when it is not (p = 4096)
-    const int kh = getenv("OBHIP_CHOL_KH") ? atoi(getenv("OBHIP_CHOL_KH")) : (two ? 32 : 64);
     // 64 x 64 tiles (a quarter of the MFMAs and loads per workgroup, three workgroups per CU)
     // unless there are thousands of 128 x 128 ones: p = 4096 2.67 -> 2.27 ms with them
     // throughout, p = 16384 43.8 -> 41.0 ms with them below 5000 tiles
@@ -644,11 +642,8 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
         const int nt = (m + 63) / 64, work = strip ? nt : nt * (nt + 1) / 2;
         hipLaunchKernelGGL((k_chol_update<64, 32>), dim3((unsigned)(work + nz)), dim3(256), 0, st, d_H, z,
                            Wt, pw, p, t0, kparts, strip, work, ljj_j0, zj0, zk0, Ljj);
-      } else if (kh == 32) {
-        hipLaunchKernelGGL((k_chol_update<128, 32>), dim3((unsigned)(work128 + nz)), dim3(256), 0, st, d_H,
-                           z, Wt, pw, p, t0, kparts, strip, work128, ljj_j0, zj0, zk0, Ljj);
       } else {
-        hipLaunchKernelGGL((k_chol_update<128, 64>), dim3((unsigned)(work128 + nz)), dim3(256), 0, st, d_H,
+        hipLaunchKernelGGL((k_chol_update<128, 32>), dim3((unsigned)(work128 + nz)), dim3(256), 0, st, d_H,
                            z, Wt, pw, p, t0, kparts, strip, work128, ljj_j0, zj0, zk0, Ljj);
       }
     };
