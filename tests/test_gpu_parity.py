@@ -819,7 +819,7 @@ def test_full_hessian_marginal_adjustment_after_optnewton():
     assert relerr(lp.gradpara, np.array([gp[0] + mgl, pgp[0] + mgp])) < 1e-8
 
 
-@pytest.mark.parametrize("p", [1, 2, 63, 64, 65, 127, 128, 129, 1000, 4097, 8192, 8257, 8385])
+@pytest.mark.parametrize("p", [1, 2, 63, 64, 65, 127, 128, 129, 1000, 3000, 4096, 4097, 4160, 8192, 8257, 8385])
 def test_newton_solve_sizes_against_library_solve(p):
     """obhip_newton_solve_dev (Cholesky + two triangular solves, fit.cpp:120) on random SPD
     systems of awkward sizes (single element, one block, ragged blocks, tile edges)
