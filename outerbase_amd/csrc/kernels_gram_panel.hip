@@ -332,10 +332,13 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
     if (tid < kGT) part[(uint64_t)J * ldo + (uint64_t)I * kGT + tid] = red[tid] + red[kGT + tid];
   }
   if constexpr (DBG) {
-    if (dbgout && blockIdx.x == gridDim.x / 2 + 7 && tid == 0) {
-      dbgout[0] = __builtin_amdgcn_s_memtime() - st0;
-      dbgout[1] = __builtin_amdgcn_s_memrealtime() - sr0;
-      dbgout[2] = nchunks;
+    // one block of the first round of 512, one of the middle, one of the last
+    const unsigned which = blockIdx.x == 7 ? 1u : blockIdx.x == gridDim.x / 2 + 7 ? 0u
+                           : blockIdx.x + 512 - 7 == gridDim.x - (gridDim.x % 512 ? gridDim.x % 512 : 0) ? 2u : 3u;
+    if (dbgout && which < 3 && tid == 0) {
+      dbgout[3 * which] = __builtin_amdgcn_s_memtime() - st0;
+      dbgout[3 * which + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
+      dbgout[3 * which + 2] = nchunks;
     }
   }
 }
@@ -473,7 +476,7 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   }
   const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
   double *part = nullptr;
-  OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 64, (void **)&part));
+  OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 128, (void **)&part));
   unsigned long long *dbgout =
       dbg ? (unsigned long long *)(part + (size_t)nsplit * npairs * kGT * kGT) : nullptr;
   if (b.gram_pairs_nb != nb || b.gram_pairs_ns != (int)nsplit) {
@@ -503,8 +506,10 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
     OB_HIP(hipGetLastError());
   }
   if (dbgout) {
-    unsigned long long h[3];
+    unsigned long long h[9];
     OB_HIP(hipMemcpy(h, dbgout, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[gram dbg] clock of a block of the first / middle / last round: %.0f / %.0f / %.0f MHz\n",
+            h[4] ? 100.0 * h[3] / h[4] : 0.0, h[1] ? 100.0 * h[0] / h[1] : 0.0, h[7] ? 100.0 * h[6] / h[7] : 0.0);
     fprintf(stderr,
             "[gram dbg] one block: %llu shader-clock ticks in %llu x 10 ns -> %.0f MHz, %.0f ticks "
             "per 16-row chunk (8192 = matrix pipe saturated by two blocks)\n",
