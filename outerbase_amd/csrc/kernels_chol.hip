@@ -514,21 +514,26 @@ __device__ __forceinline__ double back_solve64(const double *Ld, const double *I
   return th;
 }
 
+template <int CB>  // columns of the z update per workgroup
 __global__ void __launch_bounds__(256)
 k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__restrict__ theta, int p,
             int j0, const double *__restrict__ Iinv) {
+  constexpr int KG = 256 / CB, KR = NB / KG;  // groups of threads along k, rows per group
   __shared__ double Ld[NB * LDP];
   __shared__ double Iv[4 * 256];
   __shared__ double th[NB];
+  __shared__ double red[256];
   const int jb = min(NB, p - j0);
-  // This thread's column c of the 64 rows of L it will need for z[c] -= L[j0 + k][c] theta_k:
-  // they do not depend on theta, so they are fetched now and arrive under the solve.
-  const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  double lc[NB], zc = 0.0;
+  // A workgroup owns 64 columns c < j0 of the update z[c] -= sum_k L[j0 + k][c] theta_k: thread
+  // (kg, cl) takes column cl and the 16 rows k = 16 kg .. 16 kg + 15 (a single CU pulls 32 KB
+  // instead of 128, four times as many CUs pull).  The rows do not depend on theta, so they
+  // are fetched now and arrive under the solve.
+  const int cl = threadIdx.x % CB, kg = threadIdx.x / CB;
+  const int c = (int)blockIdx.x * CB + cl;
+  double lc[KR];
   if (c < j0) {
-    zc = z[c];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) lc[k] = L[(size_t)(j0 + min(k, jb - 1)) * p + c];
+    for (int k = 0; k < KR; ++k) lc[k] = L[(size_t)(j0 + min(KR * kg + k, jb - 1)) * p + c];
   }
   {
     double t[NB * NB / 256], ti[4];
@@ -556,10 +561,18 @@ k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__rest
     if (blockIdx.x == 0 && lane < jb) theta[j0 + lane] = zk;
   }
   __syncthreads();
+  double sum = 0.0;
   if (c < j0) {
 #pragma unroll
-    for (int k = 0; k < NB; ++k) zc = fma(-lc[k], th[k], zc);
-    z[c] = zc;
+    for (int k = 0; k < KR; ++k) sum = fma(lc[k], th[KR * kg + k], sum);
+  }
+  red[kg * CB + cl] = sum;
+  __syncthreads();
+  if (kg == 0 && c < j0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) tot += red[g * CB + cl];
+    z[c] -= tot;
   }
 }
 
@@ -679,8 +692,10 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
     // hand-over inside the workgroup, was measured: 0.43 instead of 0.39 ms at p = 4096 -- the
     // launches are not what a step costs.)
     for (int j0 = (p - 1) / NB * NB; j0 >= 0; j0 -= NB) {
-      const int nblk = std::max(1, (j0 + 255) / 256);
-      hipLaunchKernelGGL(k_chol_back, dim3((unsigned)nblk), dim3(256), 0, st, d_H, z, d_theta, p, j0, Iinv);
+      // 64 columns of the z update per workgroup (32: 0.29 instead of 0.30 ms at p = 4096 but
+      // 1.43 instead of 1.36 at 16384; 256, one thread per column: 0.39 / 1.85)
+      const int nblk = std::max(1, (j0 + NB - 1) / NB);
+      hipLaunchKernelGGL(k_chol_back<64>, dim3((unsigned)nblk), dim3(256), 0, st, d_H, z, d_theta, p, j0, Iinv);
     }
     OB_HIP(hipGetLastError());
   }

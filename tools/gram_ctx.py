@@ -40,9 +40,10 @@ def fresh():
     _lib.call("obhip_basis_destroy", hh)
 measure("fresh basis + materialise", fresh)
 
-def fresh_gap():
-    fresh()
-    torch.cuda.synchronize()
-    time.sleep(0.005)
-measure("fresh + 5 ms idle", fresh_gap)
+for gap_ms in (1.0, 2.5, 5.0, 20.0):
+    def fresh_gap():
+        fresh()
+        torch.cuda.synchronize()
+        time.sleep(gap_ms * 1e-3)
+    measure("fresh + %.1f ms idle" % gap_ms, fresh_gap)
 measure("whole step", lambda: hp.step())
