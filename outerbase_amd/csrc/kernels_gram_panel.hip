@@ -168,7 +168,7 @@ constexpr uint64_t kAtbNoTask = ~0ull;
 template <int MODE, bool DBG>
 __global__ void __launch_bounds__(256, 2)
 k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict__ Bm, uint64_t ldB,
-           int nb, int npairs, uint64_t ntiles, uint64_t tiles_per_split, int tri,
+           int nb, int npairs, uint64_t ntiles, uint64_t nsplit /* Gram: row splits */, int tri,
            const uint64_t *__restrict__ tasks, double *__restrict__ part, uint64_t ldo,
            unsigned long long *dbgout) {
   extern __shared__ double T[];  // [2][16][272]
@@ -190,8 +190,11 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
 
   uint64_t t0, t1;  // range of 64-row tiles of k
   if constexpr (MODE == kAtbGram) {
-    t0 = (uint64_t)ysplit * tiles_per_split;
-    t1 = min(ntiles, t0 + tiles_per_split);
+    // the row tiles in nsplit runs that differ by at most one tile (every block of a round
+    // the same length: 1954 tiles in 32 splits are 2 x 62 + 30 x 61, not 31 x 62 + 32)
+    const uint64_t base = ntiles / nsplit, rem = ntiles % nsplit, y = (uint64_t)ysplit;
+    t0 = y * base + min(y, rem);
+    t1 = t0 + base + (y < rem ? 1 : 0);
   } else {
     t0 = 0;
     t1 = tri ? min(ntiles, (uint64_t)(J + 1) * (kGT / kTileRows)) : ntiles;
@@ -467,14 +470,13 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   const uint64_t max_split = std::max<uint64_t>(
       1, std::min<uint64_t>({64, ntiles / 8, (4ull << 30) / ((uint64_t)npairs * kGT * kGT * 8)}));
   for (uint64_t ns = 1; ns <= max_split; ++ns) {
-    const uint64_t tp = (ntiles + ns - 1) / ns, nse = (ntiles + tp - 1) / tp;
-    const uint64_t rounds = (nse * npairs + slots - 1) / slots, cost = rounds * (tp + 2);
+    const uint64_t tp = (ntiles + ns - 1) / ns;  // the longest split
+    const uint64_t rounds = (ns * npairs + slots - 1) / slots, cost = rounds * (tp + 2);
     if (cost < best) {
       best = cost;
-      nsplit = nse;
+      nsplit = ns;
     }
   }
-  const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
   double *part = nullptr;
   OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 128, (void **)&part));
   unsigned long long *dbgout =
@@ -494,13 +496,13 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
       OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbGram, true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_atb_dma2<kAtbGram, true>), dim3(nblocks), dim3(256), lds, cur_stream(), d_B,
-                         t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, tps, 0, b.gram_pairs.p, part,
+                         t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, nsplit, 0, b.gram_pairs.p, part,
                          (uint64_t)0, dbgout);
     } else {
       OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbGram, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_atb_dma2<kAtbGram, false>), dim3(nblocks), dim3(256), lds, cur_stream(),
-                         d_B, t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, tps, 0, b.gram_pairs.p, part,
+                         d_B, t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, nsplit, 0, b.gram_pairs.p, part,
                          (uint64_t)0, nullptr);
     }
     OB_HIP(hipGetLastError());
