@@ -254,6 +254,8 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
   if (nchunks > 0) issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  unsigned long long sr1 = 0, sr2 = 0;
+  if constexpr (DBG) sr1 = __builtin_amdgcn_s_memrealtime();
   double a0[4], b0[4][4], a1[4], b1[4][4];
   constexpr int stp = 4 * kTP * 8;  // bytes per K step (4 rows)
 
@@ -288,6 +290,7 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
   }
 #undef OB_CHUNK_BODY2
 #undef OB_STEP
+  if constexpr (DBG) sr2 = __builtin_amdgcn_s_memrealtime();
 
   if constexpr (MODE == kAtbGram) {
     const int slot = I * nb - I * (I - 1) / 2 + (J - I);  // row-major index in the upper triangle
@@ -342,6 +345,17 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
       dbgout[3 * which] = __builtin_amdgcn_s_memtime() - st0;
       dbgout[3 * which + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
       dbgout[3 * which + 2] = nchunks;
+    }
+    // a block of the middle round and its successor one round on: start, first chunk landed,
+    // loop done, stores done (100 MHz)
+    const bool mid0 = blockIdx.x == gridDim.x / 2 + 7, mid1 = blockIdx.x == gridDim.x / 2 + 7 + 512;
+    if (dbgout && (mid0 || mid1) && tid == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long *o = dbgout + 9 + (mid1 ? 4 : 0);
+      o[0] = sr0;
+      o[1] = sr1;
+      o[2] = sr2;
+      o[3] = __builtin_amdgcn_s_memrealtime();
     }
   }
 }
@@ -478,7 +492,7 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
     }
   }
   double *part = nullptr;
-  OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 128, (void **)&part));
+  OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 256, (void **)&part));
   unsigned long long *dbgout =
       dbg ? (unsigned long long *)(part + (size_t)nsplit * npairs * kGT * kGT) : nullptr;
   if (b.gram_pairs_nb != nb || b.gram_pairs_ns != (int)nsplit) {
@@ -508,8 +522,12 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
     OB_HIP(hipGetLastError());
   }
   if (dbgout) {
-    unsigned long long h[9];
+    unsigned long long h[17];
     OB_HIP(hipMemcpy(h, dbgout, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[gram dbg] middle-round block: first chunk %.2f us, loop %.2f us, stores %.2f us; the block one round "
+                    "on starts %.2f us after this one ended (its first chunk %.2f us)\n",
+            0.01 * (double)(h[10] - h[9]), 0.01 * (double)(h[11] - h[10]), 0.01 * (double)(h[12] - h[11]),
+            0.01 * (double)((long long)h[13] - (long long)h[12]), 0.01 * (double)(h[14] - h[13]));
     fprintf(stderr, "[gram dbg] clock of a block of the first / middle / last round: %.0f / %.0f / %.0f MHz\n",
             h[4] ? 100.0 * h[3] / h[4] : 0.0, h[1] ? 100.0 * h[0] / h[1] : 0.0, h[7] ? 100.0 * h[6] / h[7] : 0.0);
     fprintf(stderr,
