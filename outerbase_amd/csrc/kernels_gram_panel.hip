@@ -472,25 +472,29 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   const bool dbg = getenv("OBHIP_GRAM_DBG") && atoi(getenv("OBHIP_GRAM_DBG")) != 0;
   const int nb = (int)((t.p + kGT - 1) / kGT);
   const int npairs = nb * (nb + 1) / 2;
-  // Row split: two blocks per CU at a time and all blocks equally long, so the launch takes
-  // ceil(blocks / slots) rounds of tiles-per-split each; pick the split that minimises that
-  // product (528 pairs x 32 splits = 33 x 512 exactly on MI355X), 2 tiles per block charged
-  // for its prologue and partial-tile write.
+  // Row split: two blocks per CU at a time and all blocks (nearly) equally long, so the launch
+  // takes ceil(blocks / slots) rounds of tiles-per-split each; pick the split that minimises
+  // that product (528 pairs x 32 splits = 33 x 512 exactly on MI355X).
   int ncu = 0;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b.device) != hipSuccess || ncu <= 0)
     ncu = 256;
   const uint64_t slots = 2 * (uint64_t)ncu;
-  uint64_t nsplit = 1, best = ~0ull;
+  uint64_t nsplit = 1;
   const uint64_t max_split = std::max<uint64_t>(
       1, std::min<uint64_t>({64, ntiles / 8, (4ull << 30) / ((uint64_t)npairs * kGT * kGT * 8)}));
+  // (the splits differ by at most one tile and the longer ones are few and dealt out first,
+  // so a round costs the average length; one tile charged for a block's first chunk, its
+  // partial-tile store and the hand-over of the slot: ~7 us measured, OBHIP_GRAM_DBG)
+  double bestc = 1e300;
   for (uint64_t ns = 1; ns <= max_split; ++ns) {
-    const uint64_t tp = (ntiles + ns - 1) / ns;  // the longest split
-    const uint64_t rounds = (ns * npairs + slots - 1) / slots, cost = rounds * (tp + 2);
-    if (cost < best) {
-      best = cost;
+    const uint64_t rounds = (ns * npairs + slots - 1) / slots;
+    const double cost = (double)rounds * ((double)ntiles / (double)ns + 1.0);
+    if (cost < bestc) {
+      bestc = cost;
       nsplit = ns;
     }
   }
+  if (const char *e = getenv("OBHIP_GRAM_NSPLIT")) nsplit = std::max<uint64_t>(1, std::min<uint64_t>(max_split, atoi(e)));
   double *part = nullptr;
   OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 256, (void **)&part));
   unsigned long long *dbgout =
