@@ -266,7 +266,7 @@ k_chol_panel2(double *__restrict__ H, double *__restrict__ z, double *__restrict
   __syncthreads();
   if (wave == 0) {
     potrf_block<48>(P, bad, Lt, dinv, lane);
-    if (bad && blockIdx.x == 0 && lane == 0) atomicMax(info, j0 + 1);
+    if (bad && blockIdx.x == 0 && lane == 0) atomicCAS(info, 0, j0 + 1);  // the first bad block stays (later ones inherit NaNs)
   } else if (blockIdx.x != 0) {
     // panel rows of this workgroup -> Ap (zero padding), waves 1-3
 #pragma unroll

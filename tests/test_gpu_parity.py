@@ -1306,3 +1306,33 @@ def test_reference_lpdf_perturbation_suite(ss, nterms):
     assert _all_equal(likinfo["dhcoeff"][0], likinfo["dhcoeff"][1], 0.01)
     assert _all_equal(likinfo["dhpara"][0], likinfo["dhpara"][1], 0.01)
     assert _all_equal(likinfo["rep"][0], likinfo["rep"][1], 1e-12)
+
+
+@pytest.mark.parametrize("p,bad_at", [(40, 17), (300, 5), (300, 299), (4200, 2100)])
+def test_newton_solve_reports_a_hessian_that_is_not_positive_definite(p, bad_at):
+    """A negative pivot anywhere (first block, last ragged block, middle of a two-panel
+    schedule) comes back as an error naming the 64-column block, not as NaNs: the reference's
+    solve() (fit.cpp:120) throws there too."""
+    import torch
+    import outerbase_amd as ob
+    from outerbase_amd._lib import call
+    kinds = ["mat25"] * 6
+    om = ob.outermod()
+    ob.setcovfs(om, kinds)
+    ob.setknot(om, knots_for(kinds, 40))
+    terms = om.selectterms(p)
+    t = ob.obmod._Terms(om, terms)
+    torch.manual_seed(p + bad_at)
+    A = torch.randn((p, p + 3), dtype=torch.float64, device="cuda")
+    G = A @ A.T + 0.5 * torch.eye(p, dtype=torch.float64, device="cuda")
+    G[bad_at, bad_at] = -1e15         # indefinite whatever the prior adds to the diagonal
+    g = torch.randn(p, dtype=torch.float64, device="cuda")
+    wsb = C.c_uint64(0)
+    call("obhip_newton_workspace_bytes", p, C.byref(wsb))
+    ws = torch.empty(wsb.value, dtype=torch.uint8, device="cuda")
+    th = torch.empty(p, dtype=torch.float64, device="cuda")
+    dH = torch.empty(p, dtype=torch.float64, device="cuda")
+    with pytest.raises(ob.ObhipError, match="not positive definite") as ei:
+        call("obhip_newton_solve_dev", om._h, t._h, G.data_ptr(), g.data_ptr(), 0.3, 2.0,
+             th.data_ptr(), dH.data_ptr(), ws.data_ptr(), wsb.value)
+    assert "column %d" % (bad_at // 64 * 64) in str(ei.value)
