@@ -434,19 +434,22 @@ k_chol_update(double *__restrict__ H, double *__restrict__ z, const double *__re
         acc[i][j][r] = (active && row < p && col <= row) ? H[(size_t)row * p + col] : 0.0;
       }
   constexpr int NU = KH * HW / 256;  // 16-byte pieces per thread and panel part
-  for (int part = 0; part < kparts * (NB / KH); ++part) {
-    // panels: KH k x TS rows each, in 16-byte pieces
-    d2v ga[NU], gb[NU];
-    {
-      const double *srca = Wt + (size_t)part * KH * pw + t0 + bi * TS;
-      const double *srcb = Wt + (size_t)part * KH * pw + t0 + bj * TS;
+  const int nparts = kparts * (NB / KH);
+  // panels: KH k x TS rows per part, in 16-byte pieces; the pieces of part + 1 are requested
+  // before the MFMAs of part, so that only the first part's round trip is exposed
+  d2v ga[NU], gb[NU];
+  auto fetch = [&](int part) {
+    const double *srca = Wt + (size_t)part * KH * pw + t0 + bi * TS;
+    const double *srcb = Wt + (size_t)part * KH * pw + t0 + bj * TS;
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int e = tid + 256 * u, k = e / HW, c2 = e % HW;
-        ga[u] = *(const d2v *)(srca + (size_t)k * pw + 2 * c2);
-        gb[u] = *(const d2v *)(srcb + (size_t)k * pw + 2 * c2);
-      }
+    for (int u = 0; u < NU; ++u) {
+      const int e = tid + 256 * u, k = e / HW, c2 = e % HW;
+      ga[u] = *(const d2v *)(srca + (size_t)k * pw + 2 * c2);
+      gb[u] = *(const d2v *)(srcb + (size_t)k * pw + 2 * c2);
     }
+  };
+  fetch(0);
+  for (int part = 0; part < nparts; ++part) {
     if (part > 0) __syncthreads();  // the previous part has been consumed
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -455,6 +458,7 @@ k_chol_update(double *__restrict__ H, double *__restrict__ z, const double *__re
       *(d2v *)&Sb[k * UP + 2 * c2] = gb[u];
     }
     __syncthreads();
+    if (part + 1 < nparts) fetch(part + 1);
     if (active) {
       const double *pa = Sa + q * UP + wm * HW + t16;
       const double *pb = Sb + q * UP + wn * HW + t16;
