@@ -168,7 +168,8 @@ constexpr uint64_t kAtbNoTask = ~0ull;
 template <int MODE, bool DBG>
 __global__ void __launch_bounds__(256, 2)
 k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict__ Bm, uint64_t ldB,
-           int nb, int npairs, uint64_t ntiles, uint64_t nsplit /* Gram: row splits */, int tri,
+           int nb, int npairs, uint64_t ntiles, uint64_t split_base /* Gram: tiles per row split ... */,
+           int tri /* Gram: ... the first `tri` splits take one more tile */,
            const uint64_t *__restrict__ tasks, double *__restrict__ part, uint64_t ldo,
            unsigned long long *dbgout) {
   extern __shared__ double T[];  // [2][16][272]
@@ -192,9 +193,9 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
   if constexpr (MODE == kAtbGram) {
     // the row tiles in nsplit runs that differ by at most one tile (every block of a round
     // the same length: 1954 tiles in 32 splits are 2 x 62 + 30 x 61, not 31 x 62 + 32)
-    const uint64_t base = ntiles / nsplit, rem = ntiles % nsplit, y = (uint64_t)ysplit;
-    t0 = y * base + min(y, rem);
-    t1 = t0 + base + (y < rem ? 1 : 0);
+    const uint64_t y = (uint64_t)ysplit, rem = (uint64_t)tri;
+    t0 = y * split_base + min(y, rem);
+    t1 = t0 + split_base + (y < rem ? 1 : 0);
   } else {
     t0 = 0;
     t1 = tri ? min(ntiles, (uint64_t)(J + 1) * (kGT / kTileRows)) : ntiles;
@@ -514,13 +515,13 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
       OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbGram, true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_atb_dma2<kAtbGram, true>), dim3(nblocks), dim3(256), lds, cur_stream(), d_B,
-                         t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, nsplit, 0, b.gram_pairs.p, part,
+                         t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, ntiles / nsplit, (int)(ntiles % nsplit), b.gram_pairs.p, part,
                          (uint64_t)0, dbgout);
     } else {
       OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbGram, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_atb_dma2<kAtbGram, false>), dim3(nblocks), dim3(256), lds, cur_stream(),
-                         d_B, t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, nsplit, 0, b.gram_pairs.p, part,
+                         d_B, t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, ntiles / nsplit, (int)(ntiles % nsplit), b.gram_pairs.p, part,
                          (uint64_t)0, nullptr);
     }
     OB_HIP(hipGetLastError());
