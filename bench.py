@@ -9,7 +9,8 @@ already resident in HBM (BASELINE.md sections 2-3):
            packed upper triangle of G + the two p-vectors + 3 scalars] -> right-hand side
            of the problem with y standardised over all rows (R/fitting.R:55-57) ->
            H = e^{-2 sigma} G + prior, Cholesky, two triangular solves
-           (lpdf::optnewton, "back end A")
+           (lpdf::optnewton, "back end A").  With ONE rank mean and sd of y are known up
+           front: y is standardised first and B^T y is the only p-vector pass.
   predict  fused basis build at the rank's n fresh rows + B theta (predictor$update/$mean)
 
 Default workload: BASELINE.json configs[2] = d=20, n=1e6, p=4096, Matern-5/2 in every
@@ -494,8 +495,10 @@ def main():
             "backend": args.backend,
             "rows_total": n_total, "rows_per_gpu": n_local, "d": args.d, "p": p,
             "terms_nnz": hp.terms_info["nnz_total"], "basis_columns": hp.ncols,
-            "parallelism": "rows sharded over %d rank(s); one exchange buffer per fit "
-                           "(packed triangle of G, B^T y, B^T 1, 3 scalars)" % world,
+            "parallelism": ("one rank: nothing to exchange (y standardised first, one B^T y pass)"
+                            if world == 1 else
+                            "rows sharded over %d rank(s); one exchange buffer per fit "
+                            "(packed triangle of G, B^T y, B^T 1, 3 scalars)" % world),
         },
         "exchange": dict(comm_info, allreduce_ms=prof.get("exchange", {}).get("avg_ms")),
         "fit_predict_split": split,

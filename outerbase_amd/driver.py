@@ -210,14 +210,31 @@ class HotPath:
             self.basis = h
         else:
             call("obhip_basis_rebuild", self.basis)
-        if self.backend == "newton":
+        if self.backend == "newton" and self.world == 1:
+            # One rank knows mean and sd of y before anything else: standardise y as obfit does
+            # (R/fitting.R:55-57) and take B^T y of that -- no B^T 1 pass, nothing to exchange.
+            call("obhip_sum_sumsq_dev", self.y_raw.data_ptr(), self.n, self.stats.data_ptr())
+            s1, s2 = self.stats[:2].tolist()
+            nt = float(self.n)
+            cent = s1 / nt
+            sca = math.sqrt(max(s2 - nt * cent * cent, 0.0) / (nt - 1.0))
+            self.y.copy_(self.y_raw)
+            call("obhip_affine_dev", self.y.data_ptr(), self.n, cent, sca)
+            call("obhip_gram_dev", self.basis, self.t._h, self.y.data_ptr(), self.G.data_ptr(),
+                 self.g.data_ptr())
+            self.y_cent, self.y_sca = cent, sca
+            self.sigma = math.log(0.01)   # loglik_std.cpp:51 with var(y) = 1
+            call("obhip_newton_solve_dev", self.om._h, self.t._h, self.G.data_ptr(),
+                 self.g.data_ptr(), self.sigma, self.rho, self.theta.data_ptr(),
+                 self.diagH.data_ptr(), self.ws.data_ptr(), self.wsb)
+        elif self.backend == "newton":
             # local pieces: G_r, B_r^T y_r (raw y), B_r^T 1, (sum y, sum y^2)
             call("obhip_sum_sumsq_dev", self.y_raw.data_ptr(), self.n, self.stats.data_ptr())
             call("obhip_gram_dev", self.basis, self.t._h, self.y_raw.data_ptr(), self.G.data_ptr(),
                  self.g.data_ptr())
             call("obhip_basis_tmm_dev", self.basis, self.t._h, self.ones.data_ptr(),
                  self.b1.data_ptr(), 0)
-            # the one exchange (no sum with one rank) + standardisation of the right-hand side
+            # the one exchange + standardisation of the right-hand side over ALL rows
             call("obhip_normal_eq_exchange_dev", self.comm, self.p, self.n, self.G.data_ptr(),
                  self.g.data_ptr(), self.b1.data_ptr(), self.stats.data_ptr(), self.exbuf_ptr,
                  self.ex_count, self.meansd.data_ptr())
