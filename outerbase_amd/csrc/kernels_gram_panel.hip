@@ -486,10 +486,16 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   // (the splits differ by at most one tile and the longer ones are few and dealt out first,
   // so a round costs the average length; one tile charged for a block's first chunk, its
   // partial-tile store and the hand-over of the slot: ~7 us measured, OBHIP_GRAM_DBG)
+  // A last round that fills at most half of the slots leaves its blocks alone on their CUs,
+  // where they run ~1.7x as fast (0.6 of a round); and every split costs k_gram_reduce one
+  // more partial of every tile pair to read (128 KB at ~4 TB/s = 0.0022 of the 14.6 us a block
+  // takes per row tile).  Both measured at p = 4096 (16 vs 32 splits at 125 000 rows: equal
+  // Gram times, half the reduction).
   double bestc = 1e300;
   for (uint64_t ns = 1; ns <= max_split; ++ns) {
-    const uint64_t rounds = (ns * npairs + slots - 1) / slots;
-    const double cost = (double)rounds * ((double)ntiles / (double)ns + 1.0);
+    const uint64_t blocks = ns * (uint64_t)npairs, full = blocks / slots, tail = blocks % slots;
+    const double rounds = (double)full + (tail == 0 ? 0.0 : (2 * tail <= slots ? 0.6 : 1.0));
+    const double cost = rounds * ((double)ntiles / (double)ns + 1.0) + 0.0022 * (double)blocks;
     if (cost < bestc) {
       bestc = cost;
       nsplit = ns;
