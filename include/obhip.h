@@ -366,9 +366,10 @@ int obhip_predict(const obhip_model *m, const obhip_terms *t,
                   double sigma, double *var);
 /* predr_std (loglik_std.cpp:218-256), the predictor of the loglik_std model with the full
  * posterior covariance of the coefficients: mean = B theta, var_i = b_i^T inv(H) b_i +
- * e^{2 sigma} (:249-256; the reference uses arma::inv, here H = L L^T and one triangular
- * solve).  H: total Hessian, p x p symmetric (host); var may be NULL (then H may be too).
- * The triangular solve is rocBLAS dtrsm, loaded at run time (OBHIP_ERR_STATE without it). */
+ * e^{2 sigma} (:249-256; the reference uses arma::inv; here H = L L^T by the library's own
+ * Cholesky, X = L^-T by a blocked triangular inversion and || L^-1 b_i ||^2 in one pass of the
+ * matrix-core kernel, csrc/posterior.cpp -- no BLAS library is involved).  H: total Hessian,
+ * p x p symmetric (host); var may be NULL (then H may be too). */
 int obhip_predict_std(const obhip_model *m, const obhip_terms *t, const double *theta,
                       const double *H, const double *x, uint64_t n, uint64_t ldx, double *mean,
                       double sigma, double *var);
@@ -377,7 +378,8 @@ int obhip_predict_std(const obhip_model *m, const obhip_terms *t, const double *
  * (lpdfvec::buildhess, fit.cpp:270-299): val = -1/2 log det H, gradhyp[l] =
  * -1/2 sum(dH/dhyp_l % inv(H)) (nhyp entries) and gradpara = {noisescale, coeffscale}
  * parts (loglik_std.cpp:180-203, logpr_gauss.cpp:165-186).  H: total Hessian (host);
- * gradhyp / gradpara may be NULL.  Uses rocBLAS dtrsm like obhip_predict_std. */
+ * gradhyp / gradpara may be NULL.  inv(H) = L^-T L^-1 on the library's own kernels, like
+ * obhip_predict_std. */
 int obhip_margadj_full(const obhip_basis *b, const obhip_terms *t, const obhip_model *m,
                        const double *H, double sigma, double rho, double *val, double *gradhyp,
                        double *gradpara);

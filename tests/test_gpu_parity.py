@@ -1336,3 +1336,48 @@ def test_newton_solve_reports_a_hessian_that_is_not_positive_definite(p, bad_at)
         call("obhip_newton_solve_dev", om._h, t._h, G.data_ptr(), g.data_ptr(), 0.3, 2.0,
              th.data_ptr(), dH.data_ptr(), ws.data_ptr(), wsb.value)
     assert "column %d" % (bad_at // 64 * 64) in str(ei.value)
+
+
+def test_host_buffer_predr_std_and_the_small_helpers():
+    """obhip_predict_std on host buffers (the entry the Rcpp glue would use for predr_std,
+    loglik_std.cpp:218-256) against the oracle, with x passed with a leading dimension larger
+    than n; and obhip_basis_dims / obhip_memcpy_d2d / obhip_synchronize, which nothing else
+    calls directly."""
+    import torch
+    import ob_oracle as O
+    import outerbase_amd as ob
+    from outerbase_amd._lib import call, ptr
+    kinds = ["mat25", "mat25pow", "mat25ang", "mat25"]
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 24))
+    x, y = O.synth_xy(42, 0, 600, kinds)
+    y = (y - y.mean()) / y.std(ddof=1)
+    terms = om_o.selectterms(150)
+    bo = O.OuterBase(om_o, x)
+    sigma = math.log(0.1)
+    theta, H = O.fit_newton(bo, terms, y, sigma=sigma)
+    n, ldx = 257, 300
+    xnew, _ = O.synth_xy(43, 0, n, kinds)
+    xpad = np.full((ldx, len(kinds)), np.nan, order="F")
+    xpad[:n] = xnew
+    t = ob.obmod._Terms(om_d, terms)
+    mean, var = np.empty(n), np.empty(n)
+    Hs = np.asfortranarray(0.5 * (H + H.T))
+    call("obhip_predict_std", om_d._h, t._h, ptr(np.ascontiguousarray(theta)), ptr(Hs), ptr(xpad),
+         n, ldx, ptr(mean), sigma, ptr(var))
+    assert relerr(mean, O.predict_mean(om_o, terms, theta, xnew)) < 1e-10
+    assert relerr(var, O.predict_var_std(om_o, terms, H, sigma, xnew)) < 1e-8
+    # mean only: H and var may be NULL
+    mean2 = np.empty(n)
+    call("obhip_predict_std", om_d._h, t._h, ptr(np.ascontiguousarray(theta)), None, ptr(xpad), n, ldx,
+         ptr(mean2), sigma, None)
+    assert np.array_equal(mean, mean2)
+    # the small helpers
+    bd = ob.outerbase(om_d, xnew)
+    nn, dd, nc = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    call("obhip_basis_dims", bd._h, C.byref(nn), C.byref(dd), C.byref(nc))
+    assert (nn.value, dd.value) == (n, len(kinds)) and nc.value >= 1 + len(kinds)
+    a = torch.arange(1000, dtype=torch.float64, device="cuda")
+    b = torch.zeros_like(a)
+    call("obhip_memcpy_d2d", C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), 8000)
+    call("obhip_synchronize")
+    assert torch.equal(a, b)
