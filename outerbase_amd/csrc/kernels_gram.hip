@@ -10,7 +10,7 @@
 //            generated inside the kernel from the factored basis (no staging memory; terms of
 //            at most 8 factors on at most 128 used columns).
 // Every back end covers the upper-triangular 128 x 128 tile pairs, splits the rows over
-// gridDim.y workgroups per pair, and writes per-block partial tiles; k_gram_reduce sums the
+// several workgroups per pair, and writes per-block partial tiles; k_gram_reduce sums the
 // partials in a fixed order (bit-reproducible, no atomics) and mirrors the result into the
 // lower triangle.
 #include "obhip_internal.h"

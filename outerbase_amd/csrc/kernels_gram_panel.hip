@@ -22,16 +22,20 @@
 //     covered by the other block's wave on the same SIMD;
 //   * blocks that share an XCD (an L2) get tile pairs from a compact square of the pair
 //     triangle, and the row split fills whole rounds of CU slots.
-// Measured at n = 1e6, p = 4096 (profiles/): 246 ms for 2 n p (p+1)/2 * 2 flops = 68 TFLOP/s
-// = 0.87 of the 78.6 TFLOP/s FP64 matrix peak; 8570 of the ideal 8192 matrix-pipe cycles
-// per chunk, the rest is clock (2.26-2.35 GHz under this load, not 2.4).
+// Measured at n = 1e6, p = 4096 (profiles/r02_*): 231-238 ms depending on the GPU of the pool
+// for n p (p + 1) flop = 71.4-72.5 TFLOP/s = 0.90-0.92 of the 78.6 TFLOP/s FP64 matrix peak;
+// MfmaUtil 94-96 %, ~8390 of the ideal 8192 matrix-pipe cycles per chunk, the rest is clock
+// (2.25-2.33 GHz under this load, not 2.4).
 //
 // k_materialize_rows: B[row][term] row-major, p_pad columns.  Lane = row for the
 //   Hadamard products (same LDS tile and register-resident term tables as k_mm), a
-//   per-wave 32-term LDS transpose, then 256-byte row segments to HBM.
-// k_gram_dma2: tile pair (I, J) of 128 x 128 terms, row range split over gridDim.y; 4 waves
-//   with 64 x 64 wave tiles (64 accumulators), operands from two LDS panel buffers
-//   [16 rows][272], row-split partials reduced by k_gram_reduce (kernels_gram.hip).
+//   per-wave 32-term LDS transpose, then 256-byte row segments to HBM.  (Terms of more than 8
+//   factors; the default copy is k_materialize_tl in kernels_prod.hip.)
+// k_atb_dma2: tile pair (I, J) of 128 x 128 terms and a run of row tiles per task, tasks in
+//   an XCD-aware table (build_task_order); 4 waves with 64 x 64 wave tiles (64 accumulators),
+//   operands from two LDS panel buffers [16 rows][272], row-split partials reduced by
+//   k_gram_reduce (kernels_gram.hip).  The same body serves C = A^T Bm for two operands
+//   (launch_atb: row norms for predr_std, stored products for the marginal adjustment).
 #include "obhip_internal.h"
 #include "device_common.h"
 
