@@ -4,13 +4,12 @@
 One "step" = one full pass of the hot path over one synthetic batch that is
 already resident in HBM (BASELINE.md sections 2-3):
 
-  fit      basis build (outerbase::build) -> Gram B^T B on the FP64 matrix cores,
-           B^T y, B^T 1, (sum y, sum y^2) -> [ONE exchange buffer summed over ranks:
-           packed upper triangle of G + the two p-vectors + 3 scalars] -> right-hand side
-           of the problem with y standardised over all rows (R/fitting.R:55-57) ->
-           H = e^{-2 sigma} G + prior, Cholesky, two triangular solves
-           (lpdf::optnewton, "back end A").  With ONE rank mean and sd of y are known up
-           front: y is standardised first and B^T y is the only p-vector pass.
+  fit      y standardised over all rows (R/fitting.R:55-57; 24 bytes cross the ranks) ->
+           basis build (outerbase::build) -> Gram B^T B on the FP64 matrix cores, B^T y ->
+           [ONE exchange buffer summed over ranks: packed upper triangle of G + B^T y, written
+           by the Gram reduction itself] -> H = e^{-2 sigma} G + prior formed by the unpack
+           (one rank: by the reduction), Cholesky, two triangular solves (lpdf::optnewton,
+           "back end A").
   predict  fused basis build at the rank's n fresh rows + B theta (predictor$update/$mean)
 
 Default workload: BASELINE.json configs[2] = d=20, n=1e6, p=4096, Matern-5/2 in every
@@ -54,12 +53,15 @@ def parse():
     ap.add_argument("--knots", type=int, default=40)
     ap.add_argument("--backend", choices=["newton", "cg"], default="newton")
     ap.add_argument("--kinds", default="mat25", help="comma list cycled over dimensions")
-    ap.add_argument("--gram-backend", type=int, default=0,
-                    help="0 auto, 1 MFMA 16x16x4, 3 fused MFMA 4x4x4, 4 materialised-B MFMA 4x4x4")
+    ap.add_argument("--gram-backend", type=int, default=0, choices=[0, 3, 4],
+                    help="0 automatic, 3 fused MFMA 4x4x4 (no staging memory), 4 staged design matrix MFMA 4x4x4")
+    ap.add_argument("--dump", default=None,
+                    help="rank 0 writes theta and its first 1000 de-standardised predictions here (.npz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-backend", action="store_true")
     ap.add_argument("--no-config3", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=400000)
+    ap.add_argument("--cpu-panel", type=int, default=200000,
+                    help="rows per panel of the CPU leg's Gram path (all n rows are processed)")
     return ap.parse_args()
 
 
@@ -135,75 +137,94 @@ def host_threads():
     return max(1, n)
 
 
-def cpu_baseline(hp, ns):
+def cpu_baseline(hp, panel):
     """CPU restatement of the reference path timed on the host cores (test infrastructure,
     oracle/): the reference's own loops (outerbase::build, getm_, prodmm_, tprodmm_) in
     C++/OpenMP with the reference's chunk schedule and thread count rule
     (omp_get_num_procs(), src/modandbase.cpp:464) in oracle/ob_cpu.cpp; BLAS/LAPACK (NumPy)
     for basismat.t()*basismat and solve() exactly where the reference hands over to
-    Armadillo.  Gram path: a bounded row sample (the reference's loglik_std would need the
-    32.8 GB design matrix at n = 1e6), row-proportional work scaled to n, the p x p solve
-    counted once.  PCG path (what obfit runs): basis build and one B a + one B^T r pass
-    timed at the FULL n, times the passes lpdf::optcg makes."""
+    Armadillo.  Gram path: ALL n rows, in row panels (the reference's loglik_std would need
+    the whole 32.8 GB design matrix at n = 1e6; BASELINE.md section 5: blocked row panels,
+    B_panel^T B_panel accumulated), nothing extrapolated.  PCG path (what obfit runs): basis
+    build and one B a + one B^T r pass timed at the FULL n, times the passes lpdf::optcg
+    makes."""
     import numpy as np
+    from threadpoolctl import threadpool_limits, threadpool_info   # hard requirement: the
+    # BLAS thread count below is what the `sample` string claims
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ob_oracle as O
     import ob_cpu
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:
-        threadpool_limits = None
     threads = host_threads()
-    ns = min(ns, hp.n)
     use_cpp = ob_cpu.available()
+    n = hp.n
+    panel = max(1, min(panel, n))
 
     om = O.OuterMod()
     om.setcovfs(hp.kinds)
     om.setknot(O.bench_knots(hp.kinds, hp.m))
+    p = hp.p
+    t = {"synth": 0.0, "build": 0.0, "getmat": 0.0, "gram": 0.0, "solve": 0.0, "predict": 0.0}
+    blas_threads = None
 
     def run():
-        x, y = O.synth_xy(42, 0, ns, hp.kinds)
-        xnew, _ = O.synth_xy(43, 0, ns, hp.kinds)
-        y = (y - y.mean()) / y.std(ddof=1)
-        t = {}
+        # y standardised over all rows first (R/fitting.R:55-57); generating the synthetic rows
+        # is input preparation, not part of the path
         t0 = time.perf_counter()
-        if use_cpp:
-            bm, bs = ob_cpu.build(om, x, threads)            # outerbase::build, all knots
-        else:
-            ob = O.OuterBase(om, x)
-            bm, bs = ob.basemat, ob.basescale
-        t["build"] = time.perf_counter() - t0
+        ys = np.concatenate([O.synth_xy(42, r0, min(panel, n - r0), hp.kinds)[1]
+                             for r0 in range(0, n, panel)])
+        cent, sca = ys.mean(), ys.std(ddof=1)
+        t["synth"] += time.perf_counter() - t0
+        sigma = O.default_sigma((ys - cent) / sca)
+        G = np.zeros((p, p))
+        g = np.zeros(p)
+        for r0 in range(0, n, panel):
+            nr = min(panel, n - r0)
+            t0 = time.perf_counter()
+            x, y = O.synth_xy(42, r0, nr, hp.kinds)
+            y = (y - cent) / sca
+            t["synth"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            if use_cpp:
+                bm, bs = ob_cpu.build(om, x, threads)            # outerbase::build, all knots
+            else:
+                ob = O.OuterBase(om, x)
+                bm, bs = ob.basemat, ob.basescale
+            t["build"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            if use_cpp:
+                B = ob_cpu.getmat(om, hp.terms, bm, bs, threads)  # getm_ (loglik_std ctor)
+            else:
+                B = O.getm(hp.terms, bm, bs, om.knotptst)
+            t["getmat"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            G += B.T @ B                                          # loglik_std::hess
+            g += B.T @ y
+            t["gram"] += time.perf_counter() - t0
+            del B, bm, bs, x
         t0 = time.perf_counter()
-        if use_cpp:
-            B = ob_cpu.getmat(om, hp.terms, bm, bs, threads)  # getm_ (loglik_std ctor)
-        else:
-            B = O.getm(hp.terms, bm, bs, om.knotptst)
-        t["getmat"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        sigma = O.default_sigma(y)
-        H = math.exp(-2 * sigma) * (B.T @ B)                  # loglik_std::hess
-        g = math.exp(-2 * sigma) * (B.T @ y)
+        H = math.exp(-2 * sigma) * G
         H[np.diag_indices_from(H)] += O.prior_prec(om, hp.terms, hp.rho)
-        t["gram"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        theta = np.linalg.solve(H, g)                         # fit.cpp:120
-        t["solve"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        if use_cpp:                                           # predictor update + mean
-            bmn, bsn = ob_cpu.build(om, xnew, threads)
-            ob_cpu.mm(om, hp.terms, bmn, bsn, theta, threads)
-        else:
-            O.predict_mean(om, hp.terms, theta, xnew)
-        t["predict"] = time.perf_counter() - t0
-        return t, theta
+        theta = np.linalg.solve(H, math.exp(-2 * sigma) * g)      # fit.cpp:120
+        t["solve"] += time.perf_counter() - t0
+        for r0 in range(0, n, panel):
+            nr = min(panel, n - r0)
+            t0 = time.perf_counter()
+            xnew, _ = O.synth_xy(43, r0, nr, hp.kinds)
+            t["synth"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            if use_cpp:                                           # predictor update + mean
+                bmn, bsn = ob_cpu.build(om, xnew, threads)
+                ob_cpu.mm(om, hp.terms, bmn, bsn, theta, threads)
+            else:
+                O.predict_mean(om, hp.terms, theta, xnew)
+            t["predict"] += time.perf_counter() - t0
+        return theta
 
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=threads):
-            t, theta = run()
-    else:
-        t, theta = run()
-    per_row = (t["build"] + t["getmat"] + t["gram"] + t["predict"]) / ns
-    full = per_row * hp.n + t["solve"]
+    with threadpool_limits(limits=threads):
+        blas_threads = sorted({int(i["num_threads"]) for i in threadpool_info()
+                               if i.get("user_api") == "blas"})
+        theta = run()
+    full = t["build"] + t["getmat"] + t["gram"] + t["solve"] + t["predict"]
     impl = "oracle/ob_cpu.cpp (C++/OpenMP, reference chunk schedule)" if use_cpp \
         else "oracle/ob_oracle.py (NumPy)"
     pcg = None
@@ -211,12 +232,11 @@ def cpu_baseline(hp, ns):
         # the matrix-free path obfit itself takes, at the full n (basemat
         # 6.4 GB): build, then per iteration update() + hessmult() = two B a and two B^T r
         # passes (fit.cpp:71-85), at the iteration count the device PCG needed, then predict
-        nfull = hp.n
-        x, _ = O.synth_xy(42, 0, nfull, hp.kinds)
+        x, _ = O.synth_xy(42, 0, n, hp.kinds)
         t0 = time.perf_counter()
         bm, bs = ob_cpu.build(om, x, threads)
         tb = time.perf_counter() - t0
-        r = np.ones(nfull)
+        r = np.ones(n)
         t0 = time.perf_counter()
         ob_cpu.mm(om, hp.terms, bm, bs, theta, threads)
         ob_cpu.tmm(om, hp.terms, bm, bs, r, threads)
@@ -224,17 +244,19 @@ def cpu_baseline(hp, ns):
         del bm, bs, x
         iters = getattr(hp, "cg_iters", None) or 22
         full_pcg = 2 * tb + (2 * (iters + 1) + 1) * tp   # fit build + predict build; +1 pass: predict
-        pcg = {"value": nfull / full_pcg, "unit": "points/s", "iterations": iters, "rows": nfull,
+        pcg = {"value": n / full_pcg, "unit": "points/s", "iterations": iters, "rows": n,
                "build_s": tb, "mm_plus_tmm_s": tp,
                "what": "build and one B a + B^T r pass timed at the full n on %d threads; "
                        "2 (iters + 1) such passes per fit as lpdf::optcg makes them" % threads}
-    return {"value": hp.n / full, "unit": "points/s", "cores": threads, "kind": "port",
-            "host_cpu_count": os.cpu_count(), "pcg_path": pcg,
-            "sample": "%s + NumPy BLAS/LAPACK for B^T B and solve, %d threads (affinity / cgroup share of the host), "
-                      "%d rows of the same workload: build %.2fs getmat %.2fs gram %.2fs solve %.2fs "
-                      "predict %.2fs; row work scaled to n=%d, solve counted once"
-                      % (impl, threads, ns, t["build"], t["getmat"], t["gram"], t["solve"],
-                         t["predict"], hp.n)}
+    return {"value": n / full, "unit": "points/s", "cores": threads, "blas_threads": blas_threads,
+            "kind": "port", "host_cpu_count": os.cpu_count(), "pcg_path": pcg,
+            "seconds": dict(t, total=full),
+            "sample": "%s + NumPy BLAS/LAPACK (%s threads) for B^T B and solve, %d OpenMP threads "
+                      "(affinity / cgroup share of the host), ALL %d rows of the same workload in "
+                      "row panels of %d (B_panel^T B_panel accumulated): build %.2fs getmat %.2fs "
+                      "gram %.2fs solve %.2fs predict %.2fs; nothing scaled"
+                      % (impl, "/".join(map(str, blas_threads)) or "?", threads, n, panel, t["build"],
+                         t["getmat"], t["gram"], t["solve"], t["predict"])}
 
 
 def which_config(d, n_total, rows_per_gpu, p):
@@ -281,7 +303,7 @@ def kernel_profile(hp, _lib, torch, nprof=2):
     torch.cuda.synchronize()
     prof = {}
     for name in ["build_basis", "materialize_B", "gram", "gram_reduce", "tmm", "mm", "sqtmm",
-                 "exchange", "form_hessian", "cholesky", "backsolve", "predict"]:
+                 "exchange", "unpack_form", "form_hessian", "cholesky", "backsolve", "predict"]:
         cnt, ms = C.c_uint64(0), C.c_double(0)
         _lib.call("obhip_profile_get", name.encode(), C.byref(cnt), C.byref(ms))
         if cnt.value:
@@ -434,16 +456,18 @@ def main():
         hp.mean.copy_(mean_newton)
 
     comm_info = hp.comm_info()
+    if args.dump and rank == 0:
+        np.savez(args.dump, theta=hp.theta.cpu().numpy(), mean=hp.mean[:1000].cpu().numpy(),
+                 meansd=hp.meansd.cpu().numpy(), n_total=n_total, world=world)
 
     # BASELINE.json configs[3]'s shape: 1.25e6 rows per GPU (weak), same d / p / knots.  Every
     # rank takes part.  Measured after the headline so that it cannot disturb it.
     config3 = None
     if not args.no_config3 and args.backend == "newton" and (args.d, args.p) == (20, 4096):
         rows3 = 1_250_000
-        keep = dict(theta=hp.theta.clone(), mean=hp.mean[:4096].clone(), g=hp.g.clone(),
-                    y_cent=hp.y_cent, y_sca=hp.y_sca)
+        keep = True
         hp.close()
-        for name in ("x", "xnew", "y_raw", "y", "ones", "mean", "G"):
+        for name in ("x", "xnew", "y_raw", "y", "mean", "G", "exbuf"):
             setattr(hp, name, None)
         torch.cuda.empty_cache()
         _lib.call("obhip_trim_pool")
@@ -497,8 +521,8 @@ def main():
             "terms_nnz": hp.terms_info["nnz_total"], "basis_columns": hp.ncols,
             "parallelism": ("one rank: nothing to exchange (y standardised first, one B^T y pass)"
                             if world == 1 else
-                            "rows sharded over %d rank(s); one exchange buffer per fit "
-                            "(packed triangle of G, B^T y, B^T 1, 3 scalars)" % world),
+                            "rows sharded over %d rank(s); per fit 24 bytes for mean / sd of y and one "
+                            "exchange buffer (packed triangle of G, B^T y)" % world),
         },
         "exchange": dict(comm_info, allreduce_ms=prof.get("exchange", {}).get("avg_ms")),
         "fit_predict_split": split,
@@ -516,31 +540,33 @@ def main():
         ach = flops / (prof["gram"]["avg_ms"] * 1e-3) / 1e12
         # HBM-side bytes per launch and the matrix-pipe utilisation come from separate
         # rocprofv3 --pmc passes on this exact workload (profiles/); see the files for the
-        # commands and the gfx950 corrections
-        traffic = mfma_util = None
+        # commands and the gfx950 corrections.  They are printed only when the profile was
+        # taken from the Gram kernel that is running (content hash of its sources, compiled
+        # into the library); otherwise null and "traffic_stale": true.
+        traffic = mfma_util = l2_hit = profile_sha = None
+        stale = False
         kernel = {0: "k_atb_dma2", 3: "k_gram_mfma4", 4: "k_atb_dma2"}.get(
             args.gram_backend, "k_atb_dma2")
-        for fn in ("r02_gram_traffic.json", "r01_gram_traffic.json"):
-            tf = os.path.join(ROOT, "profiles", fn)
-            if os.path.exists(tf):
-                tj = json.load(open(tf))
-                c = tj["config"]
-                if tj["kernel"] == kernel and \
-                        (c["d"], c["rows"], c["p"], c["knots"]) == (args.d, n_local, p, args.knots):
+        lib_sha = _lib.lib.obhip_source_hash(1).decode()
+        tf = os.path.join(ROOT, "profiles", "r03_gram_traffic.json")
+        if os.path.exists(tf):
+            tj = json.load(open(tf))
+            c = tj["config"]
+            if tj["kernel"] == kernel and \
+                    (c["d"], c["rows"], c["p"], c["knots"]) == (args.d, n_local, p, args.knots):
+                profile_sha = tj.get("source_hash_gram")
+                if profile_sha == lib_sha:
                     traffic = tj["traffic_bytes_per_launch"]
                     mfma_util = tj.get("mfma_util")
-                    break
-        mf = os.path.join(ROOT, "profiles", "r02_pmc_gram_mfma.json")
-        if mfma_util is None and os.path.exists(mf):
-            mj = json.load(open(mf))
-            c = mj["config"]
-            if mj["kernel"] == kernel and (c["d"], c["rows"], c["p"]) == (args.d, n_local, p):
-                mfma_util = mj["mfma_util"]
+                    l2_hit = tj.get("l2_hit_rate")
+                else:
+                    stale = True
         out["roofline"] = {"bound": "mfma", "kernel": kernel, "achieved": ach,
                            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                            "traffic_unit": "bytes per launch (PMC, separate pass)",
-                           "mfma_util": mfma_util,
+                           "traffic_stale": stale, "profile_sha": profile_sha, "library_sha": lib_sha,
+                           "mfma_util": mfma_util, "l2_hit_rate": l2_hit,
                            "avg_launch_ms": prof["gram"]["avg_ms"]}
     elif "mm" in prof:
         byts = float(n_local) * 8 * (hp.ncols + 1)
@@ -563,7 +589,7 @@ def main():
             hp.setup()
             hp.step()
             torch.cuda.synchronize()
-        out["cpu_baseline"] = cpu_baseline(hp, args.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(hp, args.cpu_panel)
         out["parity_check"] = check_against_oracle(hp)
     print(json.dumps(out))
     sys.stdout.flush()

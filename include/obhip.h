@@ -60,6 +60,10 @@ typedef struct obhip_comm obhip_comm;   /* the ranks of a row-sharded job (no re
 /* ---- library ----------------------------------------------------------- */
 int obhip_abi_version(void);
 const char *obhip_last_error(void);
+/* 16 hex digits of the SHA-256 over the library's sources at build time: which = 0 all of
+ * them, 1 the files the Gram kernel is built from.  Profiles record it, and bench.py prints
+ * PMC counters only when they were collected from the kernel that is running. */
+const char *obhip_source_hash(int which);
 int obhip_device_count(int *count);
 int obhip_set_device(int device);
 /* hipStream_t to launch on (NULL = default stream). */
@@ -346,6 +350,36 @@ int obhip_comm_allreduce_dev(obhip_comm *c, double *d_buf, uint64_t count);
 int obhip_quantiles_dev(obhip_comm *comm, const double *d_x, uint64_t n, uint64_t d,
                         const double *probs, uint64_t q, double *out);
 int obhip_normal_eq_count(uint64_t p, int nranks, uint64_t *count);
+/* ---- row-sharded Newton fit, start to finish on the device (ABI 3) ----------------------
+ * obfit's standardisation of y (R/fitting.R:55-57: (y - mean(y)) / sd(y), n - 1 denominator)
+ * over the rows of ALL ranks, two-pass like R's sd(): (sum y, n) and sum (y - mean)^2 are
+ * summed over the ranks (24 bytes in two exchanges), nothing returns to the host.
+ * d_y_raw, d_y: n doubles (device; may be the same buffer); d_meansd: mean, sd, rows of all
+ * ranks (device, 3 doubles).  comm may be NULL (one rank). */
+int obhip_standardise_dev(obhip_comm *comm, const double *d_y_raw, uint64_t n, double *d_y,
+                          double *d_meansd);
+/* obpred's de-standardisation (R/fitting.R:152): v = mean + sd v, in place, mean and sd read
+ * from d_meansd on the device */
+int obhip_destandardise_dev(double *d_v, uint64_t n, const double *d_meansd);
+/* doubles of exchange buffer obhip_fit_newton_sharded_dev needs: the packed upper triangle of
+ * G, then g = B^T y, padded to equal 16-byte blocks per rank */
+int obhip_fit_newton_count(uint64_t p, int nranks, uint64_t *count);
+/* lpdf::optnewton (fit.cpp:98-131) of lpdfvec(loglik_std, logpr_gauss) from coeff = 0 on a
+ * row shard: G_r = B_r^T B_r by the Gram kernels, whose reduction writes the packed upper
+ * triangle straight into d_exbuf, g_r = B_r^T y behind it; ONE sum over the ranks; the unpack
+ * forms H = e^{-2 sigma} G + diag(1 / (sd e^rho)^2) (loglik_std.cpp:170-173,
+ * logpr_gauss.cpp:153-158, fit.cpp:503-512) in full symmetric storage in d_H; Cholesky and
+ * the two triangular solves (replicated on every rank) give d_theta.  d_y: this rank's rows,
+ * already standardised.  d_H (p x p; on return its lower triangle is the Cholesky factor),
+ * d_g (p: B^T y over all ranks), d_theta (p), d_diagH (p, may be NULL), d_exbuf
+ * (obhip_fit_newton_count doubles whose padding the caller zeroed once), d_workspace
+ * (obhip_newton_workspace_bytes): device memory of the caller.  comm = NULL: one rank, the
+ * reduction writes H itself, d_exbuf is not used. */
+int obhip_fit_newton_sharded_dev(obhip_comm *comm, const obhip_basis *b, const obhip_terms *t,
+                                 const obhip_model *m, const double *d_y, double sigma, double rho,
+                                 double *d_H, double *d_g, double *d_theta, double *d_diagH,
+                                 double *d_exbuf, uint64_t exbuf_count, void *d_workspace,
+                                 uint64_t workspace_bytes);
 int obhip_normal_eq_exchange_dev(obhip_comm *comm, uint64_t p, uint64_t n_local, double *d_G,
                                  double *d_g, const double *d_b1, const double *d_sum2,
                                  double *d_buf, uint64_t buf_count, double *d_meansd);

@@ -901,21 +901,21 @@ def predict_var_gauss(om, terms, diagH, sigma, xnew):
 # ----------------------------------------------------------------------------
 def quantile7(x, probs):
     """R's stats::quantile.default, type = 7 (what .genknotlist calls, R/fitting.R:177-185;
-    base R, not part of the reference checkout): index = (n - 1) p, lo = floor(index + fuzz)
-    with fuzz = 4 eps, h = index - lo (set to 0 below fuzz), (1 - h) x[lo] + h x[lo + 1] on the
-    sorted sample.  Agrees with numpy's method="linear" to the last bit or two."""
+    base R, not part of the reference checkout): index = 1 + (n - 1) p, lo = floor(index),
+    hi = ceiling(index), h = index - lo, (1 - h) x[lo] + h x[hi] on the sorted sample (1-based;
+    the 4 eps fuzz of quantile.default belongs to types 4-6, 8 and 9, type 7 has none).  Agrees
+    with numpy's method="linear" to the last bit or two."""
     xs = np.sort(np.asarray(x, dtype=np.float64))
     n = len(xs)
     probs = np.asarray(probs, dtype=np.float64)
-    fuzz = 4 * np.finfo(np.float64).eps
-    nppm = (n - 1) * probs
-    lo = np.floor(nppm + fuzz).astype(np.int64)
-    h = nppm - lo
-    h[np.abs(h) < fuzz] = 0.0
-    hi = np.minimum(lo + 1, n - 1)
-    lo = np.minimum(lo, n - 1)
+    index = 1.0 + (n - 1) * probs
+    lo = np.floor(index).astype(np.int64)
+    hi = np.ceil(index).astype(np.int64)
+    h = index - lo
+    lo = np.clip(lo, 1, n) - 1
+    hi = np.clip(hi, 1, n) - 1
     out = xs[lo].copy()
-    nz = h != 0
+    nz = (h > 0) & (xs[hi] != out)
     out[nz] = (1 - h[nz]) * xs[lo[nz]] + h[nz] * xs[hi[nz]]
     return out
 

@@ -57,6 +57,16 @@ int basis_setup(obhip_basis *b, const obhip_model *m, const int64_t *levelcap) {
   return launch_build_basis(*b);
 }
 
+}  // namespace
+
+namespace obhip {
+std::vector<double> prior_prec_of(const obhip_model &m, const obhip_terms &t, double rho) {
+  return prior_prec(m, t, rho);
+}
+}  // namespace obhip
+
+namespace {
+
 constexpr size_t kScratch = 2048;  // doubles of scratch of the two-stage reductions: taken from
                                    // the pool per call (keyed by device and stream)
 
@@ -382,19 +392,22 @@ k_cg_eval(CgVecs v, const double *__restrict__ hv, double e2, double ntot_sigma,
 // m = diaghess (e^{-2 sigma} sqcolsums + prior), rm = grad / m, pv = rm (fit.cpp:47-60)
 __global__ void __launch_bounds__(kCgThreads)
 k_cg_init(CgVecs v, const double *__restrict__ sq, double e2, double *__restrict__ scal) {
-  __shared__ double red[kCgThreads / 64];
-  double bad[1] = {0.0};
+  __shared__ double red[2 * kCgThreads / 64];
+  double bad[2] = {0.0, 0.0};  // non-finite entries of m, of grad
   for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) {
     const double md = e2 * sq[k] + v.prec[k];
     v.mdiag[k] = md;
     const double r = v.grad[k] / md;
     v.rm[k] = r;
     v.pv[k] = r;
-    if (!(isfinite(md) && isfinite(v.grad[k]))) bad[0] += 1.0;
+    if (!isfinite(md)) bad[0] += 1.0;
+    if (!isfinite(v.grad[k])) bad[1] += 1.0;
   }
-  block_sum<1>(bad, red);
+  block_sum<2>(bad, red);
   if (threadIdx.x == 0) {
-    scal[S_FINITE] = bad[0] == 0.0 ? 1.0 : 0.0;
+    // fit.cpp:53-56 leaves only when m AND grad are both non-finite; with one of them the
+    // reference goes on (and the first step's num / denom stop the loop below)
+    scal[S_FINITE] = (bad[0] != 0.0 && bad[1] != 0.0) ? 0.0 : 1.0;
     scal[S_VALDIFF] = 10.0;
     scal[S_NUM0] = -1.0;
     scal[S_DONE] = 0.0;
@@ -483,12 +496,13 @@ k_cg_iter(CgVecs v, double tol, double *__restrict__ scal) {
 
 }  // namespace
 
-extern "C" {
+namespace obhip {
 
-int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_model *m,
-                     const double *d_y, double sigma, double rho, double tol, uint64_t maxit,
-                     double *d_theta, uint64_t *iters_out, double *d_diagH, double *val_out,
-                     obhip_comm *comm) {
+// finite_out: 0 when the loop left through the non-finite exit of fit.cpp:53-56 (val = -inf)
+int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_model *m,
+                    const double *d_y, double sigma, double rho, double tol, uint64_t maxit,
+                    double *d_theta, uint64_t *iters_out, double *d_diagH, double *val_out,
+                    obhip_comm *comm, int *finite_out) {
   if (!b || !tc || !m || !d_y || !d_theta) return fail(OBHIP_ERR_INVALID, "fit_cg_dev: null argument");
   OB_TRY(check_compat(m, tc));
   obhip_terms &t = *const_cast<obhip_terms *>(tc);
@@ -617,7 +631,20 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_mo
   OB_HIP(hipStreamSynchronize(st));
   if (iters_out) *iters_out = k;
   if (val_out) *val_out = val;
+  if (finite_out) *finite_out = hs[S_FINITE] != 0.0 ? 1 : 0;
   return 0;
+}
+
+}  // namespace obhip
+
+extern "C" {
+
+int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *tc, const obhip_model *m,
+                     const double *d_y, double sigma, double rho, double tol, uint64_t maxit,
+                     double *d_theta, uint64_t *iters_out, double *d_diagH, double *val_out,
+                     obhip_comm *comm) {
+  return fit_cg_dev_impl(b, tc, m, d_y, sigma, rho, tol, maxit, d_theta, iters_out, d_diagH, val_out,
+                         comm, nullptr);
 }
 
 int obhip_fit_cg(const obhip_basis *b, const obhip_terms *t, const obhip_model *m, const double *y,

@@ -142,6 +142,8 @@ int comm_allreduce(obhip_comm *c, double *d_buf, uint64_t count) {
     return 0;
   }
   if (c->transport == OBHIP_TRANSPORT_HOST) {
+    // one rank without a callback (obhip_comm_init_host accepts that): the sum is the identity
+    if (!c->fn) return c->nranks == 1 ? 0 : fail(OBHIP_ERR_STATE, "host communicator has no callback");
     if (c->pinned_n < count) {
       if (c->pinned) (void)hipHostFree(c->pinned);
       c->pinned = nullptr;
@@ -340,17 +342,17 @@ extern "C" int obhip_quantiles_dev(obhip_comm *comm, const double *d_x, uint64_t
   }
   const uint64_t N = (uint64_t)ntot;
   if (N == 0) return fail(OBHIP_ERR_INVALID, "quantiles_dev: no rows");
-  // type 7 as stats::quantile.default computes it: index = (N - 1) p, lo = floor(index + fuzz),
-  // h = index - lo (0 below fuzz = 4 eps), Q = (1 - h) x_(lo) + h x_(lo + 1); targets 2 j, 2 j + 1
+  // type 7 as stats::quantile.default computes it (1-based): index = 1 + (N - 1) p,
+  // lo = floor(index), h = index - lo, Q = (1 - h) x_(lo) + h x_(lo + 1) (the 4 eps fuzz of
+  // quantile.default belongs to types 4-6, 8 and 9; type 7 has none); targets 2 j, 2 j + 1
   std::vector<uint64_t> want(T);
   std::vector<double> frac(q);
-  const double fuzz = 4.0 * 2.220446049250313e-16;
   for (uint64_t j = 0; j < q; ++j) {
     if (!(probs[j] >= 0.0 && probs[j] <= 1.0)) return fail(OBHIP_ERR_INVALID, "quantiles_dev: probs outside [0, 1]");
-    const double nppm = (double)(N - 1) * probs[j];
-    const uint64_t lo = std::min<uint64_t>((uint64_t)std::floor(nppm + fuzz), N - 1);
-    double h = nppm - (double)lo;
-    if (std::fabs(h) < fuzz) h = 0.0;
+    const double index = 1.0 + (double)(N - 1) * probs[j];
+    const double lo1 = std::floor(index);
+    const uint64_t lo = std::min<uint64_t>((uint64_t)lo1 - 1, N - 1);
+    const double h = index - lo1;
     want[2 * j] = lo;
     want[2 * j + 1] = std::min<uint64_t>(lo + 1, N - 1);
     frac[j] = h;
@@ -384,7 +386,7 @@ extern "C" int obhip_quantiles_dev(obhip_comm *comm, const double *d_x, uint64_t
   for (uint64_t l = 0; l < d; ++l)
     for (uint64_t j = 0; j < q; ++j) {
       const double a = key_to_double(lo[l * T + 2 * j]), b = key_to_double(lo[l * T + 2 * j + 1]);
-      out[l * q + j] = frac[j] == 0.0 ? a : (1.0 - frac[j]) * a + frac[j] * b;
+      out[l * q + j] = (frac[j] == 0.0 || a == b) ? a : (1.0 - frac[j]) * a + frac[j] * b;
     }
   return 0;
 }

@@ -305,7 +305,7 @@ int obhip_terms::prepare(const std::vector<int64_t> &cap,
 
 extern "C" {
 
-int obhip_abi_version(void) { return 2; }
+int obhip_abi_version(void) { return 3; }
 
 const char *obhip_last_error(void) { return g_err.c_str(); }
 

@@ -71,6 +71,42 @@ k_unpack_tri(const double *__restrict__ buf, uint64_t p, int nb, double *__restr
   }
 }
 
+// The unpack of a row-sharded Newton fit: the summed packed triangle becomes the Hessian
+// H = e2 G + diag(prec) in full symmetric storage (lpdfvec::hess_, fit.cpp:503-512) and its
+// diagonal, in the one pass that has to touch the p x p matrix anyway.
+__global__ void __launch_bounds__(256)
+k_unpack_form(const double *__restrict__ buf, uint64_t p, int nb, double *__restrict__ H, double e2,
+              const double *__restrict__ prec, double *__restrict__ diagH) {
+  __shared__ double S[64 * 65];
+  int bi = 0, rem = blockIdx.x;
+  while (rem >= nb - bi) {
+    rem -= nb - bi;
+    ++bi;
+  }
+  const int bj = bi + rem;
+  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+  const uint64_t j = (uint64_t)bj * 64 + c;
+  for (int r = r4; r < 64; r += 4) {
+    const uint64_t i = (uint64_t)bi * 64 + r;
+    double v = 0.0;
+    if (i < p && j < p && j >= i) {
+      v = e2 * buf[tri_off(i, p) + (j - i)];
+      if (i == j) {
+        v += prec[i];
+        if (diagH) diagH[i] = v;
+      }
+      H[i * p + j] = v;
+    }
+    S[r * 65 + c] = v;
+  }
+  __syncthreads();
+  const uint64_t ii = (uint64_t)bi * 64 + c;
+  for (int r = r4; r < 64; r += 4) {
+    const uint64_t jj = (uint64_t)bj * 64 + r;
+    if (jj < p && ii < p && ii < jj) H[jj * p + ii] = S[c * 65 + r];
+  }
+}
+
 // tail = [g p][b1 p][sum y, sum y^2, n]: g_out = (g - cent b1) / sca, meansd = cent, sca, n
 __global__ void __launch_bounds__(256)
 k_finalize_rhs(const double *__restrict__ tail, uint64_t p, double *__restrict__ g_out,
@@ -118,6 +154,16 @@ int launch_unpack_normal_eq(uint64_t p, bool with_tri, const double *d_buf, doub
   }
   hipLaunchKernelGGL(k_finalize_rhs, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, st, d_buf + tri,
                      p, d_g, d_meansd);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_unpack_form(uint64_t p, const double *d_tri, double *d_H, double e2, const double *d_prec,
+                       double *d_diagH) {
+  ProfScope ps("unpack_form");
+  const int nb = (int)((p + 63) / 64);
+  hipLaunchKernelGGL(k_unpack_form, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, cur_stream(),
+                     d_tri, p, nb, d_H, e2, d_prec, d_diagH);
   OB_HIP(hipGetLastError());
   return 0;
 }

@@ -21,12 +21,20 @@ namespace {
 
 constexpr int kGT = 128;  // output tile edge (terms)
 
-// sum the row-split partials and scatter tile (I, J) and its mirror into the full symmetric
-// p x p matrix; ACC: add to what G holds (later row chunks of the chunked panel back end)
-template <bool ACC>
+// Sum the row-split partials of tile pair (I, J) and write it where the fit wants it (GramSink):
+//   full symmetric p x p (the tile and its mirror) -- raw G, or, with `form`, the Hessian
+//       H = e2 G + diag(prec) of lpdfvec::hess_ (fit.cpp:503-512, loglik_std.cpp:170-173,
+//       logpr_gauss.cpp:153-158) and its diagonal, so that no further pass over p x p follows;
+//   packed upper triangle (row i: entries j >= i at i p - i (i - 1) / 2 + (j - i)) -- the
+//       exchange buffer of a row-sharded fit, written here directly.
+// acc: add to what the destination holds (later row chunks of the chunked panel back end);
+// form then applies to the accumulated sum (last chunk only).
+__device__ __forceinline__ uint64_t tri_row(uint64_t i, uint64_t p) { return i * p - i * (i - 1) / 2; }
+
 __global__ void __launch_bounds__(256)
 k_gram_reduce(const double *__restrict__ part, int npairs, int nsplit, int nb, int p,
-              double *__restrict__ G) {
+              double *__restrict__ G, int acc, int packed, int form, double e2,
+              const double *__restrict__ prec, double *__restrict__ diagH) {
   __shared__ double S[64 * 65];  // one 64 x 64 quadrant, so that the mirror goes out in rows too
   int I = 0, rem = blockIdx.x;
   while (rem >= nb - I) {
@@ -38,26 +46,36 @@ k_gram_reduce(const double *__restrict__ part, int npairs, int nsplit, int nb, i
   for (int qd = 0; qd < 4; ++qd) {
     const int qr = qd >> 1, qc = qd & 1;
     if (I == J && qr > qc) continue;  // diagonal tiles: the lower-left quadrant is the mirror
+    const bool dq = I == J && qr == qc;  // quadrant on the diagonal of G
+    const int gi0 = I * kGT + qr * 64, gj0 = J * kGT + qc * 64;
     // sum of the row-split partials, 64 consecutive doubles per wave load
     for (int r = r4; r < 64; r += 4) {
       const int e = (qr * 64 + r) * kGT + qc * 64 + c;
       double s = 0.0;
 #pragma unroll 8
       for (int k = 0; k < nsplit; ++k) s += part[((uint64_t)k * npairs + blockIdx.x) * (kGT * kGT) + e];
+      const bool in = gi0 + r < p && gj0 + c < p;
+      if (in && !(dq && c < r)) {  // the entry (gi0 + r, gj0 + c), j >= i
+        const uint64_t i = (uint64_t)(gi0 + r), j = (uint64_t)(gj0 + c);
+        double *g = packed ? &G[tri_row(i, p) + (j - i)] : &G[i * p + j];
+        if (acc) s += *g;
+        if (form) {
+          s *= e2;
+          if (i == j) {
+            s += prec[i];
+            if (diagH) diagH[i] = s;
+          }
+        }
+        *g = s;
+      }
       S[r * 65 + c] = s;
     }
+    if (packed) continue;  // no mirror, and S is not read
     __syncthreads();
-    const int gi0 = I * kGT + qr * 64, gj0 = J * kGT + qc * 64;
     for (int r = r4; r < 64; r += 4) {
-      // G[gi0 + r][gj0 + c] and, mirrored, G[gj0 + r][gi0 + c] = S[c][r]
-      if (gi0 + r < p && gj0 + c < p && !(I == J && qr == qc && c < r)) {
-        double *g = &G[(uint64_t)(gi0 + r) * p + gj0 + c];
-        *g = ACC ? *g + S[r * 65 + c] : S[r * 65 + c];
-      }
-      if (gj0 + r < p && gi0 + c < p && !(I == J && qr == qc && c >= r)) {
-        double *g = &G[(uint64_t)(gj0 + r) * p + gi0 + c];
-        *g = ACC ? *g + S[c * 65 + r] : S[c * 65 + r];
-      }
+      // mirrored: G[gj0 + r][gi0 + c] = S[c][r], strictly below the diagonal of G only
+      if (gj0 + r < p && gi0 + c < p && !(dq && c >= r))
+        G[(uint64_t)(gj0 + r) * p + gi0 + c] = S[c * 65 + r];
     }
     __syncthreads();
   }
@@ -65,22 +83,21 @@ k_gram_reduce(const double *__restrict__ part, int npairs, int nsplit, int nb, i
 
 }  // namespace
 
-int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, double *d_G,
-                       bool accumulate) {
+int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, const GramSink &sink,
+                       bool accumulate, bool last) {
   ProfScope ps("gram_reduce");
-  if (accumulate)
-    hipLaunchKernelGGL(k_gram_reduce<true>, dim3((unsigned)npairs), dim3(256), 0, cur_stream(), part,
-                       npairs, nsplit, nb, p, d_G);
-  else
-    hipLaunchKernelGGL(k_gram_reduce<false>, dim3((unsigned)npairs), dim3(256), 0, cur_stream(), part,
-                       npairs, nsplit, nb, p, d_G);
+  const int form = sink.form && last ? 1 : 0;
+  if (form && !sink.prec) return fail(OBHIP_ERR_INVALID, "gram sink: form without the prior precisions");
+  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)npairs), dim3(256), 0, cur_stream(), part, npairs,
+                     nsplit, nb, p, sink.out, accumulate ? 1 : 0, sink.packed ? 1 : 0, form, sink.e2,
+                     sink.prec, sink.diagH);
   OB_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_gram_mfma4(const obhip_basis &b, obhip_terms &t, double *d_G);
+int launch_gram_mfma4(const obhip_basis &b, obhip_terms &t, const GramSink &sink);
 bool gram_mfma4_supports(const obhip_terms &t);
-int launch_gram_panel(const obhip_basis &b, obhip_terms &t, double *d_G);
+int launch_gram_panel(const obhip_basis &b, obhip_terms &t, const GramSink &sink);
 
 // 0 / 4 = staged design matrix (whole or in row chunks), 3 = fused kernel
 static int g_gram_backend = 0;
@@ -88,14 +105,20 @@ void set_gram_backend(int b) { g_gram_backend = b; }
 int get_gram_backend() { return g_gram_backend; }
 
 int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G) {
+  GramSink sink;
+  sink.out = d_G;
+  return launch_gram_to(b, t, sink);
+}
+
+int launch_gram_to(const obhip_basis &b, obhip_terms &t, const GramSink &sink) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   if (g_gram_backend == 3) {
     if (!gram_mfma4_supports(t))
       return fail(OBHIP_ERR_INVALID,
                   "fused Gram kernel: terms of at most 8 factors on at most 128 used basis columns");
-    return launch_gram_mfma4(b, t, d_G);
+    return launch_gram_mfma4(b, t, sink);
   }
-  return launch_gram_panel(b, t, d_G);
+  return launch_gram_panel(b, t, sink);
 }
 
 }  // namespace obhip

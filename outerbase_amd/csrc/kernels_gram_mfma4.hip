@@ -43,8 +43,6 @@
 
 namespace obhip {
 
-int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, double *d_G,
-                       bool accumulate);
 
 namespace {
 
@@ -261,7 +259,7 @@ k_gram_mfma4(const double *__restrict__ bm, const double *__restrict__ scale,
 }
 
 template <int W>
-int run_gram_mfma4(const obhip_basis &b, obhip_terms &t, double *d_G) {
+int run_gram_mfma4(const obhip_basis &b, obhip_terms &t, const GramSink &sink) {
   const int nb = (int)((t.p + kGT - 1) / kGT);
   const int npairs = nb * (nb + 1) / 2;
   const uint64_t ntiles = b.n_pad / kTileRows;
@@ -283,22 +281,22 @@ int run_gram_mfma4(const obhip_basis &b, obhip_terms &t, double *d_G) {
                        ntiles, tps, part);
     OB_HIP(hipGetLastError());
   }
-  return launch_gram_reduce(part, npairs, (int)nsplit, nb, (int)t.p, d_G, false);
+  return launch_gram_reduce(part, npairs, (int)nsplit, nb, (int)t.p, sink, false, true);
 }
 
 }  // namespace
 
 bool gram_mfma4_supports(const obhip_terms &t) { return t.Mu <= 16 * (uint64_t)kMaxPre && t.W <= 8; }
 
-int launch_gram_mfma4(const obhip_basis &b, obhip_terms &t, double *d_G) {
+int launch_gram_mfma4(const obhip_basis &b, obhip_terms &t, const GramSink &sink) {
   if (!gram_mfma4_supports(t))
     return fail(OBHIP_ERR_INVALID,
                 "4x4x4 matrix-core Gram kernel: at most 128 basis columns and 8 non-zero levels per term");
   switch (t.W) {
-    case 2: return run_gram_mfma4<2>(b, t, d_G);
-    case 4: return run_gram_mfma4<4>(b, t, d_G);
-    case 6: return run_gram_mfma4<6>(b, t, d_G);
-    default: return run_gram_mfma4<8>(b, t, d_G);
+    case 2: return run_gram_mfma4<2>(b, t, sink);
+    case 4: return run_gram_mfma4<4>(b, t, sink);
+    case 6: return run_gram_mfma4<6>(b, t, sink);
+    default: return run_gram_mfma4<8>(b, t, sink);
   }
 }
 

@@ -41,9 +41,6 @@
 
 namespace obhip {
 
-int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, double *d_G,
-                       bool accumulate);
-
 namespace {
 
 constexpr int kGT = 128;            // output tile edge (terms)
@@ -471,8 +468,8 @@ int materialize_any(const obhip_basis &b, obhip_terms &t, double *d_B) {
 }
 
 // partial tiles of B^T B over the ntiles row tiles of d_B, reduced into d_G
-int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_terms &t, double *d_G,
-                   bool accumulate) {
+int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_terms &t,
+                   const GramSink &sink, bool accumulate, bool last) {
   // OBHIP_GRAM_DBG=1: print one block's s_memtime / s_memrealtime span
   const bool dbg = getenv("OBHIP_GRAM_DBG") && atoi(getenv("OBHIP_GRAM_DBG")) != 0;
   const int nb = (int)((t.p + kGT - 1) / kGT);
@@ -550,7 +547,7 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
             "per 16-row chunk (8192 = matrix pipe saturated by two blocks)\n",
             h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0, h[2] ? (double)h[0] / h[2] : 0.0);
   }
-  return launch_gram_reduce(part, npairs, (int)nsplit, nb, (int)t.p, d_G, accumulate);
+  return launch_gram_reduce(part, npairs, (int)nsplit, nb, (int)t.p, sink, accumulate, last);
 }
 
 }  // namespace
@@ -577,12 +574,12 @@ int ensure_bmat(obhip_basis &b, obhip_terms &t) {
   return 0;
 }
 
-int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
+int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, const GramSink &sink) {
   obhip_basis &b = const_cast<obhip_basis &>(bc);
   const uint64_t ntiles = b.n_pad / kTileRows;
   if (gram_panel_supports(b, t)) {
     OB_TRY(ensure_bmat(b, t));
-    return gram_of_staged(b, b.bmat.p, ntiles, t, d_G, false);
+    return gram_of_staged(b, b.bmat.p, ntiles, t, sink, false, true);
   }
   // Not enough memory for all rows at once: stage and contract row chunks one after the
   // other, the later ones accumulating into G.  Chunk = a quarter of the free HBM (at most
@@ -605,7 +602,7 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, double *d_G) {
       ProfScope ps("materialize_B");
       OB_TRY(materialize_any(view.v, t, b.bmat.p));
     }
-    OB_TRY(gram_of_staged(b, b.bmat.p, nt, t, d_G, t0 != 0));
+    OB_TRY(gram_of_staged(b, b.bmat.p, nt, t, sink, t0 != 0, t0 + nt >= ntiles));
   }
   return 0;
 }

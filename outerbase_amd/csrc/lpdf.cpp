@@ -937,8 +937,13 @@ struct LpdfVec : obhip_lpdf {
     OB_TRY(dth.upload(coeff.data(), p));
     OB_TRY(ddiag.alloc(p));
     // (no value asked for: the update() below evaluates the fit anyway)
-    OB_TRY(obhip_fit_cg_dev(lik->ob, lik->t, om, lik->y.p, lik->para[0], pr->para[0], tol, maxepch,
-                            dth.p, &cgiters, ddiag.p, nullptr, lik->comm));
+    int finite = 1;
+    OB_TRY(fit_cg_dev_impl(lik->ob, lik->t, om, lik->y.p, lik->para[0], pr->para[0], tol, maxepch,
+                           dth.p, &cgiters, ddiag.p, nullptr, lik->comm, &finite));
+    if (!finite) {  // fit.cpp:53-56: val = -inf and no further update(), as obhip_lpdf::optcg
+      val = -std::numeric_limits<double>::infinity();
+      return 0;
+    }
     std::vector<double> c(p);
     OB_TRY(d2h(c.data(), dth.p, p * sizeof(double)));
     compute_gradhyp = compute_gradpara = true;  // fit.cpp:87-93

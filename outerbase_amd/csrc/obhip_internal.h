@@ -282,7 +282,21 @@ int launch_tmm_generic(const obhip_basis &b, obhip_terms &t, const double *d_a, 
                        bool squared);
 int launch_materialize_generic(const obhip_basis &b, obhip_terms &t, double *d_B);
 // kernels_gram.hip
+// where k_gram_reduce puts the summed tiles: full symmetric p x p (raw G, or with `form` the
+// Hessian e2 G + diag(prec) and its diagonal) or the packed upper triangle of a row-sharded
+// fit's exchange buffer
+struct GramSink {
+  double *out = nullptr;
+  bool packed = false;
+  bool form = false;
+  double e2 = 1.0;
+  const double *prec = nullptr;  // p, device
+  double *diagH = nullptr;       // p, device, may be null
+};
 int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G);
+int launch_gram_to(const obhip_basis &b, obhip_terms &t, const GramSink &sink);
+int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, const GramSink &sink,
+                       bool accumulate, bool last);
 void set_gram_backend(int b);
 int get_gram_backend();
 // kernels_gram_panel.hip
@@ -340,5 +354,10 @@ int launch_fill(double *d_v, uint64_t n, double c);
 // comm.cpp: in-place sum over the ranks of c (no-op for c == nullptr or one rank)
 int comm_allreduce(obhip_comm *c, double *d_buf, uint64_t count);
 int comm_nranks(const obhip_comm *c);
+// obhip_fit_cg_dev with the non-finite exit of fit.cpp:53-56 reported (finite_out = 0, val = -inf)
+int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *t, const obhip_model *m, const double *d_y,
+                    double sigma, double rho, double tol, uint64_t maxit, double *d_theta,
+                    uint64_t *iters_out, double *d_diagH, double *val_out, obhip_comm *comm,
+                    int *finite_out);
 
 }  // namespace obhip

@@ -124,32 +124,22 @@ class HotPath:
         self.xnew = torch.empty((d, n), dtype=f64, device=dev)
         self.y_raw = torch.empty(n, dtype=f64, device=dev)
         self.y = torch.empty(n, dtype=f64, device=dev)
-        self.ones = torch.ones(n, dtype=f64, device=dev)
         self.mean = torch.empty(n, dtype=f64, device=dev)
         self.G = torch.empty((p, p), dtype=f64, device=dev)
         self.g = torch.empty(p, dtype=f64, device=dev)
-        self.b1 = torch.empty(p, dtype=f64, device=dev)
         self.theta = torch.zeros(p, dtype=f64, device=dev)
         self.diagH = torch.empty(p, dtype=f64, device=dev)
-        self.stats = torch.zeros(4, dtype=f64, device=dev)
         self.meansd = torch.zeros(3, dtype=f64, device=dev)
         wsb = C.c_uint64(0)
         call("obhip_newton_workspace_bytes", p, C.byref(wsb))
         self.ws = torch.empty(wsb.value, dtype=torch.uint8, device=dev)
         self.wsb = wsb.value
         cnt = C.c_uint64(0)
-        call("obhip_normal_eq_count", p, self.world, C.byref(cnt))
+        call("obhip_fit_newton_count", p, self.world, C.byref(cnt))
         self.ex_count = cnt.value
-        # the exchange buffer [packed triangle | g | b1 | 3 scalars | padding].  With one rank
-        # the triangle part is never touched (G stays where it is), so only the tail gets
-        # memory and the buffer address is offset accordingly.
-        tri = p * (p + 1) // 2
-        if self.world > 1:
-            self.exbuf = torch.zeros(self.ex_count, dtype=f64, device=dev)
-            self.exbuf_ptr = self.exbuf.data_ptr()
-        else:
-            self.exbuf = torch.zeros(self.ex_count - tri, dtype=f64, device=dev)
-            self.exbuf_ptr = self.exbuf.data_ptr() - 8 * tri
+        # the exchange buffer of a row-sharded fit [packed triangle of G | B^T y | zero padding];
+        # one rank exchanges nothing (the Gram reduction writes H itself)
+        self.exbuf = torch.zeros(self.ex_count, dtype=f64, device=dev) if self.world > 1 else None
         self.setup_inputs()
         self.comm, self._comm_cb = make_comm(self.rank, self.world, self.transport)
 
@@ -161,7 +151,7 @@ class HotPath:
              C.byref(rv))
         return {"transport": {1: "rccl (reduce-scatter + all-gather)", 2: "host"}[tr.value],
                 "ranks": nr.value, "rccl_ranks": rr.value, "rccl_version": rv.value,
-                "bytes_per_fit": 8 * self.ex_count}
+                "bytes_per_fit": 8 * self.ex_count + 24}
 
     def setup_inputs(self):
         """(Re)generate this rank's rows of the synthetic stream in HBM."""
@@ -176,29 +166,29 @@ class HotPath:
         torch.cuda.synchronize()
         del scratch
 
+    # mean and sd of y over all rows: on the device (meansd); the host reads them only where it
+    # needs the numbers (checks, reports), never inside a step
     def _pull_standardisation(self):
         cent, sca, ntot = self.meansd.tolist()     # one small D2H (synchronises)
-        self.y_cent, self.y_sca = cent, sca
         if int(round(ntot)) != self.n_total:
             raise RuntimeError("ranks disagree on the row count: %r vs %r" % (ntot, self.n_total))
+        return cent, sca
+
+    @property
+    def y_cent(self):
+        return self._pull_standardisation()[0]
+
+    @property
+    def y_sca(self):
+        return self._pull_standardisation()[1]
+
+    def standardise(self):
+        """y = (y - mean) / sd over ALL ranks (R/fitting.R:55-57), two-pass like R's sd(): 24
+        bytes cross the ranks, nothing returns to the host."""
+        call("obhip_standardise_dev", self.comm, self.y_raw.data_ptr(), self.n, self.y.data_ptr(),
+             self.meansd.data_ptr())
         # loglik_std.cpp:51: para0 = log(0.01 * var(y)); var of the standardised y is 1
         self.sigma = math.log(0.01)
-
-    # -- y = (y - mean) / sd over ALL ranks (R/fitting.R:55-57), PCG back end -----------
-    def standardise(self):
-        """One 3-scalar exchange: (sum y, sum y^2, n) summed over ranks; the Gram back end
-        carries the same three numbers inside its one buffer instead."""
-        call("obhip_sum_sumsq_dev", self.y_raw.data_ptr(), self.n, self.stats.data_ptr())
-        self.stats[2] = float(self.n)
-        if self.comm is not None:
-            call("obhip_comm_allreduce_dev", self.comm, self.stats.data_ptr(), 3)
-        s1, s2, nt = self.stats[:3].tolist()
-        cent = s1 / nt
-        sca = math.sqrt(max(s2 - nt * cent * cent, 0.0) / (nt - 1.0))
-        self.meansd.copy_(self.torch.tensor([cent, sca, nt], dtype=self.torch.float64))
-        self.y.copy_(self.y_raw)
-        call("obhip_affine_dev", self.y.data_ptr(), self.n, cent, sca)
-        self._pull_standardisation()
 
     def fit(self):
         torch = self.torch
@@ -210,41 +200,16 @@ class HotPath:
             self.basis = h
         else:
             call("obhip_basis_rebuild", self.basis)
-        if self.backend == "newton" and self.world == 1:
-            # One rank knows mean and sd of y before anything else: standardise y as obfit does
-            # (R/fitting.R:55-57) and take B^T y of that -- no B^T 1 pass, nothing to exchange.
-            call("obhip_sum_sumsq_dev", self.y_raw.data_ptr(), self.n, self.stats.data_ptr())
-            s1, s2 = self.stats[:2].tolist()
-            nt = float(self.n)
-            cent = s1 / nt
-            sca = math.sqrt(max(s2 - nt * cent * cent, 0.0) / (nt - 1.0))
-            self.y.copy_(self.y_raw)
-            call("obhip_affine_dev", self.y.data_ptr(), self.n, cent, sca)
-            call("obhip_gram_dev", self.basis, self.t._h, self.y.data_ptr(), self.G.data_ptr(),
-                 self.g.data_ptr())
-            self.y_cent, self.y_sca = cent, sca
-            self.sigma = math.log(0.01)   # loglik_std.cpp:51 with var(y) = 1
-            call("obhip_newton_solve_dev", self.om._h, self.t._h, self.G.data_ptr(),
-                 self.g.data_ptr(), self.sigma, self.rho, self.theta.data_ptr(),
-                 self.diagH.data_ptr(), self.ws.data_ptr(), self.wsb)
-        elif self.backend == "newton":
-            # local pieces: G_r, B_r^T y_r (raw y), B_r^T 1, (sum y, sum y^2)
-            call("obhip_sum_sumsq_dev", self.y_raw.data_ptr(), self.n, self.stats.data_ptr())
-            call("obhip_gram_dev", self.basis, self.t._h, self.y_raw.data_ptr(), self.G.data_ptr(),
-                 self.g.data_ptr())
-            call("obhip_basis_tmm_dev", self.basis, self.t._h, self.ones.data_ptr(),
-                 self.b1.data_ptr(), 0)
-            # the one exchange + standardisation of the right-hand side over ALL rows
-            call("obhip_normal_eq_exchange_dev", self.comm, self.p, self.n, self.G.data_ptr(),
-                 self.g.data_ptr(), self.b1.data_ptr(), self.stats.data_ptr(), self.exbuf_ptr,
-                 self.ex_count, self.meansd.data_ptr())
-            self.sigma = math.log(0.01)
-            call("obhip_newton_solve_dev", self.om._h, self.t._h, self.G.data_ptr(),
-                 self.g.data_ptr(), self.sigma, self.rho, self.theta.data_ptr(),
-                 self.diagH.data_ptr(), self.ws.data_ptr(), self.wsb)
-            self._pull_standardisation()
+        self.standardise()
+        if self.backend == "newton":
+            # Gram on the matrix cores -> [one sum of the packed triangle + B^T y over the ranks]
+            # -> H = e^{-2 sigma} G + prior -> Cholesky, two triangular solves (replicated)
+            call("obhip_fit_newton_sharded_dev", self.comm, self.basis, self.t._h, self.om._h,
+                 self.y.data_ptr(), self.sigma, self.rho, self.G.data_ptr(), self.g.data_ptr(),
+                 self.theta.data_ptr(), self.diagH.data_ptr(),
+                 None if self.exbuf is None else self.exbuf.data_ptr(), self.ex_count,
+                 self.ws.data_ptr(), self.wsb)
         else:
-            self.standardise()
             self.theta.zero_()
             iters = C.c_uint64(0)
             maxit = self.cg_maxit
@@ -257,16 +222,13 @@ class HotPath:
 
     def standardised_targets(self):
         """(y - cent) / sca of this rank's rows (tests, parity checks)."""
-        y = self.y_raw.clone()
-        call("obhip_affine_dev", y.data_ptr(), self.n, self.y_cent, self.y_sca)
-        return y
+        return self.y.clone()
 
     def predict(self):
         call("obhip_predict_dev", self.om._h, self.t._h, self.theta.data_ptr(),
              self.xnew.data_ptr(), self.n, self.mean.data_ptr(), None, self.sigma, None)
         # obpred: y_cent + y_sca * mean (R/fitting.R:152)
-        call("obhip_affine_dev", self.mean.data_ptr(), self.n, -self.y_cent / self.y_sca,
-             1.0 / self.y_sca)
+        call("obhip_destandardise_dev", self.mean.data_ptr(), self.n, self.meansd.data_ptr())
 
     def step(self):
         self.fit()

@@ -144,3 +144,38 @@ def test_row_sharded_obfit_equals_single_process(tmp_path):
     assert np.max(np.abs(two[0]["mean"] - one["mean"])) < 1e-4 * sd
     assert np.sqrt(np.mean((two[0]["mean"] - one["truth"]) ** 2)) < 0.03 * sd      # 60 terms only
     assert np.all(two[0]["var"] > 0)
+
+
+@pytest.mark.timeout(1500)
+def test_bench_self_launch_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a process that has not touched the GPU: bench.py starts
+    its own two rank processes (torch.distributed.run), which share the one GPU of the test box
+    and sum the exchange buffer through libobhip's host transport over gloo
+    (OBHIP_DIST_BACKEND=gloo).  The line must describe a 2-rank strong-scaling job, and the
+    predictions must be those of the 1-rank run on the same 200 000 rows."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    base = [sys.executable, bench, "--rows", "200000", "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline", "--no-config3"]
+    env = dict(os.environ, OBHIP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    d2, d1 = str(tmp_path / "two.npz"), str(tmp_path / "one.npz")
+    r2 = subprocess.run(base + ["--gpus", "2", "--dump", d2], env=env, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, timeout=900)
+    assert r2.returncode == 0, r2.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in r2.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r2.stdout.decode()[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["exchange"]["ranks"] == 2 and line["exchange"]["transport"] == "host"
+    assert line["config"]["rows_total"] == 200000 and line["config"]["rows_per_gpu"] == 100000
+    assert line["value"] > 0 and line["alt_backend"]["max_rel_diff_of_predictions_vs_newton"] < 1e-6
+    r1 = subprocess.run(base + ["--gpus", "1", "--no-alt-backend", "--dump", d1], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r1.returncode == 0, r1.stderr.decode(errors="replace")[-3000:]
+    two, one = np.load(d2), np.load(d1)
+    assert int(two["world"]) == 2 and int(one["world"]) == 1 and int(two["n_total"]) == 200000
+    assert np.max(np.abs(two["meansd"] - one["meansd"])) < 1e-12 * np.max(np.abs(one["meansd"]))
+    assert np.max(np.abs(two["mean"] - one["mean"])) < 1e-6 * np.max(np.abs(one["mean"]))
+    assert np.max(np.abs(two["theta"] - one["theta"])) < 1e-6 * np.max(np.abs(one["theta"]))

@@ -98,3 +98,119 @@ def test_exchange_without_communicator_only_standardises():
     want = (g - cent * b1) / sd
     assert np.max(np.abs(dg.cpu().numpy() - want)) < 1e-11 * np.max(np.abs(want))
     assert abs(float(ms[1]) - sd) < 1e-10 * sd
+
+
+def test_one_rank_host_communicator_without_callback_is_the_identity():
+    """obhip_comm_init_host accepts fn = NULL for one rank; every exchange is then a no-op
+    (round 2 called the null pointer)."""
+    import torch
+    from outerbase_amd._lib import call, lib
+    h = C.c_void_p()
+    call("obhip_comm_init_host", C.byref(h), 1, 0, None, None)
+    try:
+        v = torch.arange(5000, dtype=torch.float64, device="cuda")
+        w = v.clone()
+        call("obhip_comm_allreduce_dev", h, w.data_ptr(), 5000)
+        torch.cuda.synchronize()
+        assert torch.equal(v, w)
+        # a two-rank communicator still needs its callback
+        h2 = C.c_void_p()
+        assert lib.obhip_comm_init_host(C.byref(h2), 2, 0, None, None) != 0
+    finally:
+        lib.obhip_comm_destroy(h)
+
+
+@pytest.mark.parametrize("shift", [0.0, 1e7])
+def test_standardise_dev_is_two_pass(shift):
+    """(y - mean) / sd with the n - 1 denominator (R/fitting.R:55-57) as R's sd() computes it:
+    centred sum of squares, so a mean 1e7 standard deviations away costs no digits (the
+    one-pass sum y^2 - n mean^2 of round 2 lost 14 of them there)."""
+    import torch
+    from outerbase_amd._lib import call
+    rng = np.random.default_rng(3)
+    y = shift + rng.standard_normal(70001)
+    dy = torch.from_numpy(y).cuda()
+    out = torch.empty_like(dy)
+    ms = torch.zeros(3, dtype=torch.float64, device="cuda")
+    call("obhip_standardise_dev", None, dy.data_ptr(), len(y), out.data_ptr(), ms.data_ptr())
+    torch.cuda.synchronize()
+    cent, sd = y.mean(), y.std(ddof=1)
+    got = ms.cpu().numpy()
+    assert abs(got[0] - cent) <= 1e-15 * abs(cent) + 1e-16 and abs(got[1] - sd) < 1e-12 * sd and got[2] == len(y)
+    want = (y - cent) / sd
+    assert np.max(np.abs(out.cpu().numpy() - want)) < (1e-8 if shift else 1e-13)
+    back = out.clone()
+    call("obhip_destandardise_dev", back.data_ptr(), len(y), ms.data_ptr())
+    torch.cuda.synchronize()
+    assert np.max(np.abs(back.cpu().numpy() - y)) < 1e-15 * (abs(shift) + 10)
+
+
+@pytest.mark.parametrize("n,p,chunk", [(3000, 300, 0), (1500, 129, 0), (5000, 260, 1024), (700, 1, 0)])
+def test_fit_newton_sharded_entry_equals_the_composed_calls(n, p, chunk, monkeypatch):
+    """obhip_fit_newton_sharded_dev -- the Gram reduction writing H (one rank) or the packed
+    exchange triangle (communicator), the unpack forming H -- against the round-2 composition
+    obhip_gram_dev + obhip_newton_solve_dev (k_gram_reduce to full storage, k_form_hessian) and
+    against the oracle; also with the design matrix staged in row chunks."""
+    import torch
+    import ob_oracle as O
+    from conftest import make_pair, knots_for
+    from outerbase_amd._lib import call, lib
+    from outerbase_amd import obmod
+    kinds = ["mat25", "mat25pow", "mat25ang", "mat25"]
+    om_o, om = make_pair(kinds, knots_for(kinds, 20))
+    terms = om_o.selectterms(p)
+    t = obmod._Terms(om, terms)
+    x, y = O.synth_xy(7, 0, n, kinds)
+    y = (y - y.mean()) / y.std(ddof=1)
+    sigma, rho = math.log(0.01), 6.0
+    dx = torch.from_numpy(np.ascontiguousarray(x.T)).cuda()
+    dy = torch.from_numpy(y).cuda()
+    if chunk:
+        monkeypatch.setenv("OBHIP_GRAM_CHUNK_ROWS", str(chunk))
+    basis = C.c_void_p()
+    call("obhip_basis_create_dev", C.byref(basis), om._h, dx.data_ptr(), n, t.maxlevels().ctypes.data)
+    wsb = C.c_uint64(0)
+    call("obhip_newton_workspace_bytes", p, C.byref(wsb))
+    ws = torch.empty(wsb.value, dtype=torch.uint8, device="cuda")
+
+    def bufs():
+        return (torch.full((p, p), float("nan"), dtype=torch.float64, device="cuda"),
+                torch.empty(p, dtype=torch.float64, device="cuda"),
+                torch.empty(p, dtype=torch.float64, device="cuda"),
+                torch.empty(p, dtype=torch.float64, device="cuda"))
+    try:
+        # round-2 composition
+        G0, g0, th0, dh0 = bufs()
+        call("obhip_gram_dev", basis, t._h, dy.data_ptr(), G0.data_ptr(), g0.data_ptr())
+        Graw = G0.cpu().numpy().copy()
+        call("obhip_newton_solve_dev", om._h, t._h, G0.data_ptr(), g0.data_ptr(), sigma, rho,
+             th0.data_ptr(), dh0.data_ptr(), ws.data_ptr(), wsb.value)
+        # one rank, no communicator: the reduction writes H
+        G1, g1, th1, dh1 = bufs()
+        call("obhip_fit_newton_sharded_dev", None, basis, t._h, om._h, dy.data_ptr(), sigma, rho,
+             G1.data_ptr(), g1.data_ptr(), th1.data_ptr(), dh1.data_ptr(), None, 0, ws.data_ptr(), wsb.value)
+        torch.cuda.synchronize()
+        assert torch.equal(th0, th1) and torch.equal(dh0, dh1) and torch.equal(g0, g1)
+        # a one-rank communicator: packed triangle -> exchange (identity) -> unpack forms H
+        comm = C.c_void_p()
+        call("obhip_comm_init_host", C.byref(comm), 1, 0, None, None)
+        cnt = C.c_uint64(0)
+        call("obhip_fit_newton_count", p, 1, C.byref(cnt))
+        ex = torch.zeros(cnt.value, dtype=torch.float64, device="cuda")
+        G2, g2, th2, dh2 = bufs()
+        call("obhip_fit_newton_sharded_dev", comm, basis, t._h, om._h, dy.data_ptr(), sigma, rho,
+             G2.data_ptr(), g2.data_ptr(), th2.data_ptr(), dh2.data_ptr(), ex.data_ptr(), cnt.value,
+             ws.data_ptr(), wsb.value)
+        torch.cuda.synchronize()
+        lib.obhip_comm_destroy(comm)
+        tri = p * (p + 1) // 2
+        hb = ex.cpu().numpy()
+        assert np.array_equal(hb[:tri], Graw[np.triu_indices(p)])       # the raw G, packed
+        assert np.array_equal(hb[tri:tri + p], g0.cpu().numpy()) and not hb[tri + p:].any()
+        assert torch.equal(th0, th2) and torch.equal(dh0, dh2) and torch.equal(g0, g2)
+        assert torch.equal(torch.tril(G0), torch.tril(G2))                 # the same factor
+        # and the oracle
+        theta_o, _ = O.fit_newton(O.OuterBase(om_o, x), terms, y, sigma=sigma)
+        assert np.max(np.abs(th1.cpu().numpy() - theta_o)) < 1e-6 * np.max(np.abs(theta_o))
+    finally:
+        lib.obhip_basis_destroy(basis)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, "declared in include/obhip.h but not exported: %s" % missing
     extra = sorted(s for s in exported if s.startswith("obhip_") and s not in protos)
     assert not extra, "exported but not declared: %s" % extra
-    assert _lib.lib.obhip_abi_version() == 2
+    assert _lib.lib.obhip_abi_version() == 3
 
 
 def test_header_cites_reference_for_every_entry_point():
