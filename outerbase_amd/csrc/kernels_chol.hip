@@ -580,432 +580,6 @@ k_chol_back(const double *__restrict__ L, double *__restrict__ z, double *__rest
   }
 }
 
-// ---- look-ahead factorisation (128 <= p <= 8192) ---------------------------------------------
-// The two-panel schedule above puts four dependent launches on the critical path of every 128
-// columns (panel, strip, panel, trailing pass: 2.2 ms at p = 4096, where the arithmetic is
-// worth 0.3).  What the NEXT panel step needs of the current one is little: the factor of the
-// next diagonal block.  So ONE launch per 64 columns; launch k holds
-//   * the panel workgroups of block column k: row block i > k (and the right-hand side z, an
-//     extra matrix row) takes its tile A(i, k), applies the one or two panels the trailing
-//     passes have not reached yet ("strip": its own rows of their k-major copies straight from
-//     HBM as MFMA operands, block k's rows through LDS), solves X L_kk^T = A with the factor
-//     and the 16 x 16 inverses the previous launch left, and adds -X X^T to its own diagonal
-//     tile's side buffer Dg[i] (the diagonal tiles of H are never touched by a trailing pass);
-//   * among them the workgroup of row block k + 1, which goes on to factorise
-//     D = H(k+1, k+1) + Dg[k+1] (the serial part: a pivot chain per column) and leaves L and its
-//     inverses for launch k + 1 -- the critical path of the whole factorisation is
-//     [solve one tile, factorise one tile] per 64 columns;
-//   * HALF of a rank-128 trailing pass: panels (j, j + 1), j even, are applied together to the
-//     tiles right of block column j + 2 -- half the traffic over the trailing matrix of two
-//     rank-64 passes, which is what bounds it -- in launches j + 2 (block column j + 3, needed
-//     next, and every other tile beyond it) and j + 3 (the rest).  No workgroup of the launch
-//     reads what these write.
-// No workgroup waits for another one of its launch, so the launch drains however the blocks
-// are scheduled.  65 dependent launches instead of 192.
-constexpr int LA_KH = 32;        // k per staged part of a trailing tile's operands
-constexpr int LA_UP = NB + 16;   // LDS pitch of such a part's row (64 matrix rows)
-constexpr int LA_SB1 = 0;                     // block k's rows of panel k - 2 [64 k][64] (strip, k even)
-constexpr int LA_SB0 = NB * LT;               // ... of panel k - 1
-constexpr int LA_X = NB * LT;                 // solved rows X [64][LDP] (after the strip); later the tile D
-constexpr int LA_TS = LA_X + NB * LDP;        // per-wave 16 x 16 scratch
-constexpr int LA_DINV = LA_TS + 4 * 16 * SP;
-constexpr int LA_END = LA_DINV + NB;
-static_assert(LA_SB0 + NB * NB <= LA_END && 2 * LA_KH * LA_UP <= LA_END, "aliases fit");
-static_assert(LA_END * 8 <= 80 * 1024, "two workgroups per CU");
-
-// OBHIP_CHOL_DBG=1: [0] earliest start and [1] latest end of a launch's workgroups, [2..7] the
-// phases of its diagonal workgroup (s_memrealtime, 10 ns)
-struct LaStamp {
-  unsigned long long *d;
-  int tid;
-  __device__ __forceinline__ void begin() const {
-    if (d && tid == 0) atomicMin(d, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  }
-  __device__ __forceinline__ void end() const {
-    if (d && tid == 0) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      atomicMax(d + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    }
-  }
-  __device__ __forceinline__ void phase(int i, bool on) const {
-    if (d && on && tid == 0) d[2 + i] = __builtin_amdgcn_s_memrealtime();
-  }
-};
-
-// t = 0 .. 9 -> the 16 x 16 tile (rt >= ct) of a 64 x 64 lower triangle, in potrf_trailing's order
-__device__ __forceinline__ void la_tile(int t, int &rt, int &ct) {
-  rt = t >= 6 ? 3 : (t >= 3 ? 2 : (t >= 1 ? 1 : 0));
-  ct = t - rt * (rt + 1) / 2;
-}
-
-// one wave instruction: 1 KB gathered from gbase + voff (16 bytes per lane) -> LDS at lds_addr + 16 lane
-__device__ __forceinline__ void la_dma_1k(const char *gbase /* uniform */, uint32_t voff,
-                                          uint32_t lds_addr /* uniform */) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-               :: "v"(voff), "s"(gbase), "s"(lds_addr) : "memory");
-}
-
-// P (64 x 64, pitch LDP, lower triangle filled, identity beyond db) -> L into the lower triangle
-// of H's diagonal block at d0 and the inverses of its four 16 x 16 diagonal sub-blocks to iout
-__device__ __forceinline__ void la_factor_diag(double *P, double *Lt, double *dinv, double *__restrict__ H,
-                                               int p, int d0, int db, int *info, double *__restrict__ iout,
-                                               int tid, int wave, int lane) {
-  bool bad = false;
-  if (wave == 0) potrf_block<0>(P, bad, Lt, dinv, lane);
-  __syncthreads();
-  potrf_trailing<0>(P, Lt, wave, lane);
-  __syncthreads();
-  if (wave == 0) potrf_block<16>(P, bad, Lt, dinv, lane);
-  __syncthreads();
-  potrf_trailing<16>(P, Lt, wave, lane);
-  __syncthreads();
-  if (wave == 0) potrf_block<32>(P, bad, Lt, dinv, lane);
-  __syncthreads();
-  potrf_trailing<32>(P, Lt, wave, lane);
-  __syncthreads();
-  if (wave == 0) {
-    potrf_block<48>(P, bad, Lt, dinv, lane);
-    if (bad && lane == 0) atomicCAS(info, 0, d0 + 1);
-  }
-  __syncthreads();
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    if (c <= r && r < db) H[(size_t)(d0 + r) * p + d0 + c] = Lt[c * LT + r];
-  }
-  // inverse of the 16 x 16 diagonal sub-block `wave`: lane j < 16 solves L_ww x = e_j
-  const int j = lane & 15, o = 16 * wave;
-  double x[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) x[i] = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const double xi = x[i] * dinv[o + i];
-    x[i] = xi;
-#pragma unroll
-    for (int m = i + 1; m < 16; ++m) x[m] = fma(-Lt[(o + i) * LT + o + m], xi, x[m]);
-  }
-  if (lane < 16) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) iout[wave * 256 + i * 16 + j] = x[i];
-  }
-}
-
-// the factor of the first diagonal block (the launch before step 0)
-__global__ void __launch_bounds__(256)
-k_chol_la_first(double *__restrict__ H, int p, int *__restrict__ info, double *__restrict__ Iinv) {
-  __shared__ __attribute__((aligned(16))) double raw[LA_END];
-  double *Lt = raw, *P = raw + LA_X, *dinv = raw + LA_DINV;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int db = min(NB, p);
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    P[r * LDP + c] = (r < db && c < db) ? H[(size_t)max(r, c) * p + min(r, c)] : (r == c ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  la_factor_diag(P, Lt, dinv, H, p, 0, db, info, Iinv, tid, wave, lane);
-}
-
-// Grid of launch k: [npan panel workgroups: row blocks k + 1 .. nblk - 1, then z]
-// [ncol tiles of block column k + 1 (k even)] [nhalf tiles: every other strictly lower tile over
-// the blocks >= k + 2 (k even: the even ones; k odd: the odd ones over the blocks >= k + 1)]
-// [nz blocks of 256 entries of z (k even)].  jp = the even panel j of the rank-128 pass this
-// launch carries a half of (k - 2 or k - 3; < 0: none).
-__global__ void __launch_bounds__(256, 2)
-k_chol_la(double *__restrict__ H, double *__restrict__ z, double *__restrict__ Wt, int pw, int p, int k,
-          int nblk, int npan, int ncol, int nhalf, int jp, int *__restrict__ info,
-          double *__restrict__ Iinv, double *__restrict__ Dg,
-          unsigned long long *__restrict__ dbg /* OBHIP_CHOL_DBG: per step 8 time stamps (100 MHz) */) {
-  __shared__ __attribute__((aligned(16))) double raw[LA_END];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t16 = lane & 15, q = lane >> 4;
-  LaStamp stamp{dbg ? dbg + 8 * k : nullptr, tid};
-  stamp.begin();
-  const int pz = nblk * NB;  // the right-hand side's "row" in the k-major copies
-  const int j0 = k * NB, jb = min(NB, p - j0);
-  const size_t slot = (size_t)NB * pw;  // Wt: a ring of four panel copies, panel j in slot j & 3
-
-  if ((int)blockIdx.x >= npan) {
-    // ---- half of the rank-128 trailing pass of panels (jp, jp + 1) ---------------------------
-    const double *__restrict__ W0 = Wt + (size_t)(jp & 3) * slot;
-    const double *__restrict__ W1 = Wt + (size_t)((jp + 1) & 3) * slot;
-    int bt = (int)blockIdx.x - npan;
-    if (bt >= ncol + nhalf) {
-      // z[c] -= sum over the 128 k of the two panels z_j[kk] L[c][64 j + kk], c >= 64 (k + 1)
-      const int c = j0 + NB + (bt - ncol - nhalf) * 256 + tid;
-      if (c < p) {
-        double s = z[c];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const double *W = h ? W1 : W0;
-          double w[NB];
-#pragma unroll
-          for (int kk = 0; kk < NB; ++kk) w[kk] = W[(size_t)kk * pw + c];
-#pragma unroll
-          for (int kk = 0; kk < NB; ++kk) s = fma(-W[(size_t)kk * pw + pz], w[kk], s);
-        }
-        z[c] = s;
-      }
-      stamp.end();
-      return;
-    }
-    // the tile (bi > bj), block indices
-    int bi, bj;
-    if (bt < ncol) {
-      bj = k + 1;
-      bi = k + 2 + bt;
-    } else {
-      const int base = (k & 1) ? k + 1 : k + 2;   // strictly lower tiles over the blocks >= base
-      int t = 2 * (bt - ncol) + (k & 1);          // k even: the even ones, k odd: the odd ones
-      int r = 1;                                  // row r (relative) holds r tiles: (r, 0 .. r - 1)
-      while (t >= r) {
-        t -= r;
-        ++r;
-      }
-      bi = base + r;
-      bj = base + t;
-    }
-    const int wm = wave >> 1, wn = wave & 1;
-    const int rbase = bi * NB + wm * 32, cbase = bj * NB + wn * 32;
-    d4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + i * 16 + q + 4 * r, col = cbase + j * 16 + t16;
-          acc[i][j][r] = row < p ? H[(size_t)row * p + col] : 0.0;
-        }
-    // operands: 4 parts of 32 k (two per panel), all requested up front
-    double *Sa = raw, *Sb = raw + LA_KH * LA_UP;
-    d2v ga[4][4], gb[4][4];
-#pragma unroll
-    for (int part = 0; part < 4; ++part) {
-      const double *W = (part >> 1) ? W1 : W0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = tid + 256 * u, kk = e >> 5, c2 = e & 31;
-        ga[part][u] = *(const d2v *)(W + (size_t)((part & 1) * LA_KH + kk) * pw + bi * NB + 2 * c2);
-        gb[part][u] = *(const d2v *)(W + (size_t)((part & 1) * LA_KH + kk) * pw + bj * NB + 2 * c2);
-      }
-    }
-#pragma unroll
-    for (int part = 0; part < 4; ++part) {
-      if (part > 0) __syncthreads();
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = tid + 256 * u, kk = e >> 5, c2 = e & 31;
-        *(d2v *)&Sa[kk * LA_UP + 2 * c2] = ga[part][u];
-        *(d2v *)&Sb[kk * LA_UP + 2 * c2] = gb[part][u];
-      }
-      __syncthreads();
-      const double *pa = Sa + q * LA_UP + wm * 32 + t16;
-      const double *pb = Sb + q * LA_UP + wn * 32 + t16;
-#pragma unroll
-      for (int s = 0; s < LA_KH / 4; ++s) {
-        double a[2], b[2];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          a[f] = -pa[4 * s * LA_UP + 16 * f];
-          b[f] = pb[4 * s * LA_UP + 16 * f];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + i * 16 + q + 4 * r, col = cbase + j * 16 + t16;
-          if (row < p) H[(size_t)row * p + col] = acc[i][j][r];
-        }
-    stamp.end();
-    return;
-  }
-
-  // ---- panel workgroups of block column k ---------------------------------------------------
-  const bool is_z = (int)blockIdx.x == npan - 1;
-  const bool is_diag = blockIdx.x == 0 && !is_z;
-  const int r0 = is_z ? pz : (k + 1 + (int)blockIdx.x) * NB;  // first row (index in the k-major copies)
-  const int nrows = is_z ? 1 : min(NB, p - r0);
-  const int npend = k == 0 ? 0 : ((k & 1) ? 1 : 2);           // panels k - npend .. k - 1 not yet applied
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)raw;
-  // block k's rows of the pending panels -> LDS, [64 k][64 rows], 2 k per wave instruction
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    if (j < npend) {
-      const char *g = (const char *)(Wt + (size_t)((k - 1 - j) & 3) * slot + j0);
-      const uint32_t base = lds0 + (j ? LA_SB1 : LA_SB0) * 8;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int kk = 2 * (wave * 8 + i) + (lane >> 5);
-        la_dma_1k(g, (uint32_t)kk * (uint32_t)pw * 8u + (lane & 31) * 16u, base + (wave * 8 + i) * 1024);
-      }
-    }
-  }
-  // the tile A(i, k) into the accumulators, wave w rows 16 w .. 16 w + 15, all 64 columns
-  d4 acc[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * wave + q + 4 * r, col = 16 * b + t16;
-      double v = 0.0;
-      if (row < nrows && col < jb) v = is_z ? z[j0 + col] : H[(size_t)(r0 + row) * p + j0 + col];
-      acc[b][r] = v;
-    }
-  // its own rows of the pending panels: MFMA A operands straight from the k-major copies
-  double aop[2][16];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-      aop[j][s] = j < npend ? Wt[(size_t)((k - 1 - j) & 3) * slot + (size_t)(4 * s + q) * pw + r0 + 16 * wave + t16] : 0.0;
-  // L_kk (identity beyond jb) and the inverses of its 16 x 16 diagonal sub-blocks -> registers
-  double lreg[16], ivr[4][4];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int e = tid + 256 * i, r = e >> 6, c = e & 63;
-    lreg[i] = (r < jb && c <= r) ? H[(size_t)(j0 + r) * p + j0 + c] : ((r == c) ? 1.0 : 0.0);
-  }
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) ivr[b][s] = Iinv[(size_t)k * 1024 + b * 256 + t16 * 16 + 4 * s + q];
-  stamp.phase(4, is_diag);
-  if (npend > 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the LDS-direct loads landed
-    __syncthreads();
-    stamp.phase(5, is_diag);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j < npend) {
-        const double *Sb = raw + (j ? LA_SB1 : LA_SB0);
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aop[j][s], Sb[(4 * s + q) * NB + 16 * b + t16], acc[b], 0, 0, 0);
-      }
-    }
-    __syncthreads();  // the staged rows are done with: the solve's buffers take their place
-  }
-  stamp.phase(0, is_diag);
-  double *Lt = raw, *Xall = raw + LA_X, *dinv = raw + LA_DINV;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int e = tid + 256 * i, r = e >> 6, c = e & 63;
-    Lt[c * LT + r] = lreg[i];  // Lt[c][kk] = L[kk][c], 0 for kk < c
-  }
-  // own diagonal tile: the side buffer (and, for the diagonal workgroup, H's tile) requested now
-  const int d0 = j0 + NB, db = min(NB, p - d0);
-  d4 dacc[3];
-  int drt[3], dct[3];
-  double *__restrict__ dg = Dg + (size_t)(k + 1 + (int)blockIdx.x) * (NB * NB);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    la_tile(min(wave + 4 * i, 9), drt[i], dct[i]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * drt[i] + q + 4 * r, col = 16 * dct[i] + t16;
-      double v = is_z ? 0.0 : dg[row * NB + col];
-      if (is_diag) {
-        const int hi = max(row, col), lo = min(row, col);
-        v += hi < db ? H[(size_t)(d0 + hi) * p + d0 + lo] : (row == col ? 1.0 : 0.0);
-      }
-      dacc[i][r] = v;
-    }
-  }
-  __syncthreads();
-  // blocked solve X L_kk^T = A, wave-local from here: X_b = (A_b - sum_{c<b} X_c L_bc^T) inv(L_bb)^T
-  double *X = Xall + wave * 16 * LDP;
-  double *T = raw + LA_TS + wave * 16 * SP;
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    d4 a2 = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < b; ++c)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(X[t16 * LDP + 16 * c + 4 * s + q],
-                                                  Lt[(16 * c + 4 * s + q) * LT + 16 * b + t16], a2, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) T[(q + 4 * r) * SP + t16] = acc[b][r] - a2[r];
-    d4 xb = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      xb = __builtin_amdgcn_mfma_f64_16x16x4f64(T[t16 * SP + 4 * s + q], ivr[b][s], xb, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * wave + q + 4 * r, col = 16 * b + t16;
-      X[(q + 4 * r) * LDP + col] = xb[r];
-      if (row < nrows && col < jb) {
-        if (is_z)
-          z[j0 + col] = xb[r];
-        else
-          H[(size_t)(r0 + row) * p + j0 + col] = xb[r];
-      }
-    }
-  }
-  // k-major copy of the solved rows: Wc[kk][row], 128-byte segments
-  if (16 * wave + t16 < nrows) {
-    double *__restrict__ Wc = Wt + (size_t)(k & 3) * slot;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int kk = 4 * i + q;
-      Wc[(size_t)kk * pw + r0 + 16 * wave + t16] = X[t16 * LDP + kk];
-    }
-  }
-  if (is_z) {
-    stamp.end();
-    return;
-  }
-  stamp.phase(1, is_diag);
-  // ---- own diagonal tile: Dg[i] -= X X^T; the diagonal workgroup factorises H(k+1,k+1) + Dg ----
-  __syncthreads();  // every wave's X rows are in LDS
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-      dacc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xall[(16 * drt[i] + t16) * LDP + 4 * s + q],
-                                                     Xall[(16 * dct[i] + t16) * LDP + 4 * s + q], dacc[i], 0, 0, 0);
-  if (!is_diag) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if (wave + 4 * i > 9) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dg[(16 * drt[i] + q + 4 * r) * NB + 16 * dct[i] + t16] = dacc[i][r];
-    }
-    stamp.end();
-    return;
-  }
-  __syncthreads();  // X is done with: D takes its place
-  double *P = Xall;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    if ((c >> 4) > (r >> 4)) P[r * LDP + c] = 0.0;  // the tiles above the diagonal (never used)
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    if (wave + 4 * i > 9) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) P[(16 * drt[i] + q + 4 * r) * LDP + 16 * dct[i] + t16] = dacc[i][r];
-  }
-  __syncthreads();
-  stamp.phase(2, true);
-  la_factor_diag(P, Lt, dinv, H, p, d0, db, info, Iinv + (size_t)(k + 1) * 1024, tid, wave, lane);
-  stamp.phase(3, true);
-  stamp.end();
-}
-
 __global__ void k_form_hessian(double *__restrict__ G, const double *__restrict__ prec, double e2,
                                int p, double *__restrict__ diagH) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1025,10 +599,8 @@ __global__ void k_form_hessian(double *__restrict__ G, const double *__restrict_
 // chol_pitch(p) doubles), scratch block for L_jj (64 x 64), the inverses of the 16 x 16
 // diagonal sub-blocks (1024 doubles per 64 columns)
 static uint64_t chol_pitch(uint64_t p) { return (p + 127) / 128 * 128 + 128; }
-// (the look-ahead schedule: four panel copies, a 64 x 64 side buffer per diagonal tile, the inverses)
 uint64_t newton_workspace_bytes(uint64_t p) {
-  const uint64_t nblk = (p + NB - 1) / NB;
-  return (p + 64 + 16 + 4 * NB * chol_pitch(p) + NB * NB + nblk * (1024 + NB * NB)) * sizeof(double);
+  return (p + 64 + 2 * NB * chol_pitch(p) + NB * NB + ((p + NB - 1) / NB) * 1024) * sizeof(double);
 }
 
 int launch_form_hessian(uint64_t p, double *d_G, const double *d_prec, double e2, double *d_diagH) {
@@ -1047,8 +619,7 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
   const int p = (int)p64;
   double *z = (double *)d_ws;
   int *info = (int *)(z + p);
-  // (128-byte aligned whatever p is: the look-ahead kernel fetches rows of it LDS-direct)
-  double *Wt = (double *)(((uintptr_t)(z + p + 64) + 127) & ~(uintptr_t)127);
+  double *Wt = z + p + 64;
   const int pw = (int)chol_pitch(p64);
   double *Ljj = Wt + (size_t)2 * NB * pw;
   double *Iinv = Ljj + NB * NB;  // [p / 64][4][16][16]: inverses of the 16 x 16 diagonal sub-blocks
@@ -1056,62 +627,7 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
   OB_HIP(hipMemsetAsync(Wt, 0, sizeof(double) * 2 * NB * pw, st));  // rows beyond p stay zero
   OB_HIP(hipMemcpyAsync(z, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, st));
   OB_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
-  // Look-ahead schedule (one launch per 64 columns, see k_chol_la) up to p = 8192
-  // (OBHIP_CHOL_LA=0: never)
-  const int la_max = getenv("OBHIP_CHOL_LA") ? atoi(getenv("OBHIP_CHOL_LA")) : 8192;
-  const bool look_ahead = p >= 2 * NB && p <= la_max;
-  if (look_ahead) {
-    ProfScope ps("cholesky");
-    const int nblk = (p + NB - 1) / NB;
-    double *Wt4 = Wt;                                   // ring of four panel copies
-    double *Dg = Wt4 + (size_t)4 * NB * pw;             // side buffers of the diagonal tiles
-    double *Iinv4 = Dg + (size_t)nblk * NB * NB;
-    OB_HIP(hipMemsetAsync(Wt4, 0, sizeof(double) * ((size_t)4 * NB * pw + (size_t)nblk * NB * NB), st));
-    const bool dbg = getenv("OBHIP_CHOL_DBG") && atoi(getenv("OBHIP_CHOL_DBG")) != 0;
-    DevBuf<unsigned long long> dbgbuf;
-    std::vector<unsigned long long> hdbg;
-    if (dbg) {
-      hdbg.assign((size_t)nblk * 8, 0);
-      for (int k = 0; k < nblk; ++k) hdbg[8 * k] = ~0ull;
-      OB_TRY(dbgbuf.upload(hdbg.data(), hdbg.size()));
-    }
-    hipLaunchKernelGGL(k_chol_la_first, dim3(1), dim3(256), 0, st, d_H, p, info, Iinv4);
-    for (int k = 0; k < nblk; ++k) {
-      const int npan = nblk - k;  // row blocks k + 1 .. nblk - 1 and the right-hand side
-      int ncol = 0, nhalf = 0, nz = 0, jp = -1;
-      if (k >= 2 && !(k & 1)) {
-        // first half of the pass of panels (k - 2, k - 1): block column k + 1 and the even tiles beyond
-        jp = k - 2;
-        ncol = std::max(0, nblk - k - 2);
-        const int m = std::max(0, nblk - k - 2), T = m * (m - 1) / 2;  // strictly lower over blocks >= k + 2
-        nhalf = (T + 1) / 2;
-        nz = std::max(0, (p - (k + 1) * NB + 255) / 256);
-      } else if (k >= 3) {
-        // second half of the pass of panels (k - 3, k - 2): the odd tiles over the blocks >= k + 1
-        jp = k - 3;
-        const int m = std::max(0, nblk - k - 1), T = m * (m - 1) / 2;
-        nhalf = T / 2;
-      }
-      hipLaunchKernelGGL(k_chol_la, dim3((unsigned)(npan + ncol + nhalf + nz)), dim3(256), 0, st, d_H, z, Wt4,
-                         pw, p, k, nblk, npan, ncol, nhalf, jp, info, Iinv4, Dg, dbgbuf.p);
-    }
-    OB_HIP(hipGetLastError());
-    if (dbg) {
-      OB_HIP(hipMemcpyAsync(hdbg.data(), dbgbuf.p, hdbg.size() * 8, hipMemcpyDeviceToHost, st));
-      OB_HIP(hipStreamSynchronize(st));
-      for (int k = 0; k < nblk; k += std::max(1, nblk / 16)) {
-        const unsigned long long *h = &hdbg[8 * k];
-        const unsigned long long *hn = k + 1 < nblk ? &hdbg[8 * (k + 1)] : nullptr;
-        fprintf(stderr, "[chol dbg] step %3d: launch span %6.2f us (next starts %5.2f us after its end); diagonal "
-                        "workgroup: loads issued %5.2f  landed %5.2f  strip %5.2f  solve %5.2f  D %5.2f  factor %5.2f us\n", k,
-                0.01 * (double)(h[1] - h[0]), hn ? 0.01 * (double)((long long)hn[0] - (long long)h[1]) : 0.0,
-                0.01 * (double)(h[6] - h[0]), h[7] ? 0.01 * (double)(h[7] - h[6]) : 0.0,
-                0.01 * (double)(h[2] - (h[7] ? h[7] : h[6])), 0.01 * (double)(h[3] - h[2]),
-                0.01 * (double)(h[4] - h[3]), 0.01 * (double)(h[5] - h[4]));
-      }
-    }
-    Iinv = Iinv4;  // the back-substitution reads the inverses where this schedule put them
-  } else {
+  {
     ProfScope ps("cholesky");
     // L_jj of the last panel of a pass: nothing follows that would move it into place
     auto place_ljj = [&](int j0) -> int {
