@@ -161,10 +161,29 @@ __device__ __forceinline__ void lds_rd_h1(const uint32_t (&baddr)[4], double (&b
 // upper triangular.  DBG: one block reports its s_memtime / s_memrealtime span (clock and
 // matrix-pipe cycles per chunk under load, OBHIP_GRAM_DBG=1); production carries none of it.
 constexpr int kAtbGram = 0, kAtbNorm = 1, kAtbStore = 2;
-__host__ __device__ inline uint64_t atb_task(uint64_t I, uint64_t J, uint64_t y) {
-  return I | (J << 24) | (y << 48);
+__host__ __device__ inline uint64_t atb_task(uint64_t I, uint64_t J, uint64_t y, uint64_t type = 0) {
+  return I | (J << 24) | (y << 48) | (type << 62);
 }
 constexpr uint64_t kAtbNoTask = ~0ull;
+// What the four waves of a block do with the 256 staged columns [panel I | panel J] of a chunk:
+// per wave one byte = A operand's 64-column group (2 bits) | B operand's (2 bits) << 2 |
+// quadrant row << 4 | quadrant column << 5 | output tile (0: (I, I), 1: (J, J), 2: (I, J)) << 6.
+//   type 0: the four quadrants of tile pair (I, J).
+//   types 1-3 (Gram only): a diagonal tile (I, I) needs three 64 x 64 wave tiles, not four (its
+//   lower-left quadrant is the mirror of the upper-right one), so FOUR consecutive diagonal tiles
+//   i .. i + 3 are twelve wave tiles = three blocks, each staging two neighbouring panels:
+//   (i, i + 1) takes i's three and (lo, lo) of i + 1; (i + 1, i + 2) the other two of i + 1 and
+//   two of i + 2; (i + 2, i + 3) the last of i + 2 and i + 3's three.  One block in four of the
+//   diagonal's saved: 1.5 % of all blocks at p = 4096.
+__device__ __forceinline__ uint32_t atb_wave_code(uint32_t type, int wave) {
+  constexpr uint32_t W = 0x80u;  // output tile (I, J)
+  const uint32_t t0 = (W | 0x08u) | (W | 0x2cu) << 8 | (W | 0x19u) << 16 | (W | 0x3du) << 24;
+  const uint32_t t1 = 0x00u | 0x24u << 8 | 0x35u << 16 | 0x4au << 24;
+  const uint32_t t2 = 0x24u | 0x35u << 8 | 0x4au << 16 | 0x6eu << 24;
+  const uint32_t t3 = 0x35u | 0x4au << 8 | 0x6eu << 16 | 0x7fu << 24;
+  const uint32_t tab = type == 0 ? t0 : (type == 1 ? t1 : (type == 2 ? t2 : t3));
+  return (tab >> (8 * wave)) & 0xffu;
+}
 
 template <int MODE, bool DBG>
 __global__ void __launch_bounds__(256, 2)
@@ -188,7 +207,8 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
   // L2) whole (square of tile pairs, row split) units, see build_task_order
   const uint64_t task = tasks[blockIdx.x];
   if (task == kAtbNoTask) return;  // padding of the shorter per-XCD sequences
-  const int I = (int)(task & 0xffffff), J = (int)((task >> 24) & 0xffffff), ysplit = (int)(task >> 48);
+  const int I = (int)(task & 0xffffff), J = (int)((task >> 24) & 0xffffff), ysplit = (int)((task >> 48) & 0x3fff);
+  const uint32_t wcode = atb_wave_code(MODE == kAtbGram ? (uint32_t)(task >> 62) : 0u, wave);
 
   uint64_t t0, t1;  // range of 64-row tiles of k
   if constexpr (MODE == kAtbGram) {
@@ -229,7 +249,8 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
     }
   };
 
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = (int)((wcode >> 4) & 1), wn = (int)((wcode >> 5) & 1);  // quadrant of the output tile
+  const int acol = (int)(wcode & 3) * 64, bcol = (int)((wcode >> 2) & 3) * 64;  // operand columns in the staged row
   const int mk = lane >> 4, mblk = (lane >> 2) & 3, me = lane & 3;
   double acc[4][4][4];
 #pragma unroll
@@ -238,11 +259,11 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
-  const uint32_t aaddr = ldsT + (mk * kTP + wm * 64 + mblk * 4 + me) * 8;
+  const uint32_t aaddr = ldsT + (mk * kTP + acol + mblk * 4 + me) * 8;
   uint32_t baddr[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    baddr[r] = ldsT + (mk * kTP + kGT + wn * 64 + ((mblk + r) & 3) * 4 + me) * 8;
+    baddr[r] = ldsT + (mk * kTP + bcol + ((mblk + r) & 3) * 4 + me) * 8;
   auto mfma_half = [&](const double (&a)[4], const double (&b)[4][4], int j0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -295,7 +316,10 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
   if constexpr (DBG) sr2 = __builtin_amdgcn_s_memrealtime();
 
   if constexpr (MODE == kAtbGram) {
-    const int slot = I * nb - I * (I - 1) / 2 + (J - I);  // row-major index in the upper triangle
+    // output tile of this wave: (I, J), or the diagonal tile of I or of J
+    const int sel = (int)(wcode >> 6);
+    const int oi = sel == 1 ? J : I, oj = sel == 0 ? I : J;
+    const int slot = oi * nb - oi * (oi - 1) / 2 + (oj - oi);  // row-major index in the upper triangle
     double *out = part + ((uint64_t)ysplit * npairs + slot) * (kGT * kGT);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -372,7 +396,7 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
 // per XCD = 33 rounds of 64.  (The first version dealt every XCD a 66-pair run of the sorted
 // pair list per split: runs straddle squares and touch 16-24 column blocks.)
 constexpr int kXcd = 8, kSq = 8;
-void build_task_order(int nb, int nsplit, std::vector<uint64_t> &tab) {
+void build_task_order(int nb, int nsplit, bool diag4, std::vector<uint64_t> &tab) {
   struct Unit {
     int bi, bj, y, size;
   };
@@ -383,7 +407,8 @@ void build_task_order(int nb, int nsplit, std::vector<uint64_t> &tab) {
       for (int bj = bi; bj < nsq; ++bj) {
         int size = 0;
         for (int i = bi * kSq; i < std::min(nb, (bi + 1) * kSq); ++i)
-          for (int j = std::max(i, bj * kSq); j < std::min(nb, (bj + 1) * kSq); ++j) ++size;
+          for (int j = std::max(i, bj * kSq); j < std::min(nb, (bj + 1) * kSq); ++j)
+            if (!(i == j && diag4 && i / 4 * 4 + 3 < nb && i % 4 == 3)) ++size;
         if (size) units.push_back({bi, bj, y, size});
       }
   // largest units first, each to the XCD with the fewest blocks so far (stable: the order
@@ -395,8 +420,18 @@ void build_task_order(int nb, int nsplit, std::vector<uint64_t> &tab) {
     for (int q = 1; q < kXcd; ++q)
       if (seq[q].size() < seq[k].size()) k = q;
     for (int i = u.bi * kSq; i < std::min(nb, (u.bi + 1) * kSq); ++i)
-      for (int j = std::max(i, u.bj * kSq); j < std::min(nb, (u.bj + 1) * kSq); ++j)
+      for (int j = std::max(i, u.bj * kSq); j < std::min(nb, (u.bj + 1) * kSq); ++j) {
+        if (i == j && diag4) {
+          // four consecutive diagonal tiles as three blocks (atb_wave_code); squares are 8 wide,
+          // so a group never straddles two of them
+          const int g0 = i / 4 * 4;
+          if (g0 + 3 < nb) {
+            if (i - g0 < 3) seq[k].push_back(atb_task(i, i + 1, u.y, 1 + (i - g0)));
+            continue;
+          }
+        }
         seq[k].push_back(atb_task(i, j, u.y));
+      }
   }
   size_t len = 0;
   for (auto &q : seq) len = std::max(len, q.size());
@@ -480,6 +515,9 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   int ncu = 0;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b.device) != hipSuccess || ncu <= 0)
     ncu = 256;
+  const bool diag4 = !(getenv("OBHIP_GRAM_DIAG4") && atoi(getenv("OBHIP_GRAM_DIAG4")) == 0);
+  // blocks per row split: four consecutive diagonal tiles take three blocks (atb_wave_code)
+  const uint64_t bps = (uint64_t)npairs - (diag4 ? (uint64_t)(nb / 4) : 0);
   const uint64_t slots = 2 * (uint64_t)ncu;
   uint64_t nsplit = 1;
   const uint64_t max_split = std::max<uint64_t>(
@@ -494,7 +532,7 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   // Gram times, half the reduction).
   double bestc = 1e300;
   for (uint64_t ns = 1; ns <= max_split; ++ns) {
-    const uint64_t blocks = ns * (uint64_t)npairs, full = blocks / slots, tail = blocks % slots;
+    const uint64_t blocks = ns * bps, full = blocks / slots, tail = blocks % slots;
     const double rounds = (double)full + (tail == 0 ? 0.0 : (2 * tail <= slots ? 0.6 : 1.0));
     const double cost = rounds * ((double)ntiles / (double)ns + 1.0) + 0.0022 * (double)blocks;
     if (cost < bestc) {
@@ -507,9 +545,10 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 256, (void **)&part));
   unsigned long long *dbgout =
       dbg ? (unsigned long long *)(part + (size_t)nsplit * npairs * kGT * kGT) : nullptr;
-  if (b.gram_pairs_nb != nb || b.gram_pairs_ns != (int)nsplit) {
+  if (b.gram_pairs_nb != nb || b.gram_pairs_ns != (int)nsplit || b.gram_pairs_diag4 != diag4) {
     std::vector<uint64_t> tab;
-    build_task_order(nb, (int)nsplit, tab);
+    build_task_order(nb, (int)nsplit, diag4, tab);
+    b.gram_pairs_diag4 = diag4;
     OB_TRY(b.gram_pairs.upload(tab.data(), tab.size()));
     b.gram_pairs_nb = nb;
     b.gram_pairs_ns = (int)nsplit;

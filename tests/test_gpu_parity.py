@@ -1381,3 +1381,30 @@ def test_host_buffer_predr_std_and_the_small_helpers():
     call("obhip_memcpy_d2d", C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), 8000)
     call("obhip_synchronize")
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,p", [(3000, 1100), (700, 520), (2500, 2048)])
+def test_gram_diagonal_tiles_packed_four_into_three_blocks(n, p, monkeypatch):
+    """The staged-design-matrix Gram kernel gives four consecutive diagonal 128 x 128 tiles to
+    three workgroups (a diagonal tile has three distinct 64 x 64 quadrants, not four).  Same G
+    as with one workgroup per diagonal tile (OBHIP_GRAM_DIAG4=0) up to summation order, exactly
+    symmetric, and the oracle's B^T B; p = 1100: two groups and a left-over tile, 520: one group
+    and one left-over, 2048: four groups."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25"] * 8
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 30))
+    rng = np.random.default_rng(p)
+    x = sample_x(rng, n, kinds)
+    terms = om_o.selectterms(p)
+    y = rng.standard_normal(n)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OBHIP_GRAM_DIAG4", flag)
+        lik = ob.loglik_std(om_d, terms, y, x)
+        got[flag] = lik.hess() * math.exp(2 * lik.para[0])
+        assert np.array_equal(got[flag], got[flag].T)
+    scale = np.max(np.abs(got["0"]))
+    assert np.max(np.abs(got["1"] - got["0"])) < 1e-13 * scale
+    B = O.ob_getmat(O.OuterBase(om_o, x), terms)
+    assert relerr(got["1"], B.T @ B) < 1e-9

@@ -27,4 +27,5 @@ for name in ("materialize_B", "gram", "gram_reduce"):
     if cnt.value:
         print("  %-14s %.3f ms" % (name, pm.value / cnt.value))
 _lib.call("obhip_profile_enable", 0)
+print("source_hash_gram=%s" % _lib.lib.obhip_source_hash(1).decode())
 print("backend %d n=%d gram %.2f ms  %.2f TFLOP/s (dbg=%s)" % (backend, n, ms, n * 4096.0 * 4097 / ms / 1e9, os.environ.get("OBHIP_GRAM_DBG")))

@@ -1,0 +1,56 @@
+#!/bin/bash
+# One gpurun call: the full bench line, rocprofv3 kernel statistics of the same command, the
+# PMC passes of the Gram kernel (matrix-pipe utilisation; fabric read / write bytes; L2 hits),
+# each in its own rocprofv3 run with --kernel-trace only, as the pool requires, and the bench
+# lines of the per-rank shard sizes.  Outputs under gpurun_out/r03/; tools/r03_summarise.py turns
+# them into profiles/r03_*.
+#
+#   tools/r03_profile.sh [TAG]          collect everything
+#   tools/r03_profile.sh --check        regression guard of the Gram kernel's L2 behaviour: one
+#       TCC_HIT / TCC_MISS pass and one timed run on this box against the committed
+#       profiles/r03_gram_traffic.json; fails (exit 1) when the L2 hit rate is below 0.78 or the
+#       Gram's average launch exceeds 1.02 x the committed figure
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r03
+mkdir -p $OUT
+cd $R
+pmc() {  # $1 = tag, $2... = counters
+  local tag=$1; shift
+  local name=$(echo "$*" | tr ' ' '_')
+  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --pmc $* --output-format csv \
+      -d $OUT/pmc_${tag}_$name -o p -- python3 $R/tools/gram_only.py 1000000 0 > $OUT/pmc_${tag}_$name.log 2>&1 ) \
+    || { tail -5 $OUT/pmc_${tag}_$name.log; return 1; }
+  local f=$(find $OUT/pmc_${tag}_$name -name "*counter_collection.csv" | head -1)
+  grep -E "k_atb_dma2|Counter_Name" $f > $OUT/pmc_${tag}_$name.csv
+  rm -rf $OUT/pmc_${tag}_$name
+  echo "pmc $* ok"
+}
+if [ "$1" = "--check" ]; then
+  pmc check TCC_HIT_sum TCC_MISS_sum || exit 1
+  timeout -k 10 300 python3 tools/gram_only.py 1000000 0 > $OUT/check_gram_only.log 2>&1 || { tail -5 $OUT/check_gram_only.log; exit 1; }
+  python3 tools/r03_summarise.py --check
+  exit $?
+fi
+TAG=${1:-a}
+timeout -k 10 900 python3 bench.py > $OUT/bench_line_$TAG.json 2> $OUT/bench_$TAG.err || { tail -5 $OUT/bench_$TAG.err; exit 1; }
+echo "bench ok"
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$TAG -o p -- \
+  python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-backend --no-config3 \
+  > $OUT/bench_line_profiled_$TAG.json 2> $OUT/stats_$TAG.err ) || { tail -5 $OUT/stats_$TAG.err; exit 1; }
+rm -f $OUT/stats_$TAG/*kernel_trace.csv
+echo "stats ok"
+timeout -k 10 300 python3 tools/gram_only.py 1000000 0 > $OUT/gram_only_$TAG.log 2>&1 || { tail -5 $OUT/gram_only_$TAG.log; exit 1; }
+for set in "MfmaUtil VALUBusy" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  pmc $TAG $set || exit 1
+done
+rm -f $OUT/bench_lines_shard_sizes_$TAG.jsonl
+for rows in 125000 250000 500000; do
+  timeout -k 10 300 python3 bench.py --rows $rows --steps 10 --warmup 2 --no-cpu-baseline --no-alt-backend --no-config3 \
+    >> $OUT/bench_lines_shard_sizes_$TAG.jsonl 2>> $OUT/bench_$TAG.err || exit 1
+done
+echo "shard sizes ok"
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats125_$TAG -o p -- \
+  python3 $R/bench.py --rows 125000 --steps 5 --warmup 1 --no-cpu-baseline --no-alt-backend --no-config3 \
+  > /dev/null 2> $OUT/stats125_$TAG.err ) || { tail -5 $OUT/stats125_$TAG.err; exit 1; }
+rm -f $OUT/stats125_$TAG/*kernel_trace.csv
+echo "all ok"
