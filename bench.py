@@ -302,7 +302,7 @@ def kernel_profile(hp, _lib, torch, nprof=2):
         hp.step()
     torch.cuda.synchronize()
     prof = {}
-    for name in ["build_basis", "materialize_B", "gram", "gram_reduce", "tmm", "mm", "sqtmm",
+    for name in ["build_basis", "materialize_B", "gram", "gram_reduce", "tmm", "mm", "sqtmm", "hessmult",
                  "exchange", "unpack_form", "form_hessian", "cholesky", "backsolve", "predict"]:
         cnt, ms = C.c_uint64(0), C.c_double(0)
         _lib.call("obhip_profile_get", name.encode(), C.byref(cnt), C.byref(ms))

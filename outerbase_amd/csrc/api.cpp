@@ -548,14 +548,20 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
     theta_zero = s == 0.0;
   }
   auto update = [&]() -> int {
-    if (theta_zero)
-      OB_TRY(launch_fill(yhat.p, n, 0.0));
-    else
-      OB_TRY(launch_mm(*b, t, v.theta, yhat.p, false));      // loglik_gauss.cpp:117
+    // one fused pass (k_hm_tl): B^T (e^{-2 sigma} (y - B theta)) and sum (B theta - y)^2
+    int fused = theta_zero ? kNotFused
+                           : launch_hessmult_fused(*b, t, v.theta, d_y, -e2, e2, dpv.p, nullptr, dpv.p + p + 1);
+    if (fused != kNotFused) OB_TRY(fused);
+    if (fused == kNotFused) {
+      if (theta_zero)
+        OB_TRY(launch_fill(yhat.p, n, 0.0));
+      else
+        OB_TRY(launch_mm(*b, t, v.theta, yhat.p, false));      // loglik_gauss.cpp:117
+      OB_TRY(launch_resid(yhat.p, d_y, n, e2, r.p, tmp.p));    // :118-124
+      OB_TRY(launch_tmm(*b, t, r.p, dpv.p, false));            // :125
+      OB_TRY(launch_sum_sumsq(tmp.p, n, dpv.p + p, red));
+    }
     theta_zero = false;
-    OB_TRY(launch_resid(yhat.p, d_y, n, e2, r.p, tmp.p));    // :118-124
-    OB_TRY(launch_tmm(*b, t, r.p, dpv.p, false));            // :125
-    OB_TRY(launch_sum_sumsq(tmp.p, n, dpv.p + p, red));
     if (many) OB_TRY(comm_allreduce(comm, dpv.p, p + 2));
     hipLaunchKernelGGL(k_cg_eval, dim3(1), dim3(kCgThreads), 0, st, v, dpv.p, e2, ntot * sigma, logsd,
                        scal.p);
@@ -564,8 +570,12 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
   };
   // q = lpdfvec::hessmult(pv): loglik_gauss.cpp:137-145 + logpr_gauss.cpp:113-115
   auto hessmult = [&]() -> int {
-    OB_TRY(launch_mm(*b, t, v.pv, yhat.p, false));
-    OB_TRY(launch_tmm(*b, t, yhat.p, dpv.p, false));
+    const int fused = launch_hessmult_fused(*b, t, v.pv, nullptr, 1.0, 0.0, dpv.p, nullptr, nullptr);
+    if (fused != kNotFused) OB_TRY(fused);
+    if (fused == kNotFused) {
+      OB_TRY(launch_mm(*b, t, v.pv, yhat.p, false));
+      OB_TRY(launch_tmm(*b, t, yhat.p, dpv.p, false));
+    }
     if (many) OB_TRY(comm_allreduce(comm, dpv.p, p));
     hipLaunchKernelGGL(k_cg_q, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, st, v, dpv.p, e2);
     OB_HIP(hipGetLastError());

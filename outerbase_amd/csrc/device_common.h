@@ -283,7 +283,7 @@ __device__ __forceinline__ void tl_waitn(double (&b)[12]) {
 //   uint32_t ad[NU][W]                       LDS byte addresses of row 0 of the chunk
 //   template <int RR> void row()             once per row, before its first unit
 //   template <int RR, int UNIT> void use(v)  the product of unit UNIT at row RR
-template <int WE, int W, int NU, int ROWS, int INFLIGHT = 12, int U0 = 0>
+template <int WE, int W, int NU, int ROWS, int INFLIGHT = 12, int U0 = 0, int ROW0 = 0>
 struct TlPipe {
   static_assert(WE >= 1 && WE <= W && W <= 8 && INFLIGHT <= 12, "");
   static constexpr int D = (INFLIGHT / WE) > 0 ? INFLIGHT / WE : 1;
@@ -293,7 +293,7 @@ struct TlPipe {
   static __device__ __forceinline__ void issue(C &c, double (&buf)[12]) {
     constexpr int rr = U / NU, unit = U % NU, s = (U % D) * WE;
 #pragma unroll
-    for (int j = 0; j < WE; ++j) buf[s + j] = tl_rd<rr * 8>(c.ad[U0 + unit][W - WE + j]);
+    for (int j = 0; j < WE; ++j) buf[s + j] = tl_rd<(ROW0 + rr) * 8>(c.ad[U0 + unit][W - WE + j]);
   }
   template <int U, typename C>
   static __device__ __forceinline__ void steps(C &c, double (&buf)[12]) {
@@ -328,16 +328,17 @@ struct TlPipe {
 // Run the pipeline instantiated for we column reads per term on units [U0, U0 + NUH) of a
 // lane.  Variants: W, W-1, W-2, W-3.  k_tmm_tl runs the two halves of its units separately,
 // each with the width its own terms need.
-template <int W, int NUH, int ROWS, int INFLIGHT, int U0, typename C>
+// ROW0: first row of the chunk relative to the addresses in c.ad (an immediate of the reads)
+template <int W, int NUH, int ROWS, int INFLIGHT, int U0, int ROW0 = 0, typename C>
 __device__ __forceinline__ void tl_run_half(C &c, int we) {
   if (we == W) {
-    TlPipe<W, W, NUH, ROWS, INFLIGHT, U0>::run(c);
+    TlPipe<W, W, NUH, ROWS, INFLIGHT, U0, ROW0>::run(c);
   } else if (we == W - 1) {
-    TlPipe<W - 1, W, NUH, ROWS, INFLIGHT, U0>::run(c);
+    TlPipe<W - 1, W, NUH, ROWS, INFLIGHT, U0, ROW0>::run(c);
   } else if (W >= 3 && we == W - 2) {
-    TlPipe<(W >= 3 ? W - 2 : 1), W, NUH, ROWS, INFLIGHT, U0>::run(c);
+    TlPipe<(W >= 3 ? W - 2 : 1), W, NUH, ROWS, INFLIGHT, U0, ROW0>::run(c);
   } else {
-    TlPipe<(W >= 4 ? W - 3 : 1), W, NUH, ROWS, INFLIGHT, U0>::run(c);
+    TlPipe<(W >= 4 ? W - 3 : 1), W, NUH, ROWS, INFLIGHT, U0, ROW0>::run(c);
   }
 }
 template <int W>

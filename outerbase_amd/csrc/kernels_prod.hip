@@ -695,6 +695,227 @@ k_mm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
   if (t0 < t1 && wave == 0) emit(t1 - 1);
 }
 
+// ---- B^T (c_a B a + c_b y), term-per-lane, ONE pass over the basis --------------------------------
+// The Hessian product of the PCG (loglik_gauss::hessmult, loglik_gauss.cpp:137-145:
+// B^T (B p) -- c_a = 1, c_b = 0) and the gradient pass of its update() (loglik_gauss.cpp:117-125:
+// yhat = B theta, B^T (e^{-2 sigma} (y - yhat)) -- c_a = -e^{-2 sigma}, c_b = e^{-2 sigma}) as one
+// kernel instead of k_mm_tl followed by k_tmm_tl.  Both are bound by the LDS column reads
+// (W per term and row), and the two kernels read every column twice: once
+// for B a, once for B^T r.  Here a block holds ALL terms (8 waves x NU x 64), takes a tile in
+// chunks of 4 rows, and keeps the NU x 4 term products of a chunk in registers:
+//   1. products as in k_mm_tl (TlPipe): prod[u][r], and s[r] += a_u prod[u][r];
+//   2. s[r] summed over the 64 lanes (permlane swaps + DPP) and, through 32 doubles of LDS and
+//      one s_barrier, over the 8 waves: tot_r = sum_k a_k prod_k(row r), wave-uniform;
+//   3. w_r = c_a s_r^2 tot_r + c_b s_r y_r, and acc[u] += prod[u][r] w_r as in k_tmm_tl.
+// Half the LDS reads of the two-kernel form, the tile staged once, no n-vector through HBM
+// (yhat is written only when the caller wants it).
+constexpr int kHmChunk = 4;
+
+template <int W, int NU>
+struct HmCtx {
+  uint32_t ad[NU][W];
+  double av[NU];
+  double acc[NU];
+  double prod[NU][kHmChunk];
+  double s[kHmChunk];
+  template <int RR>
+  __device__ __forceinline__ void row() {}
+  template <int RR, int UNIT>
+  __device__ __forceinline__ void use(double v) {
+    prod[UNIT][RR] = v;
+    s[RR] = fma(v, av[UNIT], s[RR]);
+  }
+};
+
+// one sub-chunk of 4 rows (ROW0 .. ROW0 + 3 beyond the rows the addresses point at): steps 1-3
+template <int W, int NU, int ROW0, bool ROWS_OUT>
+__device__ __forceinline__ void hm_subchunk(HmCtx<W, NU> &c, bool live, int wea, int web, double *rb,
+                                            int wave, int lane, int rc /* tile row of ROW0 */,
+                                            double vA, double vB, double &totrow) {
+  constexpr int kInflight = NU * W >= 32 ? 8 : 12;
+#pragma unroll
+  for (int r = 0; r < kHmChunk; ++r) c.s[r] = 0.0;
+  if (live) {
+    if constexpr (NU == 1) {
+      tl_run_half<W, 1, kHmChunk, kInflight, 0, ROW0>(c, wea);
+    } else {
+      tl_run_half<W, NU / 2, kHmChunk, kInflight, 0, ROW0>(c, wea);
+      tl_run_half<W, NU / 2, kHmChunk, kInflight, NU / 2, ROW0>(c, web);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int r = 0; r < kHmChunk; ++r) c.prod[u][r] = 0.0;
+  }
+  // s[0..3] over the 64 lanes: 16-lane row q ends with the sum of s[q]
+  static_assert(kHmChunk == 4, "the butterfly below reduces 4 rows");
+  double v = swap16_sum(swap32_sum(c.s[0], c.s[2]), swap32_sum(c.s[1], c.s[3]));
+  v = row16_ror_add<8>(v);
+  v = row16_ror_add<4>(v);
+  v = row16_ror_add<2>(v);
+  v = row16_ror_add<1>(v);
+  if ((lane & 15) == 0) rb[wave * kHmChunk + (lane >> 4)] = v;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (not vmcnt: the next tile's loads stay in flight)
+  __builtin_amdgcn_s_barrier();
+  // over the 8 waves: lane l takes red[wave (l & 31) / 4][row l % 4]; afterwards EVERY lane l holds
+  // tot of row l % 4
+  double t = rb[lane & 31];
+  t = row16_ror_add<4>(t);
+  t = row16_ror_add<8>(t);
+  t += __shfl_xor(t, 16, 64);
+  // w of row l % 4 in lane l: the row's vA, vB (lane = row) fetched by the lanes that want them
+  const int src = rc + (lane & 3);
+  double wl = __shfl(vA, src, 64) * t;
+  if (ROWS_OUT) {
+    wl += __shfl(vB, src, 64);
+    if ((lane & ~3) == rc) totrow = t;  // lane = row keeps sum_k a_k prod_k of its row
+  }
+#pragma unroll
+  for (int r = 0; r < kHmChunk; ++r) {
+    const double wv = readlane_f64(wl, r);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) c.acc[u] = fma(c.prod[u][r], wv, c.acc[u]);
+  }
+}
+
+// ROWS_OUT: the update() form (y, yhat, sum of squared residuals); without it the Hessian product
+template <int W2, int NU, bool PREFETCH, bool ROWS_OUT>
+__global__ void __launch_bounds__(kTlThreads, 2)
+k_hm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
+        const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc,
+        const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm,
+        const double *__restrict__ a, int p, const double *__restrict__ y, double ca, double cb,
+        uint64_t n, uint64_t ntiles, uint64_t tiles_per_split, uint64_t p_pad,
+        double *__restrict__ part, double *__restrict__ yhat, double *__restrict__ sspart) {
+  extern __shared__ double lds[];
+  constexpr int W = 2 * W2;
+  double *red = lds + (size_t)Mu * kTlPitch;  // [2][8 waves][4 rows]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+
+  HmCtx<W, NU> c;
+  int nza = 1, nzb = 1;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const uint64_t slot = tl_slot<NU>(0, wave, u, lane);
+    const bool ok = slot < p_pad;
+    const uint64_t k = ok ? sperm[slot] : 0;
+    c.acc[u] = 0.0;
+    c.av[u] = ok && k < (uint64_t)p ? a[k] : 0.0;
+    uint32_t cw[W2];
+#pragma unroll
+    for (int w = 0; w < W2; ++w) {
+      cw[w] = ok ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+      c.ad[u][2 * w] = (cw[w] & 0xffffu) * (kTlPitch * 8);
+      c.ad[u][2 * w + 1] = (cw[w] >> 16) * (kTlPitch * 8);
+    }
+    if (NU == 1 || u < NU / 2)
+      nza = max(nza, tl_nnz<W2>(cw));
+    else
+      nzb = max(nzb, tl_nnz<W2>(cw));
+  }
+  const int wea = tl_variant<W>(wave_max_i32(nza)), web = tl_variant<W>(wave_max_i32(nzb));
+  const bool live = ((uint64_t)wave * NU) * 64 < p_pad;  // (whole waves beyond p_pad: zeros)
+
+  int lu[PREFETCH ? kTlPre : 1];
+  double pre[PREFETCH ? kTlPre : 1];
+  if (PREFETCH) {
+#pragma unroll
+    for (int q = 0; q < kTlPre; ++q) {
+      const int u = wave + kTlWaves * q;
+      lu[q] = u < Mu ? __builtin_amdgcn_readfirstlane((int)ucol[u] * kTileRows) : 0;
+    }
+  }
+  // per row (lane = row): vA = c_a s^2, vB = c_b s y  ->  w = vA tot + vB
+  double vAn = 0.0, vBn = 0.0, vA = 0.0, vB = 0.0;
+  auto weights = [&](uint64_t tile) {
+    const uint64_t row = tile * kTileRows + lane;
+    vAn = vBn = 0.0;
+    if (row < n) {
+      const double sc = scale[row];
+      vAn = ca * sc * sc;
+      if (ROWS_OUT) vBn = cb * sc * y[row];
+    }
+  };
+  auto fetch = [&](uint64_t tile) {
+    const double *src = bm + tile * Mc * kTileRows + lane;
+#pragma unroll
+    for (int q = 0; q < kTlPre; ++q) {
+      const int u = wave + kTlWaves * q;
+      pre[q] = u < Mu ? src[lu[q]] : 0.0;
+    }
+    weights(tile);
+  };
+  if (PREFETCH && t0 < t1) fetch(t0);
+  double ssacc = 0.0;  // wave 0: sum over its rows of (yhat - y)^2
+
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    __syncthreads();  // every wave is done with the previous tile
+    if (PREFETCH) {
+#pragma unroll
+      for (int q = 0; q < kTlPre; ++q) {
+        const int u = wave + kTlWaves * q;
+        if (u < Mu) lds[u * kTlPitch + lane] = pre[q];
+      }
+    } else {
+      const double *src = bm + tile * Mc * kTileRows + lane;
+      for (int u = wave; u < Mu; u += kTlWaves) lds[u * kTlPitch + lane] = src[(size_t)ucol[u] * kTileRows];
+      weights(tile);
+    }
+    vA = vAn;
+    vB = vBn;
+    __syncthreads();
+    if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
+    double totrow = 0.0;  // lane = row: sum_k a_k prod_k of this tile's row
+#pragma unroll 1
+    for (int rc = 0; rc < kTileRows; rc += 2 * kHmChunk) {
+      // two sub-chunks per address update: the second reads at immediate row offsets 4 .. 7;
+      // the cross-wave sums alternate between the two halves of red
+      hm_subchunk<W, NU, 0, ROWS_OUT>(c, live, wea, web, red, wave, lane, rc, vA, vB, totrow);
+      hm_subchunk<W, NU, kHmChunk, ROWS_OUT>(c, live, wea, web, red + kTlWaves * kHmChunk, wave, lane,
+                                             rc + kHmChunk, vA, vB, totrow);
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          c.ad[u][j] += (rc + 2 * kHmChunk < kTileRows) ? 2 * kHmChunk * 8 : -(kTileRows - 2 * kHmChunk) * 8;
+          asm volatile("" : "+v"(c.ad[u][j]));
+        }
+    }
+    if (ROWS_OUT && wave == 0) {
+      const uint64_t row = tile * kTileRows + lane;
+      if (row < n) {
+        const double yh = scale[row] * totrow;
+        if (yhat != nullptr) yhat[row] = yh;
+        const double dlt = yh - y[row];
+        ssacc = fma(dlt, dlt, ssacc);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const uint64_t slot = tl_slot<NU>(0, wave, u, lane);
+    if (slot < p_pad) part[(uint64_t)blockIdx.x * p_pad + sperm[slot]] = c.acc[u];
+  }
+  if (ROWS_OUT && wave == 0 && sspart != nullptr) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ssacc += __shfl_xor(ssacc, off, 64);
+    if (lane == 0) sspart[blockIdx.x] = ssacc;
+  }
+}
+
+// out[0] = sum of the per-block sums, in block order
+__global__ void k_hm_ss(const double *__restrict__ sspart, int nblk, double *__restrict__ out) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += sspart[b];
+    out[0] = s;
+  }
+}
+
 // several blocks along p: out = scale * sum of their partial row sums
 template <bool SQ>
 __global__ void k_mm_tl_sum(const double *__restrict__ part, int pblocks, uint64_t n_pad,
@@ -1048,6 +1269,85 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *
   }
   hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0,
                      cur_stream(), part, (int)nsplit, p_pad, (int)t.p, d_out);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+
+// d_out (p) = B^T (c_a B a + c_b y) in one pass over the basis (k_hm_tl); d_yhat (n, may be
+// null) = B a; d_ss (1, may be null) = sum (B a - y)^2.  Returns 1 when the terms do not fit the
+// fused kernel (more terms than one block holds, wide terms, too many used columns): the caller
+// then takes the two-kernel path.
+template <int W2, int NU, bool PF, bool RO>
+int run_hm_tl2(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,
+               double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
+               uint64_t tps, size_t lds) {
+  OB_TRY(set_lds(k_hm_tl<W2, NU, PF, RO>, lds));
+  hipLaunchKernelGGL((k_hm_tl<W2, NU, PF, RO>), dim3(nsplit), dim3(kTlThreads), lds, cur_stream(), b.bm.p,
+                     b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, t.sperm.p, d_a,
+                     (int)t.p, d_y, ca, cb, b.n, ntiles, tps, t.p_pad, part, d_yhat, sspart);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+template <int W2, int NU>
+int run_hm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,
+              double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
+              uint64_t tps) {
+  const size_t lds = (t.Mu * kTlPitch + 2 * kTlWaves * kHmChunk) * sizeof(double);
+  static const bool nopf = getenv("OBHIP_HM_NOPREFETCH") != nullptr;
+  const bool pf = !nopf && t.Mu <= (uint64_t)kTlWaves * kTlPre;
+  const bool ro = d_y != nullptr;
+  if (pf && ro) return run_hm_tl2<W2, NU, true, true>(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, nsplit, ntiles, tps, lds);
+  if (pf) return run_hm_tl2<W2, NU, true, false>(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, nsplit, ntiles, tps, lds);
+  if (ro) return run_hm_tl2<W2, NU, false, true>(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, nsplit, ntiles, tps, lds);
+  return run_hm_tl2<W2, NU, false, false>(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, nsplit, ntiles, tps, lds);
+}
+
+int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y,
+                          double ca, double cb, double *d_out, double *d_yhat, double *d_ss) {
+  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  static const bool off = getenv("OBHIP_HESSMULT_FUSED") && atoi(getenv("OBHIP_HESSMULT_FUSED")) == 0;
+  const int w2 = (int)(t.W / 2);
+  const int numax = w2 <= 2 ? 8 : 4;
+  if (off || beyond_lds(t) || w2 < 1 || w2 > kMaxW2 || t.p_pad > (uint64_t)kTlWaves * numax * 64 ||
+      (t.Mu * kTlPitch + 2 * kTlWaves * kHmChunk) * sizeof(double) > 156 * 1024)
+    return kNotFused;
+  int nu = 1;
+  while ((uint64_t)kTlWaves * nu * 64 < t.p_pad) nu *= 2;
+  const uint64_t ntiles = b.n_pad / kTileRows;
+  // one resident block per CU (the products of a chunk live in registers), one round
+  uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)device_cus(b.device));
+  nsplit = std::min(nsplit, std::max<uint64_t>(1, ntiles / 4));
+  const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  double *part = nullptr;
+  OB_TRY(const_cast<obhip_basis &>(b).workspace((nsplit * t.p_pad + nsplit) * sizeof(double), (void **)&part));
+  if ((d_yhat || d_ss) && !d_y) return fail(OBHIP_ERR_INVALID, "hessmult: yhat / residual sum need y");
+  double *sspart = d_ss ? part + nsplit * t.p_pad : nullptr;
+  {
+    ProfScope ps("hessmult");
+#define OB_HM(W2_, NU_) OB_TRY((run_hm_tl<W2_, NU_>(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps))); break
+    switch (w2 * 16 + nu) {
+      case 1 * 16 + 1: OB_HM(1, 1);
+      case 1 * 16 + 2: OB_HM(1, 2);
+      case 1 * 16 + 4: OB_HM(1, 4);
+      case 1 * 16 + 8: OB_HM(1, 8);
+      case 2 * 16 + 1: OB_HM(2, 1);
+      case 2 * 16 + 2: OB_HM(2, 2);
+      case 2 * 16 + 4: OB_HM(2, 4);
+      case 2 * 16 + 8: OB_HM(2, 8);
+      case 3 * 16 + 1: OB_HM(3, 1);
+      case 3 * 16 + 2: OB_HM(3, 2);
+      case 3 * 16 + 4: OB_HM(3, 4);
+      case 4 * 16 + 1: OB_HM(4, 1);
+      case 4 * 16 + 2: OB_HM(4, 2);
+      case 4 * 16 + 4: OB_HM(4, 4);
+      default: return kNotFused;
+    }
+#undef OB_HM
+  }
+  hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0, cur_stream(),
+                     part, (int)nsplit, t.p_pad, (int)t.p, d_out);
+  if (d_ss) hipLaunchKernelGGL(k_hm_ss, dim3(1), dim3(64), 0, cur_stream(), sspart, (int)nsplit, d_ss);
   OB_HIP(hipGetLastError());
   return 0;
 }

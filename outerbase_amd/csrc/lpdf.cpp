@@ -495,6 +495,15 @@ struct LoglikGauss : Loglik {
   }
   int hessmult(const double *g, double *out) override {  // loglik_gauss.cpp:137-145
     OB_TRY(dcoeff.upload(g, nterms));
+    // one fused pass B^T (e^{-2 sigma} B g) when the terms fit one block of k_hm_tl
+    OB_TRY(dpv.alloc(nterms));
+    const int fused = launch_hessmult_fused(*ob, *t, dcoeff.p, nullptr, std::exp(-2.0 * para[0]), 0.0, dpv.p,
+                                            nullptr, nullptr);
+    if (fused != kNotFused) {
+      OB_TRY(fused);
+      if (comm) OB_TRY(comm_allreduce(comm, dpv.p, nterms));
+      return d2h(out, dpv.p, nterms * sizeof(double));
+    }
     OB_TRY(launch_mm(*ob, *t, dcoeff.p, tmp.p, false));
     OB_TRY(launch_scale(tmp.p, n, std::exp(-2.0 * para[0])));
     return tmm_host(tmp.p, false, out);

@@ -276,6 +276,12 @@ int launch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a,
               double *d_out, bool squared);
 int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a,
                double *d_out, bool squared);
+// d_out (p) = B^T (c_a B a + c_b y) in ONE pass over the basis; d_yhat (n) = B a and d_ss (1) =
+// sum (B a - y)^2 when asked for.  Returns kNotFused (nothing done) when the terms do not fit the
+// fused kernel: the caller then composes launch_mm / launch_tmm.
+constexpr int kNotFused = -1;
+int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y,
+                          double ca, double cb, double *d_out, double *d_yhat, double *d_ss);
 // kernels_generic.hip: any number of used columns / factors, columns read from HBM
 int launch_mm_generic(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, int mode,
                       uint64_t ld);
