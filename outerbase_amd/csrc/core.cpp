@@ -157,10 +157,22 @@ static void prof_drain(ProfEntry &pe) {
 int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
   if (!m.knots_set) return fail(OBHIP_ERR_STATE, "knots not set");
   const uint64_t d = m.d;
+  // nothing changed since the last build (same model state, same level caps): the device tables
+  // stand -- obhip_basis_rebuild on new rows or a repeated fit must not pay for them again
+  if (dims.p && model_version == m.version && built_for == &m && dims_h.size() == d) {
+    bool same = cap.size() == d;
+    for (uint64_t l = 0; same && l < d; ++l) {
+      int64_t c = cap_in.empty() ? (int64_t)m.m_of(l) - 1 : cap_in[l];
+      c = std::max<int64_t>(0, std::min<int64_t>(c, (int64_t)m.m_of(l) - 1));
+      same = c == cap[l];
+    }
+    if (same) return 0;
+  }
   cap.resize(d);
   dims_h.resize(d);
   std::vector<double> hka(m.M()), hkb(m.M()), hkc(m.M());
-  std::vector<double> hrot;
+  std::vector<double> hrot, htab;
+  std::vector<int> table_dims;  // per dimension: itself when it gets interval tables, else -1
   uint64_t ccol = 1;  // compact column 0 is the all-ones column
   for (uint64_t l = 0; l < d; ++l) {
     const uint64_t ml = m.m_of(l), o = m.knotptst[l];
@@ -176,7 +188,7 @@ int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
     D.ncolp = (D.ncol + 7) / 8 * 8;
     D.rotoff = (int)hrot.size();
     D.ccol0 = (int)ccol;
-    D.pad = 0;
+    D.tab = -1;
     ccol += (uint64_t)c;
     const double *hy = &m.hyp[m.hypst[l]];
     const double a = 2.0, b = 0.25;  // covfuncs.h:42,53-54,66
@@ -208,7 +220,9 @@ int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
       }
       // knots spread too far for the separable exponentials: one exp per knot on the device
       if (!safe) D.kind = D.kind == OBHIP_COV_MAT25 ? 3 : 4;  // kCovMat25Direct / kCovMat25PowDirect
+      table_dims.push_back(safe ? (int)l : -1);
     } else {
+      table_dims.push_back(-1);
       D.p0 = std::exp(a * hy[0]);  // expLSs, covfuncs.cpp:290
       D.p1 = std::exp(a * hy[1]);  // expLSc, :291
       D.p2 = 0;
@@ -223,6 +237,61 @@ int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
     for (uint64_t j = 0; j < ml; ++j)
       for (int cc = 0; cc < D.ncol; ++cc)
         hrot[D.rotoff + j * D.ncolp + cc] = m.rotmat[(o + cc) * m.mmax + j];
+    // Interval tables (mat25 / mat25pow, device_common.h build_dim_tab): the kernel is
+    // (1 + h + h^2 / 3) e^{-h} with h = |u(x) - u_j|, so between two neighbouring knots the whole
+    // knot sum R[c] = sum_j k(x, knot_j) rot[j][c] is e^{-t} (quadratic in t) + e^{+t} (quadratic in
+    // t), t = u(x) - (the largest u_j <= u(x)): with the knots sorted by u, J of them <= u(x),
+    // ref = u_(J-1) (u_(0) for J = 0) and d_j = |u_j - ref|,
+    //   h = t + d_j (j < J):  (1 + h + h^2/3) e^{-h} = e^{-t} e^{-d_j} [(1 + d_j + d_j^2/3) + t (1 + 2 d_j/3) + t^2/3]
+    //   h = d_j - t (j >= J): (1 + h + h^2/3) e^{-h} = e^{+t} e^{-d_j} [(1 + d_j + d_j^2/3) - t (1 + 2 d_j/3) + t^2/3]
+    // Six sums over the knots per (interval, level), taken here once per hyper-parameter update
+    // in extended precision; the device then spends O(1) per (row, level) instead of a pass over
+    // the knots.  Every weight e^{-d_j} is <= 1 and every bracket term positive: what cancels is
+    // what cancels in the knot sum itself (the signs of rot), nothing more.
+    if (table_dims.back() >= 0) {
+      std::vector<int> ord(ml);
+      for (uint64_t j = 0; j < ml; ++j) ord[j] = (int)j;
+      std::stable_sort(ord.begin(), ord.end(), [&](int a2, int b2) { return hka[o + a2] < hka[o + b2]; });
+      const uint64_t mu = (ml + 1) / 2 * 2;  // sorted u, padded to an even length (16-byte aligned tables)
+      if (htab.size() % 2) htab.push_back(0.0);
+      D.tab = (int)htab.size();
+      htab.resize(htab.size() + mu + (ml + 1) * (uint64_t)D.ncol * 6, 0.0);
+      double *us = &htab[D.tab];
+      for (uint64_t j = 0; j < ml; ++j) us[j] = hka[o + ord[j]];
+      for (uint64_t j = ml; j < mu; ++j) us[j] = us[ml - 1];
+      double *cf = us + mu;
+      // e^{-d_j} = e^{u_j} e^{-ref} (j < J) or e^{-u_j} e^{ref}: |u| < 150, far from the range's end
+      std::vector<long double> ep(ml), em(ml);
+      for (uint64_t j = 0; j < ml; ++j) {
+        ep[j] = expl((long double)us[j]);
+        em[j] = expl(-(long double)us[j]);
+      }
+      for (uint64_t J = 0; J <= ml; ++J) {
+        const uint64_t jr = J >= 1 ? J - 1 : 0;
+        const double ref = us[jr];
+        for (int cc = 0; cc < D.ncol; ++cc) {
+          long double A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, B2 = 0;
+          for (uint64_t j = 0; j < ml; ++j) {
+            const long double dj = j < J ? (long double)ref - us[j] : (long double)us[j] - ref;
+            const long double w = (j < J ? ep[j] * em[jr] : em[j] * ep[jr]) *
+                                  (long double)m.rotmat[(o + cc) * m.mmax + ord[j]];
+            const long double q0 = 1 + dj + dj * dj / 3, q1 = 1 + 2 * dj / 3;
+            if (j < J) {
+              A0 += w * q0;
+              A1 += w * q1;
+              A2 += w / 3;
+            } else {
+              B0 += w * q0;
+              B1 += w * q1;
+              B2 += w / 3;
+            }
+          }
+          double *e = cf + (J * D.ncol + cc) * 6;
+          e[0] = (double)A0, e[1] = (double)A1, e[2] = (double)A2;
+          e[3] = (double)B0, e[4] = (double)B1, e[5] = (double)B2;
+        }
+      }
+    }
   }
   Mc = ccol;
   OB_TRY(dims.upload(dims_h.data(), d));
@@ -230,7 +299,10 @@ int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
   OB_TRY(kb.upload(hkb.data(), hkb.size()));
   OB_TRY(kc.upload(hkc.data(), hkc.size()));
   OB_TRY(rot.upload(hrot.data(), hrot.size()));
+  if (htab.empty()) htab.assign(2, 0.0);
+  OB_TRY(tab.upload(htab.data(), htab.size()));
   model_version = m.version;
+  built_for = &m;
   return 0;
 }
 

@@ -136,10 +136,52 @@ __device__ __forceinline__ double build_dim(const DimDesc &D, const double *ka, 
   return cl;
 }
 
+// mat25 / mat25pow from the interval tables (ModelDev::build, core.cpp): J = number of knots with
+// u_j <= u(x) by bisection on the sorted u, t = u(x) - u_(J-1), and per level six table entries:
+//   R[c] = e^{-t} (A0 + t (A1 + t A2)) + e^{+t} (B0 + t (t B2 - B1)).
+// O(1) per (row, level) where the knot loop spends ~17 instructions per (row, knot); two
+// exponentials per (row, dimension) as before.  No knots below (J = 0): the e^{-t} part is empty
+// and e^{-t} may overflow (t < 0), so it is dropped; likewise e^{+t} for J = m.
+template <int KIND, typename Store>
+__device__ __forceinline__ double build_dim_tab(const DimDesc &D, const double *__restrict__ tab,
+                                                double xv, const Store &store) {
+  typedef double dd2 __attribute__((ext_vector_type(2)));
+  const double ux = (KIND == OBHIP_COV_MAT25 ? xv / D.p0 : pow(xv, D.p0) / D.p1) - D.p2;
+  const double *__restrict__ us = tab + D.tab;
+  int lo = 0, hi = D.m;  // u_(lo-1) <= ux < u_(hi)
+  for (int it = 0; it < 7; ++it) {  // m <= 127
+    const int mid = (lo + hi) >> 1;
+    const bool open = lo < hi;
+    const bool le = us[min(mid, D.m - 1)] <= ux;
+    lo = open && le ? mid + 1 : lo;
+    hi = open && !le ? mid : hi;
+  }
+  const int J = lo;
+  const double t = ux - us[max(J - 1, 0)];
+  const double em = J == 0 ? 0.0 : exp(-t), ep = J == D.m ? 0.0 : exp(t);
+  const dd2 *__restrict__ cf = (const dd2 *)(us + ((D.m + 1) & ~1) + (size_t)J * D.ncol * 6);
+  double cl = 1.0, icl = 1.0;
+  for (int c = 0; c < D.ncol; ++c) {
+    const dd2 e0 = cf[3 * c], e1 = cf[3 * c + 1], e2 = cf[3 * c + 2];  // A0 A1 | A2 B0 | B1 B2
+    const double r = em * fma(t, fma(t, e1.x, e0.y), e0.x) + ep * fma(t, fma(t, e2.y, -e2.x), e1.y);
+    if (c == 0) {
+      cl = r;
+      icl = 1.0 / r;  // one division per (row, dimension); the levels are scaled by the reciprocal
+    } else {
+      store(D.ccol0 + c - 1, r * icl);
+    }
+  }
+  return cl;
+}
+
 template <typename Store>
 __device__ __forceinline__ double build_dim_any(const DimDesc &D, const double *ka, const double *kb,
-                                                const double *kc, const double *rot, double xv,
-                                                const Store &store) {
+                                                const double *kc, const double *rot,
+                                                const double *tab, double xv, const Store &store) {
+  if (D.tab >= 0) {
+    if (D.kind == OBHIP_COV_MAT25) return build_dim_tab<OBHIP_COV_MAT25>(D, tab, xv, store);
+    return build_dim_tab<OBHIP_COV_MAT25POW>(D, tab, xv, store);
+  }
   if (D.kind == OBHIP_COV_MAT25) return build_dim<OBHIP_COV_MAT25>(D, ka, kb, kc, rot, xv, store);
   if (D.kind == OBHIP_COV_MAT25POW)
     return build_dim<OBHIP_COV_MAT25POW>(D, ka, kb, kc, rot, xv, store);

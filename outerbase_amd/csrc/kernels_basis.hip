@@ -16,9 +16,9 @@
 // column dims[l].ccol0 + t - 1.  One lane owns one row, so every store is a
 // fully coalesced 512-byte wave store and no LDS transposition is needed.
 //
-// Work split: block = 4 waves = one 64-row tile; wave w evaluates dimensions
-// w, w+4, ...  All per-dimension tables (knot constants, rotmat columns) are
-// wave-uniform and are fetched with scalar loads.
+// Work split and the interval tables of mat25 / mat25pow: at k_build_basis.  In the knot-loop
+// path all per-dimension tables (knot constants, rotmat columns) are wave-uniform and are
+// fetched with scalar loads.
 #include "obhip_internal.h"
 #include "device_common.h"
 
@@ -26,33 +26,83 @@ namespace obhip {
 
 namespace {
 
-__global__ void __launch_bounds__(256)
+// Work split: a block of 4 waves takes 4 consecutive 64-row tiles, one per wave; all waves walk
+// the dimensions together, so that a dimension's interval tables (mat25 / mat25pow,
+// build_dim_tab: [m sorted u][m + 1][levels][6], 12 KB at 40 knots and 6 levels) are staged once
+// per block in LDS and the per-row table reads -- seven bisection steps and 3 x levels 16-byte
+// entries, a different interval per lane -- are LDS gathers, not vector-memory ones (23 gather
+// instructions per row and dimension through the texture path were as slow as the
+// ~17-instruction-per-knot loop they replace).  A lane keeps the running basescale of its row
+// across the dimensions, so no reduction over waves is needed.  Dimensions without tables
+// (mat25ang, out-of-range hyper-parameters) or with tables beyond the LDS buffer (all levels
+// kept: tables grow with levels x knots) take the scalar-operand knot loop.  The kernel is
+// latency-bound (a chain of bisection steps and table reads per dimension; the next dimension's
+// tables and x values are fetched under it), so the register budget is capped for the five
+// blocks per CU the two 16-KB table buffers allow.
+constexpr int kBbTab = 2048;      // doubles of LDS for one dimension's tables
+
+__device__ __forceinline__ int bb_tab_size(const DimDesc &D) {
+  return ((D.m + 1) & ~1) + (D.m + 1) * D.ncol * 6;
+}
+
+__global__ void __launch_bounds__(256, 5)
 k_build_basis(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
               const double *__restrict__ kb, const double *__restrict__ kc,
-              const double *__restrict__ rot, const double *__restrict__ x, uint64_t n, int d,
-              uint64_t Mc, double *__restrict__ bm, double *__restrict__ scale) {
-  __shared__ double part[4][kTileRows];
+              const double *__restrict__ rot, const double *__restrict__ tab,
+              const double *__restrict__ x, uint64_t n, int d, uint64_t Mc, uint64_t ntiles,
+              double *__restrict__ bm, double *__restrict__ scale) {
+  __shared__ __attribute__((aligned(16))) double ltab[2][kBbTab];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint64_t tile = blockIdx.x;
+  const uint64_t tile = (uint64_t)blockIdx.x * 4 + wave;
+  const bool mine = tile < ntiles;  // (wave-uniform)
   const uint64_t row = tile * kTileRows + lane;
-  const bool valid = row < n;
-  double *tile_out = bm + tile * Mc * kTileRows + lane;
-  double sc = 1.0;
-  for (int l = wave; l < d; l += 4) {
+  const StoreGlobal store{bm + tile * Mc * kTileRows + lane};
+  // The tables and the x values of dimension l + 1 are fetched into registers before dimension l
+  // is evaluated and go to the other LDS buffer after it: one barrier per dimension, and the
+  // fetch latency hides under the evaluation.
+  constexpr int kPer = kBbTab / 256;
+  double treg[kPer];
+  double xnext = 0.5;
+  auto fetch = [&](int l) {
+    if (l >= d) return;
     const DimDesc D = dims[l];
     // padded rows evaluate at the first knot-free point of the domain; their
     // scale is forced to zero below so they never contribute.
-    const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
-    const double cl = build_dim_any(D, ka, kb, kc, rot, xv, StoreGlobal{tile_out});
-    sc *= cl;  // modandbase.cpp:573
+    xnext = mine && row < n ? x[(uint64_t)l * n + row] : 0.5;
+    if (D.tab >= 0 && bb_tab_size(D) <= kBbTab) {
+      const int sz = bb_tab_size(D);
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        treg[i] = e < sz ? tab[D.tab + e] : 0.0;
+      }
+    }
+  };
+  auto put = [&](int l) {
+    if (l >= d) return;
+    const DimDesc D = dims[l];
+    if (D.tab >= 0 && bb_tab_size(D) <= kBbTab) {
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) ltab[l & 1][threadIdx.x + 256 * i] = treg[i];
+    }
+  };
+  fetch(0);
+  put(0);
+  double sc = 1.0;
+  for (int l = 0; l < d; ++l) {
+    DimDesc D = dims[l];
+    const bool staged = D.tab >= 0 && bb_tab_size(D) <= kBbTab;
+    if (staged) D.tab = 0;
+    const double xv = xnext;
+    __syncthreads();  // this dimension's tables are in place, the other buffer is free
+    fetch(l + 1);
+    if (mine) sc *= build_dim_any(D, ka, kb, kc, rot, staged ? (const double *)ltab[l & 1] : tab, xv, store);  // modandbase.cpp:573
+    put(l + 1);
   }
-  part[wave][lane] = sc;
-  if (wave == 0) tile_out[0] = 1.0;  // the all-ones column (modandbase.cpp:574)
-  __syncthreads();
-  if (wave == 0) {
-    const double s = part[0][lane] * part[1][lane] * part[2][lane] * part[3][lane];
-    scale[row] = valid ? s : 0.0;
+  if (mine) {
+    bm[tile * Mc * kTileRows + lane] = 1.0;  // the all-ones column (modandbase.cpp:574)
+    scale[row] = row < n ? sc : 0.0;
   }
 }
 
@@ -97,9 +147,9 @@ k_getbase(DimDesc D, const double *__restrict__ ka, const double *__restrict__ k
 int launch_build_basis(obhip_basis &b) {
   ProfScope ps("build_basis");
   const uint64_t tiles = b.n_pad / kTileRows;
-  hipLaunchKernelGGL(k_build_basis, dim3((unsigned)tiles), dim3(256), 0, cur_stream(),
-                     b.md.dims.p, b.md.ka.p, b.md.kb.p, b.md.kc.p, b.md.rot.p, b.x.p, b.n,
-                     (int)b.d, b.md.Mc, b.bm.p, b.scale.p);
+  hipLaunchKernelGGL(k_build_basis, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, cur_stream(),
+                     b.md.dims.p, b.md.ka.p, b.md.kb.p, b.md.kc.p, b.md.rot.p, b.md.tab.p, b.x.p, b.n,
+                     (int)b.d, b.md.Mc, tiles, b.bm.p, b.scale.p);
   OB_HIP(hipGetLastError());
   return 0;
 }

@@ -22,7 +22,7 @@ template <int W2, bool VAR>
 __global__ void __launch_bounds__(kPrThreads)
 k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
           const double *__restrict__ kb, const double *__restrict__ kc,
-          const double *__restrict__ rot, const int *__restrict__ cpos, int d, int Mu,
+          const double *__restrict__ rot, const double *__restrict__ tab, const int *__restrict__ cpos, int d, int Mu,
           const uint32_t *__restrict__ colsw, int W2rt, int p, const double *__restrict__ theta,
           const double *__restrict__ coeffvar, double e2sigma, const double *__restrict__ x,
           uint64_t n, double *__restrict__ mean, double *__restrict__ var) {
@@ -39,7 +39,7 @@ k_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
   for (int l = wave; l < d; l += kPrWaves) {
     const DimDesc D = dims[l];
     const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
-    sc *= build_dim_any(D, ka, kb, kc, rot, xv, store);
+    sc *= build_dim_any(D, ka, kb, kc, rot, tab, xv, store);
   }
   if (wave == 0) lds[lane] = 1.0;  // used column 0 = all ones
   red[wave * kTileRows + lane] = sc;
@@ -141,7 +141,7 @@ template <int W2, int NG, bool VAR>
 __global__ void __launch_bounds__(kTlThreads, 4)
 k_predict_tl(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
              const double *__restrict__ kb, const double *__restrict__ kc,
-             const double *__restrict__ rot, const int *__restrict__ cpos, int d, int Mu,
+             const double *__restrict__ rot, const double *__restrict__ tab, const int *__restrict__ cpos, int d, int Mu,
              const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm, int p,
              uint64_t p_pad, int npass,
              const double *__restrict__ theta, const double *__restrict__ coeffvar, double e2sigma,
@@ -210,7 +210,7 @@ k_predict_tl(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
       for (int l = wave; l < d; l += kTlWaves) {
         const DimDesc D = dims[l];
         const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
-        sc *= build_dim_any(D, ka, kb, kc, rot, xv, store);
+        sc *= build_dim_any(D, ka, kb, kc, rot, tab, xv, store);
       }
       if (wave == 0) lds[lane] = 1.0;  // used column 0 = all ones
       reds[wave * kTileRows + lane] = sc;
@@ -277,7 +277,7 @@ int run_predict_tl(const obhip_model &m, obhip_terms &t, const double *d_theta, 
   nsplit = (ntiles + tps - 1) / tps;
   hipLaunchKernelGGL((k_predict_tl<W2, NG, VAR>), dim3((unsigned)nsplit), dim3(kTlThreads), lds,
                      cur_stream(), t.pred_md.dims.p, t.pred_md.ka.p, t.pred_md.kb.p, t.pred_md.kc.p,
-                     t.pred_md.rot.p, t.cpos.p, (int)m.d, (int)t.Mu, (const uint32_t *)t.cols.p,
+                     t.pred_md.rot.p, t.pred_md.tab.p, t.cpos.p, (int)m.d, (int)t.Mu, (const uint32_t *)t.cols.p,
                      t.sperm.p, (int)t.p, t.p_pad, npass, d_theta, d_coeffvar, e2sigma, d_x, n, ntiles, tps,
                      d_mean, d_var);
   OB_HIP(hipGetLastError());
@@ -329,7 +329,7 @@ int run_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, con
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_predict<W2, VAR>), dim3((unsigned)((n + kTileRows - 1) / kTileRows)),
                      dim3(kPrThreads), lds, cur_stream(), t.pred_md.dims.p, t.pred_md.ka.p, t.pred_md.kb.p,
-                     t.pred_md.kc.p, t.pred_md.rot.p, t.cpos.p, (int)m.d, (int)t.Mu,
+                     t.pred_md.kc.p, t.pred_md.rot.p, t.pred_md.tab.p, t.cpos.p, (int)m.d, (int)t.Mu,
                      (const uint32_t *)t.cols.p, (int)(t.W / 2), (int)t.p, d_theta, d_coeffvar,
                      e2sigma, d_x, n, d_mean, d_var);
   OB_HIP(hipGetLastError());

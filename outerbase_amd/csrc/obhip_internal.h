@@ -153,18 +153,20 @@ struct DimDesc {
   int ncolp;   // ncol rounded up to a multiple of 8
   int rotoff;  // offset into rot (doubles)
   int ccol0;   // compact column of level 1 (level t -> ccol0 + t - 1)
-  int pad;
+  int tab;     // offset (doubles) of the dimension's interval tables in ModelDev::tab, -1: none
   double p0, p1, p2;  // kernel constants (see kernels_basis.hip)
 };
 
 struct ModelDev {
   uint64_t model_version = ~0ull;
+  const void *built_for = nullptr;  // the model the tables were built from
   std::vector<int64_t> cap;     // d
   std::vector<DimDesc> dims_h;
   uint64_t Mc = 0;              // compact columns incl. the ones column 0
   DevBuf<DimDesc> dims;
   DevBuf<double> ka, kb, kc;    // per-knot constants (M each)
   DevBuf<double> rot;           // per dim [m][ncolp]
+  DevBuf<double> tab;           // per mat25 / mat25pow dim [m sorted u (even length)][m + 1][ncol][6]
   int build(const obhip_model &m, const std::vector<int64_t> &cap);
 };
 
