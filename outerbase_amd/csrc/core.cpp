@@ -375,6 +375,39 @@ int obhip_terms::prepare(const std::vector<int64_t> &cap,
   return 0;
 }
 
+
+namespace obhip {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel) and only when a launch
+// needs more than what was granted before -- not on every launch
+int ensure_dyn_lds(const void *kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, size_t> granted;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  size_t &g = granted[{dev, kernel}];
+  if (bytes <= g || bytes <= 64 * 1024) return 0;
+  OB_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  g = bytes;
+  return 0;
+}
+
+// compute units of a device (cached per device, not per process)
+int device_cus(int device) {
+  static std::atomic<int> ncu[64];
+  const int slot = device >= 0 && device < 64 ? device : 0;
+  int v = ncu[slot].load();
+  if (!v) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0)
+      v = 256;
+    ncu[slot].store(v);
+  }
+  return v;
+}
+
+}  // namespace obhip
+
 extern "C" {
 
 int obhip_abi_version(void) { return 3; }

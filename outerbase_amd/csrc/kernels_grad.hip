@@ -608,8 +608,7 @@ int run_tmm_ge0(const obhip_basis &src, obhip_terms &t, const int *d_c0, int nhy
                 const double *d_a, dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
   const size_t lds = (t.Mu + 16 * NHB) * kTlPitch * sizeof(double);
   if (lds > 64 * 1024)
-    OB_HIP(hipFuncSetAttribute((const void *)k_tmm_ge0<W2, NHB>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    OB_TRY(ensure_dyn_lds((const void *)k_tmm_ge0<W2, NHB>, lds));
   hipLaunchKernelGGL((k_tmm_ge0<W2, NHB>), grid, dim3(kTlThreads), lds, cur_stream(), src.bm.p,
                      src.scale.p, t.ucol.p, (int)t.Mu, src.md.Mc, (const uint32_t *)t.cols.p,
                      t.sperm.p, d_c0, nhyp, h0, d_a, src.n, ntiles, tps, t.p_pad, part);

@@ -272,8 +272,7 @@ int run_gram_mfma4(const obhip_basis &b, obhip_terms &t, const GramSink &sink) {
   OB_TRY(const_cast<obhip_basis &>(b).workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double),
                                                 (void **)&part));
   const size_t lds = (2 * (t.Mu + 1) * kLD + 3 * kCR * kTP) * sizeof(double) + t.Mu * sizeof(int);
-  OB_HIP(hipFuncSetAttribute((const void *)k_gram_mfma4<W>,
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  OB_TRY(ensure_dyn_lds((const void *)k_gram_mfma4<W>, lds));
   {
     ProfScope ps("gram");
     hipLaunchKernelGGL(k_gram_mfma4<W>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(768), lds,

@@ -36,6 +36,10 @@
 //   operands from two LDS panel buffers [16 rows][272], row-split partials reduced by
 //   k_gram_reduce (kernels_gram.hip).  The same body serves C = A^T Bm for two operands
 //   (launch_atb: row norms for predr_std, stored products for the marginal adjustment).
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "obhip_internal.h"
 #include "device_common.h"
 
@@ -443,8 +447,7 @@ void build_task_order(int nb, int nsplit, bool diag4, std::vector<uint64_t> &tab
 template <int W2>
 int run_materialize(const obhip_basis &b, obhip_terms &t, double *d_B) {
   const size_t lds = (t.Mu * kTileRows + 4 * 32 * kTB) * sizeof(double);
-  OB_HIP(hipFuncSetAttribute((const void *)k_materialize_rows<W2>,
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  OB_TRY(ensure_dyn_lds((const void *)k_materialize_rows<W2>, lds));
   hipLaunchKernelGGL(k_materialize_rows<W2>, dim3((unsigned)(b.n_pad / kTileRows)), dim3(256), lds,
                      cur_stream(), b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc,
                      (const uint32_t *)t.cols.p, (int)(t.W / 2), t.p_pad, d_B);
@@ -512,9 +515,7 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   // Row split: two blocks per CU at a time and all blocks (nearly) equally long, so the launch
   // takes ceil(blocks / slots) rounds of tiles-per-split each; pick the split that minimises
   // that product (528 pairs x 32 splits = 33 x 512 exactly on MI355X).
-  int ncu = 0;
-  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b.device) != hipSuccess || ncu <= 0)
-    ncu = 256;
+  const int ncu = device_cus(b.device);
   const bool diag4 = !(getenv("OBHIP_GRAM_DIAG4") && atoi(getenv("OBHIP_GRAM_DIAG4")) == 0);
   // blocks per row split: four consecutive diagonal tiles take three blocks (atb_wave_code)
   const uint64_t bps = (uint64_t)npairs - (diag4 ? (uint64_t)(nb / 4) : 0);
@@ -558,14 +559,12 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   {
     ProfScope ps("gram");
     if (dbg) {
-      OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbGram, true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      OB_TRY(ensure_dyn_lds((const void *)k_atb_dma2<kAtbGram, true>, lds));
       hipLaunchKernelGGL((k_atb_dma2<kAtbGram, true>), dim3(nblocks), dim3(256), lds, cur_stream(), d_B,
                          t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, ntiles / nsplit, (int)(ntiles % nsplit), b.gram_pairs.p, part,
                          (uint64_t)0, dbgout);
     } else {
-      OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbGram, false>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      OB_TRY(ensure_dyn_lds((const void *)k_atb_dma2<kAtbGram, false>, lds));
       hipLaunchKernelGGL((k_atb_dma2<kAtbGram, false>), dim3(nblocks), dim3(256), lds, cur_stream(),
                          d_B, t.p_pad, d_B, t.p_pad, nb, npairs, ntiles, ntiles / nsplit, (int)(ntiles % nsplit), b.gram_pairs.p, part,
                          (uint64_t)0, nullptr);
@@ -658,43 +657,62 @@ int launch_atb(int mode, const double *A, uint64_t ldA, uint64_t M, const double
     return fail(OBHIP_ERR_INVALID, "launch_atb: sizes must be padded to the tile");
   const uint64_t mt = M / kGT, nt = N / kGT;
   if (mt >= (1ull << 24) || nt >= (1ull << 24)) return fail(OBHIP_ERR_INVALID, "launch_atb: too many tiles");
-  // units of up to 8 x 8 tiles, column-tile squares of equal k range together, dealt to the
-  // XCD with the fewest blocks so far
-  std::vector<std::vector<uint64_t>> seq(kXcd);
-  for (uint64_t bj = 0; bj * kSq < nt; ++bj)
-    for (uint64_t bi = 0; bi * kSq < mt; ++bi) {
-      int k = 0;
-      for (int q = 1; q < kXcd; ++q)
-        if (seq[q].size() < seq[k].size()) k = q;
-      for (uint64_t i = bi * kSq; i < std::min(mt, (bi + 1) * kSq); ++i)
-        for (uint64_t j = bj * kSq; j < std::min(nt, (bj + 1) * kSq); ++j) seq[k].push_back(atb_task(i, j, 0));
+  // The task table depends on (mt, nt) only and a predictor asks for the same one at every
+  // var() call: built and uploaded once per device and shape, kept for the life of the process
+  // (no per-call upload, no stream synchronisation for a local buffer).
+  static std::mutex mu;
+  static std::map<std::tuple<int, uint64_t, uint64_t>, DevBuf<uint64_t> *> cache;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  DevBuf<uint64_t> *dtabp = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    DevBuf<uint64_t> *&slot = cache[std::make_tuple(dev, mt, nt)];
+    if (!slot) {
+      // units of up to 8 x 8 tiles, column-tile squares of equal k range together, dealt to the
+      // XCD with the fewest blocks so far
+      std::vector<std::vector<uint64_t>> seq(kXcd);
+      for (uint64_t bj = 0; bj * kSq < nt; ++bj)
+        for (uint64_t bi = 0; bi * kSq < mt; ++bi) {
+          int k = 0;
+          for (int q = 1; q < kXcd; ++q)
+            if (seq[q].size() < seq[k].size()) k = q;
+          for (uint64_t i = bi * kSq; i < std::min(mt, (bi + 1) * kSq); ++i)
+            for (uint64_t j = bj * kSq; j < std::min(nt, (bj + 1) * kSq); ++j) seq[k].push_back(atb_task(i, j, 0));
+        }
+      size_t len = 0;
+      for (auto &q : seq) len = std::max(len, q.size());
+      std::vector<uint64_t> tab(len * kXcd, kAtbNoTask);
+      for (int k = 0; k < kXcd; ++k)
+        for (size_t m = 0; m < seq[k].size(); ++m) tab[m * kXcd + k] = seq[k][m];
+      slot = new DevBuf<uint64_t>();  // never freed: outlives every stream that reads it
+      const int rc = slot->upload(tab.data(), tab.size());
+      if (rc) {
+        delete slot;
+        slot = nullptr;
+        return rc;
+      }
     }
-  size_t len = 0;
-  for (auto &q : seq) len = std::max(len, q.size());
-  std::vector<uint64_t> tab(len * kXcd, kAtbNoTask);
-  for (int k = 0; k < kXcd; ++k)
-    for (size_t m = 0; m < seq[k].size(); ++m) tab[m * kXcd + k] = seq[k][m];
-  DevBuf<uint64_t> dtab;
-  OB_TRY(dtab.upload(tab.data(), tab.size()));
+    dtabp = slot;
+  }
+  DevBuf<uint64_t> &dtab = *dtabp;
+  const size_t ntasks = dtab.n;
   const size_t lds = (size_t)2 * kCR * kTP * sizeof(double);
   const uint64_t ktiles = K / kTileRows;
   if (mode == kAtbNorm) {
-    OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbNorm, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_atb_dma2<kAtbNorm, false>), dim3((unsigned)tab.size()), dim3(256), lds,
+    OB_TRY(ensure_dyn_lds((const void *)k_atb_dma2<kAtbNorm, false>, lds));
+    hipLaunchKernelGGL((k_atb_dma2<kAtbNorm, false>), dim3((unsigned)ntasks), dim3(256), lds,
                        cur_stream(), A, ldA, Bm, ldB, 0, 0, ktiles, ktiles, tri ? 1 : 0, dtab.p, out,
                        ldo, nullptr);
   } else if (mode == kAtbStore) {
-    OB_HIP(hipFuncSetAttribute((const void *)k_atb_dma2<kAtbStore, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_atb_dma2<kAtbStore, false>), dim3((unsigned)tab.size()), dim3(256), lds,
+    OB_TRY(ensure_dyn_lds((const void *)k_atb_dma2<kAtbStore, false>, lds));
+    hipLaunchKernelGGL((k_atb_dma2<kAtbStore, false>), dim3((unsigned)ntasks), dim3(256), lds,
                        cur_stream(), A, ldA, Bm, ldB, 0, 0, ktiles, ktiles, tri ? 1 : 0, dtab.p, out,
                        ldo, nullptr);
   } else {
     return fail(OBHIP_ERR_INVALID, "launch_atb: unknown mode");
   }
   OB_HIP(hipGetLastError());
-  OB_HIP(hipStreamSynchronize(cur_stream()));  // dtab is a local
   return 0;
 }
 

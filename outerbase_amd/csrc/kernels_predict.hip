@@ -261,16 +261,10 @@ int run_predict_tl(const obhip_model &m, obhip_terms &t, const double *d_theta, 
                    uint64_t n, double *d_mean, const double *d_coeffvar, double e2sigma,
                    double *d_var, int npass) {
   const size_t lds = (t.Mu * kTlPitch + 3 * kTlWaves * kTileRows) * sizeof(double);
-  if (lds > 64 * 1024)
-    OB_HIP(hipFuncSetAttribute((const void *)k_predict_tl<W2, NG, VAR>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-      ncu = 256;
-  }
+  OB_TRY(ensure_dyn_lds((const void *)k_predict_tl<W2, NG, VAR>, lds));
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int ncu = device_cus(dev);
   const uint64_t ntiles = (n + kTileRows - 1) / kTileRows;
   uint64_t nsplit = std::min<uint64_t>(ntiles, (uint64_t)ncu * 4);
   const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
@@ -324,9 +318,7 @@ template <int W2, bool VAR>
 int run_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, const double *d_x,
                 uint64_t n, double *d_mean, const double *d_coeffvar, double e2sigma, double *d_var) {
   const size_t lds = (t.Mu * kTileRows + 2 * kPrWaves * kTileRows) * sizeof(double);
-  if (lds > 64 * 1024)
-    OB_HIP(hipFuncSetAttribute((const void *)k_predict<W2, VAR>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  OB_TRY(ensure_dyn_lds((const void *)k_predict<W2, VAR>, lds));
   hipLaunchKernelGGL((k_predict<W2, VAR>), dim3((unsigned)((n + kTileRows - 1) / kTileRows)),
                      dim3(kPrThreads), lds, cur_stream(), t.pred_md.dims.p, t.pred_md.ka.p, t.pred_md.kb.p,
                      t.pred_md.kc.p, t.pred_md.rot.p, t.pred_md.tab.p, t.cpos.p, (int)m.d, (int)t.Mu,

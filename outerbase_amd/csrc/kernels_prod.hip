@@ -960,10 +960,7 @@ k_tmm_reduce(const double *__restrict__ part, int nsplit, uint64_t p_pad, int p,
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024)
-    OB_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes));
-  return 0;
+  return ensure_dyn_lds((const void *)kernel, bytes);
 }
 
 // more used columns than one LDS tile holds: the generic kernels (kernels_generic.hip)
@@ -1034,17 +1031,6 @@ int launch_getmat(const obhip_basis &b, obhip_terms &t, double *d_out, uint64_t 
   return dispatch_mm<2>(b, t, nullptr, d_out, ld);
 }
 
-int device_cus(int device) {
-  static std::atomic<int> ncu[64];  // per device
-  const int slot = device >= 0 && device < 64 ? device : 0;
-  int v = ncu[slot].load();
-  if (!v) {
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0)
-      v = 256;
-    ncu[slot].store(v);
-  }
-  return v;
-}
 
 template <int W2, bool SQ, int NG>
 int run_mm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, double *part,

@@ -29,6 +29,8 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 int require_device();
 hipStream_t cur_stream();
+int ensure_dyn_lds(const void *kernel, size_t bytes);  // dynamic LDS above 64 KB, granted once per kernel
+int device_cus(int device);                            // compute units (cached per device)
 
 // ---- profiling --------------------------------------------------------------
 struct ProfScope {
