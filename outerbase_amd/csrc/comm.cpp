@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "obhip_internal.h"
@@ -128,7 +129,10 @@ int comm_allreduce(obhip_comm *c, double *d_buf, uint64_t count) {
     const uint64_t nr = (uint64_t)c->nranks;
     // reduce-scatter + all-gather need nranks equal blocks (16-byte multiples); small or
     // ragged buffers take the plain all-reduce (latency-bound anyway)
-    if (count >= 4096 * nr && count % (2 * nr) == 0) {
+    // (OBHIP_RCCL_ALLREDUCE=1 forces the plain all-reduce: a switch for a node where the in-place
+    // reduce-scatter / all-gather pair misbehaves)
+    static const bool plain = getenv("OBHIP_RCCL_ALLREDUCE") && atoi(getenv("OBHIP_RCCL_ALLREDUCE")) != 0;
+    if (!plain && count >= 4096 * nr && count % (2 * nr) == 0) {
       const uint64_t blk = count / nr;
       double *mine = d_buf + (uint64_t)c->rank * blk;
       int rc = r->reduce_scatter(d_buf, mine, blk, kNcclDouble, kNcclSum, c->nccl, st);

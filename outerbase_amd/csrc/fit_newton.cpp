@@ -129,8 +129,20 @@ int obhip_fit_newton_sharded_dev(obhip_comm *comm, const obhip_basis *b, const o
     sink.prec = d_prec;
     sink.diagH = d_diagH;
   }
-  OB_TRY(launch_gram_to(*b, t, sink));
-  OB_TRY(launch_tmm(*b, t, d_y, comm ? d_exbuf + tri : d_g, false));
+  // B^T y: taken along by the staging pass of the design matrix when there is one (its
+  // products are the entries of B), by its own pass over the basis otherwise
+  obhip_basis &bw = *const_cast<obhip_basis *>(b);
+  double *g_dst = comm ? d_exbuf + tri : d_g;
+  bw.fuse_y = d_y;
+  bw.fuse_g = g_dst;
+  bw.fuse_done = false;
+  const int grc = launch_gram_to(*b, t, sink);
+  const bool g_done = bw.fuse_done;
+  bw.fuse_y = nullptr;
+  bw.fuse_g = nullptr;
+  bw.fuse_done = false;
+  OB_TRY(grc);
+  if (!g_done) OB_TRY(launch_tmm(*b, t, d_y, g_dst, false));
   if (comm) {
     {
       ProfScope ps("exchange");

@@ -495,7 +495,14 @@ struct RowView {
 int materialize_any(const obhip_basis &b, obhip_terms &t, double *d_B) {
   if (t.Mu > 280 || getenv("OBHIP_FORCE_GENERIC")) return launch_materialize_generic(b, t, d_B);
   static const bool lane_row = getenv("OBHIP_MATERIALIZE_LANE_ROW") != nullptr;
-  if (!lane_row && materialize_tl_supports(t)) return launch_materialize_tl(b, t, d_B);
+  if (!lane_row && materialize_tl_supports(t)) {
+    // the fit's B^T y rides along (the caller asked through fuse_y / fuse_g; whole basis only)
+    obhip_basis &bw = const_cast<obhip_basis &>(b);
+    const bool fuse = b.fuse_y && b.fuse_g && !b.fuse_done;
+    OB_TRY(launch_materialize_tl(b, t, d_B, fuse ? b.fuse_y : nullptr, fuse ? b.fuse_g : nullptr));
+    if (fuse) bw.fuse_done = true;
+    return 0;
+  }
   switch (t.W / 2) {
     case 1: return run_materialize<1>(b, t, d_B);
     case 2: return run_materialize<2>(b, t, d_B);

@@ -422,12 +422,17 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
 // B[row][k] for the materialised-B Gram kernel (kernels_gram_panel.hip).  lane = two adjacent
 // terms, so a wave instruction stores 64 x 16 B = 1 KB of one row of B and no transpose is
 // needed; products exactly as in k_tmm_tl, the row's basescale is the last factor.
-template <int W, int NPAIR>
+// WITH_Y: B^T y on the way (acc[unit] += B[row][term] y[row]): the fit's only other pass over the
+// basis (k_tmm_tl for B^T y, 1 ms per 1e6 rows) rides on products this kernel forms anyway; it is
+// bound by its HBM writes, so the extra multiply-add per (term, row) is free.
+template <int W, int NPAIR, bool WITH_Y>
 struct MtCtx {
   uint32_t ad[NPAIR * 2][W];  // unit 2 q + i = term i of the lane's pair in pair-group q
   uint32_t koff[NPAIR];       // first of the lane's two terms in pair-group q
   double sc;                  // basescale of row = lane
   double sr;                  // basescale of the current row, wave-uniform
+  double yl, yr;              // y of row = lane / of the current row
+  double acc[WITH_Y ? NPAIR * 2 : 1];
   double v0;
   double *rowp;               // B + current row * p_pad (uniform)
   uint64_t p_pad;
@@ -435,11 +440,13 @@ struct MtCtx {
   template <int RR>
   __device__ __forceinline__ void row() {
     sr = readlane_f64(sc, rc + RR);
+    if constexpr (WITH_Y) yr = readlane_f64(yl, rc + RR);
     if constexpr (RR > 0) rowp += p_pad;
   }
   template <int RR, int UNIT>
   __device__ __forceinline__ void use(double v) {
     v *= sr;
+    if constexpr (WITH_Y) acc[UNIT] = fma(v, yr, acc[UNIT]);
     if constexpr (UNIT % 2 == 0) {
       v0 = v;
     } else {
@@ -451,12 +458,13 @@ struct MtCtx {
   }
 };
 
-template <int W2, int NPAIR, bool PREFETCH>
+template <int W2, int NPAIR, bool PREFETCH, bool WITH_Y>
 __global__ void __launch_bounds__(kTlThreads, 4)
 k_materialize_tl(const double *__restrict__ bm, const double *__restrict__ scale,
                  const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc,
-                 const uint32_t *__restrict__ colsw, uint64_t ntiles, uint64_t tiles_per_split,
-                 uint64_t p_pad, double *__restrict__ out) {
+                 const uint32_t *__restrict__ colsw, uint64_t n, uint64_t ntiles, uint64_t tiles_per_split,
+                 uint64_t p_pad, double *__restrict__ out, const double *__restrict__ y,
+                 double *__restrict__ ypart /* [gridDim.x][p_pad] partial B^T y */) {
   extern __shared__ double lds[];
   constexpr int W = 2 * W2;
   const int lane = threadIdx.x & 63;
@@ -465,8 +473,12 @@ k_materialize_tl(const double *__restrict__ bm, const double *__restrict__ scale
   const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
 
   // pair-group ((blockIdx.y * NPAIR + q) * 8 + wave) covers 128 terms, lane takes two
-  MtCtx<W, NPAIR> c;
+  MtCtx<W, NPAIR, WITH_Y> c;
   c.p_pad = p_pad;
+  if constexpr (WITH_Y) {
+#pragma unroll
+    for (int u = 0; u < NPAIR * 2; ++u) c.acc[u] = 0.0;
+  }
   bool any = false;
 #pragma unroll
   for (int q = 0; q < NPAIR; ++q) {
@@ -494,7 +506,11 @@ k_materialize_tl(const double *__restrict__ bm, const double *__restrict__ scale
       lu[q] = u < Mu ? __builtin_amdgcn_readfirstlane((int)ucol[u] * kTileRows) : 0;
     }
   }
-  double scn = 0.0;
+  double scn = 0.0, yn = 0.0;
+  auto rowy = [&](uint64_t tile) {
+    const uint64_t row = tile * kTileRows + lane;
+    return WITH_Y && row < n ? y[row] : 0.0;
+  };
   auto fetch = [&](uint64_t tile) {
     const double *src = bm + tile * Mc * kTileRows + lane;
 #pragma unroll
@@ -503,6 +519,7 @@ k_materialize_tl(const double *__restrict__ bm, const double *__restrict__ scale
       pre[q] = u < Mu ? src[lu[q]] : 0.0;
     }
     scn = scale[tile * kTileRows + lane];  // 0 in padding rows
+    yn = rowy(tile);
   };
   if (PREFETCH && t0 < t1) fetch(t0);
 
@@ -515,10 +532,12 @@ k_materialize_tl(const double *__restrict__ bm, const double *__restrict__ scale
         if (u < Mu) lds[u * kTlPitch + lane] = pre[q];
       }
       c.sc = scn;
+      c.yl = yn;
     } else {
       const double *src = bm + tile * Mc * kTileRows + lane;
       for (int u = wave; u < Mu; u += kTlWaves) lds[u * kTlPitch + lane] = src[(size_t)ucol[u] * kTileRows];
       c.sc = scale[tile * kTileRows + lane];
+      c.yl = rowy(tile);
     }
     __syncthreads();
     if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
@@ -535,6 +554,16 @@ k_materialize_tl(const double *__restrict__ bm, const double *__restrict__ scale
           c.ad[u][j] += (rc + kTlChunk < kTileRows) ? kTlChunk * 8 : -(kTileRows - kTlChunk) * 8;
           asm volatile("" : "+v"(c.ad[u][j]));
         }
+    }
+  }
+  if constexpr (WITH_Y) {
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) {
+      const uint64_t k = (((uint64_t)blockIdx.y * NPAIR + q) * kTlWaves + wave) * 128 + 2 * lane;
+      if (k < p_pad) {
+        ypart[(uint64_t)blockIdx.x * p_pad + k] = c.acc[2 * q];
+        ypart[(uint64_t)blockIdx.x * p_pad + k + 1] = c.acc[2 * q + 1];
+      }
     }
   }
 }
@@ -1158,30 +1187,33 @@ int tmm_tl_supports(const obhip_terms &t) {
   return w2 >= 1 && w2 <= kMaxW2 && t.Mu * kTlPitch * sizeof(double) <= 156 * 1024;
 }
 
-template <int W2, int NPAIR>
-int run_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B, dim3 grid, uint64_t ntiles,
-                       uint64_t tps) {
+template <int W2, int NPAIR, bool PF, bool WY>
+int run_materialize_tl2(const obhip_basis &b, obhip_terms &t, double *d_B, dim3 grid, uint64_t ntiles,
+                        uint64_t tps, const double *d_y, double *ypart) {
   const size_t lds = t.Mu * kTlPitch * sizeof(double);
-  const bool pf = t.Mu <= (uint64_t)kTlWaves * kTlPre;
-  if (pf) {
-    OB_TRY(set_lds(k_materialize_tl<W2, NPAIR, true>, lds));
-    hipLaunchKernelGGL((k_materialize_tl<W2, NPAIR, true>), grid, dim3(kTlThreads), lds, cur_stream(),
-                       b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,
-                       ntiles, tps, t.p_pad, d_B);
-  } else {
-    OB_TRY(set_lds(k_materialize_tl<W2, NPAIR, false>, lds));
-    hipLaunchKernelGGL((k_materialize_tl<W2, NPAIR, false>), grid, dim3(kTlThreads), lds, cur_stream(),
-                       b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,
-                       ntiles, tps, t.p_pad, d_B);
-  }
+  OB_TRY(set_lds(k_materialize_tl<W2, NPAIR, PF, WY>, lds));
+  hipLaunchKernelGGL((k_materialize_tl<W2, NPAIR, PF, WY>), grid, dim3(kTlThreads), lds, cur_stream(),
+                     b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p, b.n,
+                     ntiles, tps, t.p_pad, d_B, d_y, ypart);
   OB_HIP(hipGetLastError());
   return 0;
+}
+template <int W2, int NPAIR>
+int run_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B, dim3 grid, uint64_t ntiles,
+                       uint64_t tps, const double *d_y, double *ypart) {
+  const bool pf = t.Mu <= (uint64_t)kTlWaves * kTlPre;
+  if (pf && d_y) return run_materialize_tl2<W2, NPAIR, true, true>(b, t, d_B, grid, ntiles, tps, d_y, ypart);
+  if (pf) return run_materialize_tl2<W2, NPAIR, true, false>(b, t, d_B, grid, ntiles, tps, d_y, ypart);
+  if (d_y) return run_materialize_tl2<W2, NPAIR, false, true>(b, t, d_B, grid, ntiles, tps, d_y, ypart);
+  return run_materialize_tl2<W2, NPAIR, false, false>(b, t, d_B, grid, ntiles, tps, d_y, ypart);
 }
 
 bool materialize_tl_supports(const obhip_terms &t) { return tmm_tl_supports(t) != 0; }
 
-// d_B: n_pad x p_pad doubles, row-major; t prepared by the caller
-int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B) {
+// d_B: n_pad x p_pad doubles, row-major; t prepared by the caller.  d_y (n, may be null): also
+// d_g (p) = B^T y, from the products the copy forms anyway.
+int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B, const double *d_y,
+                          double *d_g) {
   const int npmax = t.W / 2 <= 2 ? 4 : 2;
   int npair = 1;
   while (npair < npmax && (uint64_t)kTlWaves * npair * 128 < t.p_pad) npair *= 2;
@@ -1193,14 +1225,30 @@ int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B) {
   const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
   nsplit = (ntiles + tps - 1) / tps;
   const dim3 grid((unsigned)nsplit, (unsigned)pblocks);
-#define OB_MT(W2_, NP_) return run_materialize_tl<W2_, NP_>(b, t, d_B, grid, ntiles, tps)
-  switch (t.W / 2) {
-    case 1: if (npair == 4) OB_MT(1, 4); if (npair == 2) OB_MT(1, 2); OB_MT(1, 1);
-    case 2: if (npair == 4) OB_MT(2, 4); if (npair == 2) OB_MT(2, 2); OB_MT(2, 1);
-    case 3: if (npair == 2) OB_MT(3, 2); OB_MT(3, 1);
-    default: if (npair == 2) OB_MT(4, 2); OB_MT(4, 1);
+  double *ypart = nullptr;
+  if (d_y) OB_TRY(const_cast<obhip_basis &>(b).workspace(nsplit * t.p_pad * sizeof(double), (void **)&ypart));
+  int rc = 0;
+#define OB_MT(W2_, NP_) rc = run_materialize_tl<W2_, NP_>(b, t, d_B, grid, ntiles, tps, d_y, ypart); break
+  switch ((int)(t.W / 2) * 8 + npair) {
+    case 1 * 8 + 4: OB_MT(1, 4);
+    case 1 * 8 + 2: OB_MT(1, 2);
+    case 1 * 8 + 1: OB_MT(1, 1);
+    case 2 * 8 + 4: OB_MT(2, 4);
+    case 2 * 8 + 2: OB_MT(2, 2);
+    case 2 * 8 + 1: OB_MT(2, 1);
+    case 3 * 8 + 2: OB_MT(3, 2);
+    case 3 * 8 + 1: OB_MT(3, 1);
+    case 4 * 8 + 2: OB_MT(4, 2);
+    default: rc = run_materialize_tl<4, 1>(b, t, d_B, grid, ntiles, tps, d_y, ypart); break;
   }
 #undef OB_MT
+  OB_TRY(rc);
+  if (d_y) {
+    hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0, cur_stream(),
+                       ypart, (int)nsplit, t.p_pad, (int)t.p, d_g);
+    OB_HIP(hipGetLastError());
+  }
+  return 0;
 }
 
 int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, bool squared) {

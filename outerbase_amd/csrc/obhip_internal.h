@@ -249,6 +249,11 @@ struct obhip_basis {
   obhip::DevBuf<double> bmat;   // row-major design matrix [n_pad][p_pad], staging of the
                                 // materialised-B Gram kernel (allocated on first use)
   uint64_t bmat_terms = 0;      // uid of the terms bmat currently holds (0: none)
+  // a fit's request to take B^T y along when the design matrix is staged (set by the caller of
+  // launch_gram_to, cleared by it; fuse_done tells whether the staging pass did it)
+  const double *fuse_y = nullptr;
+  double *fuse_g = nullptr;
+  bool fuse_done = false;
   obhip::DevBuf<uint64_t> gram_pairs;  // XCD-aware (tile pair, row split) task order of that kernel
   int gram_pairs_nb = -1, gram_pairs_ns = -1;
   bool gram_pairs_diag4 = false;
@@ -343,7 +348,8 @@ int grad_tmm_host(obhip_basis &b, obhip_terms &t, bool squared, const double *d_
 // kernels_chol.hip
 uint64_t newton_workspace_bytes(uint64_t p);
 bool materialize_tl_supports(const obhip_terms &t);
-int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B);
+int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B, const double *d_y = nullptr,
+                          double *d_g = nullptr);
 int launch_newton_solve(uint64_t p, double *d_H, const double *d_rhs,
                         double *d_theta, void *d_ws, uint64_t ws_bytes);
 int launch_form_hessian(uint64_t p, double *d_G, const double *d_prec,
