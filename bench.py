@@ -336,7 +336,8 @@ def secondary_rooflines(hp, prof):
         b = 8.0 * n * nnz
         return {"lds_GBs": b / ms / 1e6, "lds_frac": b / ms / 1e6 / LDS_PEAK_GBS,
                 "bound": "lds (term-per-lane column reads)"}
-    hbm("build_basis", "k_build_basis", n * 8 * (d + Mc + 1), lambda ms: {"bound": "fp64 valu issue"})
+    hbm("build_basis", "k_build_basis", n * 8 * (d + Mc + 1),
+        lambda ms: {"bound": "latency (bisection + table reads per dimension; interval tables in LDS)"})
     hbm("materialize_B", "k_materialize_tl", n * 8 * (Mc + 1 + p), lambda ms: {"bound": "hbm write"})
     hbm("tmm", "k_tmm_tl", n * 8 * (Mc + 2), lds)
     hbm("mm", "k_mm_tl", n * 8 * (Mc + 2), lds)
