@@ -1341,6 +1341,7 @@ int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   static const bool off = getenv("OBHIP_HESSMULT_FUSED") && atoi(getenv("OBHIP_HESSMULT_FUSED")) == 0;
   const int w2 = (int)(t.W / 2);
+  // (8 terms of 6 factors per lane spill and run at half the speed of the two-kernel form: measured)
   const int numax = w2 <= 2 ? 8 : 4;
   if (off || beyond_lds(t) || w2 < 1 || w2 > kMaxW2 || t.p_pad > (uint64_t)kTlWaves * numax * 64 ||
       (t.Mu * kTlPitch + 2 * kTlWaves * kHmChunk) * sizeof(double) > 156 * 1024)
