@@ -220,7 +220,7 @@ int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
       }
       // knots spread too far for the separable exponentials: one exp per knot on the device
       if (!safe) D.kind = D.kind == OBHIP_COV_MAT25 ? 3 : 4;  // kCovMat25Direct / kCovMat25PowDirect
-      table_dims.push_back(safe ? (int)l : -1);
+      table_dims.push_back(safe && ml <= 127 ? (int)l : -1);  // (build_dim_tab bisects in 7 steps)
     } else {
       table_dims.push_back(-1);
       D.p0 = std::exp(a * hy[0]);  // expLSs, covfuncs.cpp:290
@@ -391,6 +391,11 @@ int ensure_dyn_lds(const void *kernel, size_t bytes) {
   OB_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   g = bytes;
   return 0;
+}
+
+uint64_t next_model_version() {
+  static std::atomic<uint64_t> counter{0};
+  return ++counter;
 }
 
 // compute units of a device (cached per device, not per process)

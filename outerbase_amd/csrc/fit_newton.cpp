@@ -108,16 +108,19 @@ int obhip_fit_newton_sharded_dev(obhip_comm *comm, const obhip_basis *b, const o
     if (!d_exbuf || exbuf_count < cnt) return fail(OBHIP_ERR_INVALID, "fit_newton_sharded_dev: exchange buffer too small");
     exbuf_count = cnt;
   }
-  double *d_prec = (double *)d_workspace;
-  double *d_rhs = d_prec + p;
+  double *d_rhs = (double *)d_workspace + p;
   void *d_cholws = d_rhs + p;
   const double e2 = std::exp(-2.0 * sigma);
   hipStream_t st = cur_stream();
-  {
+  // prior precisions: uploaded when the model state or rho changed, otherwise already in HBM
+  if (!t.prec_dev.p || t.prec_model != m || t.prec_version != m->version || t.prec_rho != rho) {
     const std::vector<double> prec = prior_prec_of(*m, t, rho);
-    OB_HIP(hipMemcpyAsync(d_prec, prec.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
-    OB_HIP(hipStreamSynchronize(st));  // prec is a local
+    OB_TRY(t.prec_dev.upload(prec.data(), p));  // (synchronises: prec is a local)
+    t.prec_model = m;
+    t.prec_version = m->version;
+    t.prec_rho = rho;
   }
+  const double *d_prec = t.prec_dev.p;
   GramSink sink;
   if (comm) {
     sink.out = d_exbuf;

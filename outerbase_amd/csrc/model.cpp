@@ -315,7 +315,7 @@ int obhip_model::build() {
       });
     for (std::thread &th : pool) th.join();
   }
-  ++version;
+  version = obhip::next_model_version();
   return 0;
 }
 
@@ -468,7 +468,7 @@ int obhip_model_set_rotation(obhip_model *m, const double *rotmat,
       return fail(OBHIP_ERR_INVALID, "set_rotation: maxlevel out of range");
   }
   m->maxlevel.assign(maxlevel, maxlevel + m->d);
-  ++m->version;
+  m->version = obhip::next_model_version();
   return 0;
 }
 
@@ -501,7 +501,7 @@ int obhip_model_set_rotation_grad(obhip_model *m, const double *rotmat_gradhyp,
   const uint64_t ng = m->gest.back();
   m->rotmat_gradhyp.assign(rotmat_gradhyp, rotmat_gradhyp + m->mmax * ng);
   m->logbasisvar_gradhyp.assign(logbasisvar_gradhyp, logbasisvar_gradhyp + ng);
-  ++m->version;
+  m->version = obhip::next_model_version();
   return 0;
 }
 

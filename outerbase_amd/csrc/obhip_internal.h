@@ -29,6 +29,10 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 int require_device();
 hipStream_t cur_stream();
+// model state stamps are drawn from one process-wide counter: device tables cached under
+// (model address, stamp) can then never be taken for those of another model that came to live at
+// the same address
+uint64_t next_model_version();
 int ensure_dyn_lds(const void *kernel, size_t bytes);  // dynamic LDS above 64 KB, granted once per kernel
 int device_cus(int device);                            // compute units (cached per device)
 
@@ -207,6 +211,12 @@ struct obhip_terms {
   // device view of the model capped at maxlev, for the fused predictor
   obhip::ModelDev pred_md;
   const obhip_model *pred_model = nullptr;
+  // prior precisions 1 / (sd e^rho)^2 of these terms on the device, for the model state and rho
+  // they were last asked for (the device-side Newton fit: no upload, no host sync per fit)
+  obhip::DevBuf<double> prec_dev;
+  const obhip_model *prec_model = nullptr;
+  uint64_t prec_version = 0;
+  double prec_rho = 0.0;
   int prepare(const std::vector<int64_t> &cap, const std::vector<obhip::DimDesc> &dims);
 };
 
