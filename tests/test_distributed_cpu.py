@@ -1,6 +1,9 @@
 """N > 1 path on CPU: two gloo ranks shard the rows of the synthetic stream and exchange
-ONE buffer per fit -- the layout libobhip packs on the device (include/obhip.h,
-obhip_normal_eq_exchange_dev): [packed upper triangle of G_r][B_r^T y_r][B_r^T 1]
+ONE buffer per fit.  Two contracts are rehearsed: the ABI-3 flow the driver runs
+(obhip_standardise_dev + obhip_fit_newton_sharded_dev: 24 bytes for mean / sd of y, then
+[packed upper triangle of G_r][B_r^T y_r of the standardised y][padding];
+test_two_rank_abi3_flow_equals_single_process) and the ABI-2 composition that is still exported
+(include/obhip.h, obhip_normal_eq_exchange_dev): [packed upper triangle of G_r][B_r^T y_r][B_r^T 1]
 [sum y_r, sum y_r^2, n_r][padding].  The local arithmetic comes from the CPU oracle here
 (no GPU in this tier); what is checked is the sharding contract of SURVEY.md section 8e:
 contiguous row blocks by rank, the buffer size the library reports, that the summed buffer
@@ -136,6 +139,83 @@ def test_two_rank_row_sharding_equals_single_process(tmp_path):
         xnew, _ = O.synth_xy(43, int(r["row0"]), 20, KINDS)
         want = cent + sd * O.predict_mean(om, terms, theta, xnew)
         assert np.max(np.abs(r["mean"] - want)) < 1e-6 * np.max(np.abs(want))
+
+
+def _worker_v3(rank, world, port, out_dir):
+    """One rank of the ABI-3 flow (obhip_standardise_dev + obhip_fit_newton_sharded_dev) with the
+    local arithmetic from the CPU oracle: (sum y, n) summed -> mean; sum (y - mean)^2 summed ->
+    sd (two-pass, like R's sd()); y standardised BEFORE B^T y; ONE buffer [packed upper triangle
+    of G_r][B_r^T y_r][zero padding] summed; H = e^{-2 sigma} G + prior formed while unpacking."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    from outerbase_amd import _lib, driver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        om = _model()
+        terms = om.selectterms(P)
+        row0, nrow = driver.shard_rows(rank, world, ROWS_TOTAL)
+        x, y = O.synth_xy(42, row0, nrow, KINDS)
+        comm, cb = driver.make_comm(rank, world, "host")
+
+        def allsum(vals):
+            v = np.ascontiguousarray(vals, dtype=np.float64)
+            assert cb(None, v.ctypes.data, len(v)) == 0
+            return v
+        s1, ntot = allsum([y.sum(), float(nrow)])              # 16 bytes
+        cent = s1 / ntot
+        sd = math.sqrt(allsum([np.sum((y - cent) ** 2)])[0] / (ntot - 1.0))   # 8 bytes
+        ys = (y - cent) / sd
+        G, g = O.gram(O.OuterBase(om, x), terms, ys)
+        cnt = C.c_uint64(0)
+        _lib.call("obhip_fit_newton_count", P, world, C.byref(cnt))
+        tri = P * (P + 1) // 2
+        buf = np.zeros(cnt.value)
+        buf[:tri] = G[np.triu_indices(P)]                       # what k_gram_reduce writes (packed)
+        buf[tri:tri + P] = g                                    # what the staging pass writes
+        allsum_buf = allsum(buf)
+        _lib.call("obhip_comm_destroy", comm)
+        sigma = math.log(0.01)
+        e2 = math.exp(-2 * sigma)
+        H = np.zeros((P, P))                                    # k_unpack_form
+        H[np.triu_indices(P)] = e2 * allsum_buf[:tri]
+        H = H + np.triu(H, 1).T
+        H[np.diag_indices(P)] += O.prior_prec(om, terms, O.DEFAULT_RHO)
+        theta = np.linalg.solve(H, e2 * allsum_buf[tri:tri + P])
+        xnew, _ = O.synth_xy(43, row0, 20, KINDS)
+        mean = cent + sd * O.predict_mean(om, terms, theta, xnew)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), theta=theta, mean=mean, cent=cent,
+                 sd=sd, ntot=ntot, row0=row0, count=cnt.value, pad=allsum_buf[tri + P:])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_abi3_flow_equals_single_process(tmp_path):
+    """The exchange contract of obhip_fit_newton_sharded_dev under gloo: 24 bytes for the
+    standardisation, one [triangle | B^T y] buffer, replicated solve."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker_v3, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    assert int(r0["ntot"]) == ROWS_TOTAL and int(r0["count"]) % (2 * world) == 0
+    assert int(r0["count"]) >= P * (P + 1) // 2 + P and not r0["pad"].any()
+    assert np.array_equal(r0["theta"], r1["theta"])
+    om = _model()
+    terms = om.selectterms(P)
+    x, y = O.synth_xy(42, 0, ROWS_TOTAL, KINDS)
+    cent, sd = y.mean(), y.std(ddof=1)
+    assert abs(r0["cent"] - cent) < 1e-14 * abs(cent) and abs(r0["sd"] - sd) < 1e-14 * sd
+    theta, _ = O.fit_newton(O.OuterBase(om, x), terms, (y - cent) / sd, sigma=math.log(0.01))
+    assert np.max(np.abs(r0["theta"] - theta)) < 1e-9 * np.max(np.abs(theta))
+    for r in (r0, r1):
+        xnew, _ = O.synth_xy(43, int(r["row0"]), 20, KINDS)
+        want = cent + sd * O.predict_mean(om, terms, theta, xnew)
+        assert np.max(np.abs(r["mean"] - want)) < 1e-9 * np.max(np.abs(want))
 
 
 def test_shards_cover_the_rows_exactly_once():
