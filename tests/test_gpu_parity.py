@@ -1081,6 +1081,24 @@ def test_term_per_lane_variants(max_nnz, p, maxlev):
         assert relerr(var, (Bd * Bd) @ cv + math.exp(2 * sig)) < 1e-11
         call("obhip_predict", om_d._h, tt._h, ptr(a), ptr(xf), n, n, ptr(mean), None, sig, None)
         assert relerr(mean, Bd @ a) < 1e-11
+        # the fused Hessian product (k_hm_tl: B^T (e^{-2 sigma} B a) in one pass when all terms
+        # fit one block, the two kernels otherwise) through loglik_gauss$hessmult, and its
+        # update() form (B^T (e^{-2 sigma} (y - B theta)), sum of squared residuals) through
+        # three iterations of the device PCG against the oracle's lpdf::optcg
+        if n >= 2:
+            lik = ob.loglik_gauss(om_d, terms, v, x)
+            e2 = math.exp(-2 * lik.para[0])
+            assert relerr(lik.hessmult(a), e2 * (Bd.T @ (Bd @ a))) < 1e-11
+            if n <= 1100 and maxlev < 12:
+                sig0 = float(lik.para[0])
+                th_o, it_o, _ = O.fit_cg(O.OuterBase(om_o, x), terms, v, sigma=sig0, tol=1e-30, maxit=3)
+                th = np.zeros(terms.shape[0])
+                its = C.c_uint64(0)
+                yv = np.ascontiguousarray(v)
+                call("obhip_fit_cg", bd._h, tt._h, om_d._h, ptr(yv), sig0, 6.0, 1e-30, 3, ptr(th),
+                     C.byref(its), None, None)
+                assert its.value == it_o == 3
+                assert relerr(th, th_o) < (1e-5 if maxlev >= 5 else 1e-8)
 
 
 @pytest.mark.parametrize("seed", range(16))
