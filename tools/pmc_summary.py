@@ -1,12 +1,13 @@
 """Sums rocprofv3 --pmc counter_collection.csv per kernel (tuning aid)."""
-import collections, csv, sys
+import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 pat = sys.argv[2] if len(sys.argv) > 2 else "gram"
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.Counter()
 for r in rows:
     if pat in r["Kernel_Name"]:
-        k = r["Kernel_Name"].split("(")[0][-40:]
+        m = re.search(r"k_\w+(<[^>]*>)?", r["Kernel_Name"])   # "(anonymous namespace)" holds the first "("
+        k = m.group(0) if m else r["Kernel_Name"][:60]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, v in agg.items():
     print(k)
