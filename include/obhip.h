@@ -58,6 +58,8 @@ typedef struct obhip_comm obhip_comm;   /* the ranks of a row-sharded job (no re
                                            modandbase.cpp:464) */
 
 /* ---- library ----------------------------------------------------------- */
+/* 3.  (2 -> 3: obhip_standardise_dev, obhip_destandardise_dev, obhip_fit_newton_count,
+ * obhip_fit_newton_sharded_dev, obhip_source_hash added; nothing removed or changed.) */
 int obhip_abi_version(void);
 const char *obhip_last_error(void);
 /* 16 hex digits of the SHA-256 over the library's sources at build time: which = 0 all of
