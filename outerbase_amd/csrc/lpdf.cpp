@@ -394,15 +394,25 @@ struct Loglik : obhip_lpdf {
   }
   virtual int set_comm(obhip_comm *c) {
     comm = c;
-    double v[3];
-    // sum y, sum y^2, n over all rows: para0 = log(0.01 var(y)) must be the same on every rank
+    // var(y) over ALL rows, two-pass like R's var() (para0 = log(0.01 var(y)) must be the same on
+    // every rank): (sum y, n) summed -> mean, then sum (y - mean)^2 summed.  (The one-pass form
+    // sum y^2 - n mean^2 of round 2 lost eps (mean / sd)^2 relative.)
+    double v[2];
     OB_TRY(launch_sum_sumsq(y.p, n, red.p, red.p + 64));
-    OB_TRY(d2h(v, red.p, 2 * sizeof(double)));
-    v[2] = (double)n;
-    OB_TRY(sum_ranks(v, 3));
-    n_total = v[2];
-    const double cent = v[0] / v[2];
-    yvar_total = std::max(v[1] - v[2] * cent * cent, 0.0) / (v[2] - 1.0);
+    OB_TRY(d2h(v, red.p, sizeof(double)));
+    v[1] = (double)n;
+    OB_TRY(sum_ranks(v, 2));
+    n_total = v[1];
+    const double cent = v[0] / v[1];
+    const double *yp = y.p;
+    OB_TRY(vsum<1>(n, [=] __device__(uint64_t i, double (&acc)[1]) {
+      const double dl = yp[i] - cent;
+      acc[0] = fma(dl, dl, acc[0]);
+    }, red.p, red.p + 64));
+    double ssq = 0;
+    OB_TRY(d2h(&ssq, red.p, sizeof(double)));
+    OB_TRY(sum_ranks(&ssq, 1));
+    yvar_total = n_total > 1.0 ? ssq / (n_total - 1.0) : std::numeric_limits<double>::quiet_NaN();
     return 0;
   }
   double yvar_total = 0;
