@@ -22,7 +22,16 @@
  *     they do not synchronise.  Functions without the suffix take host
  *     pointers and return after the result is in the host buffer;
  *   - there is NO CPU fallback: without a visible gfx950 device every
- *     device-touching call fails with OBHIP_ERR_NO_DEVICE.
+ *     device-touching call fails with OBHIP_ERR_NO_DEVICE;
+ *   - handles are NOT re-entrant: like the reference (one R main thread,
+ *     SURVEY.md section 8b "Threading") a model / basis / terms / lpdf /
+ *     communicator is used by one thread at a time.  Calls on a `const`
+ *     handle may still fill caches behind it (device tables of the terms, the
+ *     staged design matrix and task tables of a basis, the prior precisions);
+ *     different handles may be used from different threads concurrently;
+ *   - collective calls (anything taking an obhip_comm with more than one rank)
+ *     must be made by every rank with the same sizes: an argument error on one
+ *     rank returns on that rank while its peers wait in the collective.
  */
 #ifndef OBHIP_H
 #define OBHIP_H
@@ -58,8 +67,10 @@ typedef struct obhip_comm obhip_comm;   /* the ranks of a row-sharded job (no re
                                            modandbase.cpp:464) */
 
 /* ---- library ----------------------------------------------------------- */
-/* 3.  (2 -> 3: obhip_standardise_dev, obhip_destandardise_dev, obhip_fit_newton_count,
- * obhip_fit_newton_sharded_dev, obhip_source_hash added; nothing removed or changed.) */
+/* 4.  (2 -> 3: obhip_standardise_dev, obhip_destandardise_dev, obhip_fit_newton_count,
+ * obhip_fit_newton_sharded_dev, obhip_source_hash added; 3 -> 4: obhip_comm_selftest_dev,
+ * obhip_comm_exchange_path, obhip_comm_init_sim added, obhip_standardise_dev accepts an empty
+ * shard when it has a communicator; nothing removed.) */
 int obhip_abi_version(void);
 const char *obhip_last_error(void);
 /* 16 hex digits of the SHA-256 over the library's sources at build time: which = 0 all of
@@ -317,6 +328,13 @@ int obhip_fit_cg_dev(const obhip_basis *b, const obhip_terms *t,
 #define OBHIP_TRANSPORT_NONE 0
 #define OBHIP_TRANSPORT_RCCL 1 /* ncclReduceScatter + ncclAllGather over xGMI */
 #define OBHIP_TRANSPORT_HOST 2 /* caller-supplied sum of a host buffer (MPI, gloo) */
+#define OBHIP_TRANSPORT_SIM 3  /* N virtual ranks holding this rank's shard: sum = N x, on the device */
+/* what sums a buffer of a given size (obhip_comm_exchange_path) */
+#define OBHIP_EXCHANGE_NONE 0
+#define OBHIP_EXCHANGE_PAIR 1      /* ncclReduceScatter + ncclAllGather, in place */
+#define OBHIP_EXCHANGE_ALLREDUCE 2 /* ncclAllReduce */
+#define OBHIP_EXCHANGE_HOST 3
+#define OBHIP_EXCHANGE_SIM 4
 /* rank 0 draws the communicator id (ncclGetUniqueId); the launcher hands the 128 bytes to
  * every rank */
 int obhip_comm_unique_id(void *id);
@@ -336,6 +354,28 @@ int obhip_comm_info(const obhip_comm *c, int *nranks, int *rank, int *transport,
                     int *rccl_version);
 /* in-place sum of count doubles in HBM over the ranks, on the library's stream */
 int obhip_comm_allreduce_dev(obhip_comm *c, double *d_buf, uint64_t count);
+/* A communicator of nranks VIRTUAL ranks that all hold this process's shard: every sum is one
+ * device pass buf *= nranks, nothing leaves the GPU.  For timing, on one GPU, the step one rank
+ * of an nranks-GPU job runs (exchange-buffer layout, unpack, replicated solve); the result is
+ * the fit of the shard's rows repeated nranks times. */
+int obhip_comm_init_sim(obhip_comm **out, int nranks);
+/* path: OBHIP_EXCHANGE_* a buffer of count doubles takes on this communicator (large buffers
+ * in equal 16-byte blocks per rank: the reduce-scatter / all-gather pair, unless
+ * OBHIP_RCCL_ALLREDUCE=1 was set on any rank when the communicator was made -- the flags are
+ * summed over the ranks at init -- or the self-test switched it off); selftest: 0 not run,
+ * 1 passed, 2 passed after switching the pair off.  Either pointer may be NULL. */
+int obhip_comm_exchange_path(const obhip_comm *c, uint64_t count, int *path, int *selftest);
+/* Collective self-test of the exchange on a buffer of count doubles (pass the size of the real
+ * exchange, obhip_fit_newton_count): rank r fills (r + 1) w_i with small integers w_i, the sums
+ * over the ranks are compared ON THE DEVICE with the closed form nranks (nranks + 1) / 2 w_i,
+ * once through the reduce-scatter / all-gather pair (if a buffer of this size takes it) and
+ * once through the plain all-reduce; the mismatch counts are summed over the ranks so that all
+ * take the same decision.  Pair wrong, all-reduce right: the communicator switches to the
+ * all-reduce for every size, in this process, and the call succeeds.  All-reduce wrong:
+ * OBHIP_ERR_STATE.  result (4 values, may be NULL): OBHIP_EXCHANGE_* in use afterwards for this
+ * size, mismatching elements of the pair (-1: not tried), of the all-reduce, 1 if the pair was
+ * switched off by this call. */
+int obhip_comm_selftest_dev(obhip_comm *c, uint64_t count, int64_t *result);
 /* The one exchange of back end A.  Buffer layout (count doubles, obhip_normal_eq_count):
  * [upper triangle of G_r = B_r^T B_r, row-major packed, p (p + 1) / 2][B_r^T y_r : p]
  * [B_r^T 1 : p][sum y_r, sum y_r^2, n_r][zero padding to 2 nranks].  Pack -> sum over ranks ->
@@ -357,7 +397,9 @@ int obhip_normal_eq_count(uint64_t p, int nranks, uint64_t *count);
  * over the rows of ALL ranks, two-pass like R's sd(): (sum y, n) and sum (y - mean)^2 are
  * summed over the ranks (24 bytes in two exchanges), nothing returns to the host.
  * d_y_raw, d_y: n doubles (device; may be the same buffer); d_meansd: mean, sd, rows of all
- * ranks (device, 3 doubles).  comm may be NULL (one rank). */
+ * ranks (device, 3 doubles).  comm may be NULL (one rank).  With a communicator n = 0 is a legal
+ * shard (it still takes part in the two sums; d_y_raw / d_y may then be NULL); fewer than two
+ * rows over all ranks give sd = NaN as R's sd() does. */
 int obhip_standardise_dev(obhip_comm *comm, const double *d_y_raw, uint64_t n, double *d_y,
                           double *d_meansd);
 /* obpred's de-standardisation (R/fitting.R:152): v = mean + sd v, in place, mean and sd read

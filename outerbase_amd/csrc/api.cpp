@@ -63,6 +63,7 @@ namespace obhip {
 std::vector<double> prior_prec_of(const obhip_model &m, const obhip_terms &t, double rho) {
   return prior_prec(m, t, rho);
 }
+int check_compat_of(const obhip_model *m, const obhip_terms *t) { return check_compat(m, t); }
 }  // namespace obhip
 
 namespace {

@@ -15,6 +15,16 @@
 //   host  (obhip_comm_init_host): the caller supplies "sum this HOST buffer over ranks"
 //         (gloo in the one-GPU rehearsals of the tests, MPI_Allreduce under R); the library
 //         stages through a pinned buffer.
+//   sim   (obhip_comm_init_sim): N virtual ranks that all hold THIS rank's shard; a sum is one
+//         device pass buf *= N.  No wire: it exists to time, on one GPU, the step a rank of an
+//         N-GPU job runs (pack, unpack, form H, replicated solve), and its result is checkable
+//         (the fit of the shard's rows repeated N times).
+//
+// Which collective an RCCL communicator uses is fixed when it is created and is the same on all
+// ranks: OBHIP_RCCL_ALLREDUCE=1 on ANY rank (the flags are summed over the ranks at init) turns
+// the reduce-scatter / all-gather pair off everywhere, and obhip_comm_selftest_dev does the same
+// when the pair returns wrong sums on this node.  Ranks can therefore never issue different
+// collectives on one communicator.
 #include <dlfcn.h>
 
 #include <cmath>
@@ -22,6 +32,7 @@
 #include <cstring>
 
 #include "obhip_internal.h"
+#include "vec_ops.h"
 
 using namespace obhip;
 
@@ -111,7 +122,45 @@ struct obhip_comm {
   size_t pinned_n = 0;
   // statistics of the last exchange
   uint64_t last_bytes = 0, calls = 0;
+  // RCCL: plain ncclAllReduce for every size (agreed over the ranks at init, or set by the
+  // self-test); selftest: 0 not run, 1 passed, 2 passed after switching the pair off
+  bool plain = false;
+  int selftest = 0;
 };
+
+namespace {
+
+// reduce-scatter + all-gather need nranks equal blocks (16-byte multiples); small or ragged
+// buffers take the plain all-reduce (latency-bound anyway)
+bool pair_fits(const obhip_comm *c, uint64_t count) {
+  const uint64_t nr = (uint64_t)c->nranks;
+  return count >= 4096 * nr && count % (2 * nr) == 0;
+}
+
+int rccl_pair(obhip_comm *c, double *d_buf, uint64_t count, hipStream_t st) {
+  Rccl *r = c->r;
+  const uint64_t blk = count / (uint64_t)c->nranks;
+  double *mine = d_buf + (uint64_t)c->rank * blk;
+  int rc = r->reduce_scatter(d_buf, mine, blk, kNcclDouble, kNcclSum, c->nccl, st);
+  if (rc) return rccl_fail(r, rc, "ncclReduceScatter");
+  rc = r->all_gather(mine, d_buf, blk, kNcclDouble, c->nccl, st);
+  if (rc) return rccl_fail(r, rc, "ncclAllGather");
+  // fault injection for the tests of the self-test's in-process switch: one wrong element
+  if (const char *e = getenv("OBHIP_FAULT_INJECT_PAIR"))
+    if (atoi(e) != 0) {
+      double *q = d_buf + count / 2;
+      OB_TRY(vmap(1, [=] __device__(uint64_t) { *q += 1.0; }));
+    }
+  return 0;
+}
+
+int rccl_plain(obhip_comm *c, double *d_buf, uint64_t count, hipStream_t st) {
+  const int rc = c->r->all_reduce(d_buf, d_buf, count, kNcclDouble, kNcclSum, c->nccl, st);
+  if (rc) return rccl_fail(c->r, rc, "ncclAllReduce");
+  return 0;
+}
+
+}  // namespace
 
 namespace obhip {
 
@@ -124,26 +173,11 @@ int comm_allreduce(obhip_comm *c, double *d_buf, uint64_t count) {
   hipStream_t st = cur_stream();
   c->last_bytes = count * sizeof(double);
   c->calls += 1;
-  if (c->transport == OBHIP_TRANSPORT_RCCL) {
-    Rccl *r = c->r;
-    const uint64_t nr = (uint64_t)c->nranks;
-    // reduce-scatter + all-gather need nranks equal blocks (16-byte multiples); small or
-    // ragged buffers take the plain all-reduce (latency-bound anyway)
-    // (OBHIP_RCCL_ALLREDUCE=1 forces the plain all-reduce: a switch for a node where the in-place
-    // reduce-scatter / all-gather pair misbehaves)
-    static const bool plain = getenv("OBHIP_RCCL_ALLREDUCE") && atoi(getenv("OBHIP_RCCL_ALLREDUCE")) != 0;
-    if (!plain && count >= 4096 * nr && count % (2 * nr) == 0) {
-      const uint64_t blk = count / nr;
-      double *mine = d_buf + (uint64_t)c->rank * blk;
-      int rc = r->reduce_scatter(d_buf, mine, blk, kNcclDouble, kNcclSum, c->nccl, st);
-      if (rc) return rccl_fail(r, rc, "ncclReduceScatter");
-      rc = r->all_gather(mine, d_buf, blk, kNcclDouble, c->nccl, st);
-      if (rc) return rccl_fail(r, rc, "ncclAllGather");
-    } else {
-      const int rc = r->all_reduce(d_buf, d_buf, count, kNcclDouble, kNcclSum, c->nccl, st);
-      if (rc) return rccl_fail(r, rc, "ncclAllReduce");
-    }
-    return 0;
+  if (c->transport == OBHIP_TRANSPORT_RCCL)
+    return !c->plain && pair_fits(c, count) ? rccl_pair(c, d_buf, count, st) : rccl_plain(c, d_buf, count, st);
+  if (c->transport == OBHIP_TRANSPORT_SIM) {
+    const double nr = (double)c->nranks;
+    return vmap(count, [=] __device__(uint64_t i) { d_buf[i] *= nr; });
   }
   if (c->transport == OBHIP_TRANSPORT_HOST) {
     // one rank without a callback (obhip_comm_init_host accepts that): the sum is the identity
@@ -208,7 +242,120 @@ int obhip_comm_init(obhip_comm **out, int nranks, int rank, const void *id) {
     delete c;
     return fail(OBHIP_ERR_STATE, "RCCL communicator reports a different rank count");
   }
+  // OBHIP_RCCL_ALLREDUCE=1 (a switch for a node where the in-place reduce-scatter / all-gather
+  // pair misbehaves): decided here once, and agreed -- the flags of all ranks are summed, so a
+  // launcher that forwards the variable to some ranks only cannot make them issue different
+  // collectives
+  {
+    const char *e = getenv("OBHIP_RCCL_ALLREDUCE");
+    double flag = e && atoi(e) != 0 ? 1.0 : 0.0;
+    DevBuf<double> f;
+    int rc2 = f.upload(&flag, 1);
+    hipStream_t st = cur_stream();
+    if (!rc2) rc2 = rccl_plain(c, f.p, 1, st);
+    if (!rc2 && (hipMemcpyAsync(&flag, f.p, sizeof flag, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                 hipStreamSynchronize(st) != hipSuccess))
+      rc2 = fail(OBHIP_ERR_HIP, "comm_init: reading back the agreed exchange path failed");
+    if (rc2) {
+      (void)r->comm_destroy(c->nccl);
+      delete c;
+      return rc2;
+    }
+    c->plain = flag > 0.0;
+  }
   *out = c;
+  return 0;
+}
+
+int obhip_comm_init_sim(obhip_comm **out, int nranks) {
+  if (!out || nranks < 1) return fail(OBHIP_ERR_INVALID, "comm_init_sim: bad argument");
+  OB_TRY(require_device());
+  obhip_comm *c = new obhip_comm();
+  c->nranks = nranks;
+  c->rank = 0;
+  c->transport = OBHIP_TRANSPORT_SIM;
+  (void)hipGetDevice(&c->device);
+  *out = c;
+  return 0;
+}
+
+int obhip_comm_exchange_path(const obhip_comm *c, uint64_t count, int *path, int *selftest) {
+  if (!c) return fail(OBHIP_ERR_INVALID, "comm_exchange_path: null communicator");
+  if (path) {
+    if (c->transport == OBHIP_TRANSPORT_RCCL)
+      *path = !c->plain && pair_fits(c, count) ? OBHIP_EXCHANGE_PAIR : OBHIP_EXCHANGE_ALLREDUCE;
+    else
+      *path = c->transport == OBHIP_TRANSPORT_HOST ? OBHIP_EXCHANGE_HOST
+                                                   : (c->transport == OBHIP_TRANSPORT_SIM ? OBHIP_EXCHANGE_SIM : OBHIP_EXCHANGE_NONE);
+  }
+  if (selftest) *selftest = c->selftest;
+  return 0;
+}
+
+// Every rank fills count doubles with (rank + 1) w_i, w_i = 1 + i mod 1021 (small integers: every
+// partial sum is exact in any order), sums them over the ranks and compares ON THE DEVICE with
+// the closed form nranks (nranks + 1) / 2 w_i -- once through the reduce-scatter / all-gather
+// pair (when a buffer of this size would take it) and once through the plain all-reduce.  The
+// mismatch counts are summed over the ranks, so every rank takes the same decision.
+int obhip_comm_selftest_dev(obhip_comm *c, uint64_t count, int64_t *result) {
+  if (!c || count == 0) return fail(OBHIP_ERR_INVALID, "comm_selftest_dev: bad argument");
+  OB_TRY(require_device());
+  hipStream_t st = cur_stream();
+  DevBuf<double> buf, bad, red;
+  OB_TRY(buf.alloc(count));
+  OB_TRY(bad.alloc(2));
+  OB_TRY(red.alloc((size_t)kSumBlocks));
+  OB_HIP(hipMemsetAsync(bad.p, 0, 2 * sizeof(double), st));
+  double *b = buf.p;
+  const double mine = (double)(c->rank + 1);
+  const double nr = (double)c->nranks;
+  const double tot = c->transport == OBHIP_TRANSPORT_SIM ? nr * mine : nr * (nr + 1.0) / 2.0;
+  auto fill = [&]() { return vmap(count, [=] __device__(uint64_t i) { b[i] = mine * (double)(1 + i % 1021); }); };
+  auto check = [&](double *dst) {
+    return vsum<1>(count, [=] __device__(uint64_t i, double (&acc)[1]) {
+      acc[0] += b[i] == tot * (double)(1 + i % 1021) ? 0.0 : 1.0;
+    }, dst, red.p);
+  };
+  const bool rccl_t = c->transport == OBHIP_TRANSPORT_RCCL;
+  const bool try_pair = rccl_t && !c->plain && pair_fits(c, count);
+  if (try_pair) {
+    OB_TRY(fill());
+    OB_TRY(rccl_pair(c, b, count, st));
+    OB_TRY(check(bad.p));
+  }
+  OB_TRY(fill());
+  if (rccl_t) OB_TRY(rccl_plain(c, b, count, st));
+  else OB_TRY(comm_allreduce(c, b, count));
+  OB_TRY(check(bad.p + 1));
+  // the verdicts of all ranks (through the plain path: were that one broken, the rank that saw
+  // it has a non-zero count of its own and fails below whatever the sum says)
+  double own[2], all[2];
+  OB_HIP(hipMemcpyAsync(own, bad.p, sizeof own, hipMemcpyDeviceToHost, st));
+  OB_HIP(hipStreamSynchronize(st));
+  if (rccl_t) OB_TRY(rccl_plain(c, bad.p, 2, st));
+  else OB_TRY(comm_allreduce(c, bad.p, 2));
+  OB_HIP(hipMemcpyAsync(all, bad.p, sizeof all, hipMemcpyDeviceToHost, st));
+  OB_HIP(hipStreamSynchronize(st));
+  const bool pair_bad = try_pair && (own[0] != 0.0 || all[0] != 0.0);
+  const bool plain_bad = own[1] != 0.0 || all[1] != 0.0;
+  if (result) {
+    result[0] = 0;
+    result[1] = try_pair ? (int64_t)std::max(own[0], all[0]) : -1;
+    result[2] = (int64_t)std::max(own[1], all[1]);
+    result[3] = pair_bad ? 1 : 0;
+  }
+  if (plain_bad)
+    return fail(OBHIP_ERR_STATE, "comm_selftest: the all-reduce of this communicator returns wrong sums (" +
+                                     std::to_string((long long)std::max(own[1], all[1])) + " of " +
+                                     std::to_string((unsigned long long)count) + " elements over all ranks)" +
+                                     (pair_bad ? "; so does the reduce-scatter / all-gather pair" : ""));
+  if (pair_bad) c->plain = true;  // in-process switch, same decision on every rank
+  c->selftest = pair_bad ? 2 : 1;
+  if (result) {
+    int path = 0;
+    (void)obhip_comm_exchange_path(c, count, &path, nullptr);
+    result[0] = path;
+  }
   return 0;
 }
 

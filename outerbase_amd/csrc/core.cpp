@@ -220,7 +220,10 @@ int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
       }
       // knots spread too far for the separable exponentials: one exp per knot on the device
       if (!safe) D.kind = D.kind == OBHIP_COV_MAT25 ? 3 : 4;  // kCovMat25Direct / kCovMat25PowDirect
-      table_dims.push_back(safe && ml <= 127 ? (int)l : -1);  // (build_dim_tab bisects in 7 steps)
+      // (build_dim_tab bisects in 7 steps; tables beyond the LDS buffer of k_build_basis are not
+      // built: the knot loop is as fast as gathering them from global memory)
+      const uint64_t tab_doubles = (ml + 1) / 2 * 2 + (ml + 1) * (uint64_t)D.ncol * 6;
+      table_dims.push_back(safe && ml <= 127 && tab_doubles <= (uint64_t)kIntervalTabMax ? (int)l : -1);
     } else {
       table_dims.push_back(-1);
       D.p0 = std::exp(a * hy[0]);  // expLSs, covfuncs.cpp:290
@@ -415,7 +418,7 @@ int device_cus(int device) {
 
 extern "C" {
 
-int obhip_abi_version(void) { return 3; }
+int obhip_abi_version(void) { return 4; }
 
 const char *obhip_last_error(void) { return g_err.c_str(); }
 

@@ -23,6 +23,7 @@ namespace obhip {
 int launch_unpack_form(uint64_t p, const double *d_tri, double *d_H, double e2, const double *d_prec,
                        double *d_diagH);
 std::vector<double> prior_prec_of(const obhip_model &m, const obhip_terms &t, double rho);
+int check_compat_of(const obhip_model *m, const obhip_terms *t);
 }  // namespace obhip
 
 namespace {
@@ -49,7 +50,12 @@ extern "C" {
 
 int obhip_standardise_dev(obhip_comm *comm, const double *d_y_raw, uint64_t n, double *d_y,
                           double *d_meansd) {
-  if (!d_y_raw || !d_y || !d_meansd || n == 0) return fail(OBHIP_ERR_INVALID, "standardise_dev: bad argument");
+  // A rank of a sharded job may hold no rows (fewer rows than ranks, a ragged last shard): it
+  // must still take part in the two sums or its peers wait for ever, so with a communicator
+  // n = 0 is legal and contributes (0, 0) and 0.  Fewer than two rows over ALL ranks give
+  // sd = NaN, as R's sd() does (the count is known on the device only: rejecting it here would
+  // put a host synchronisation into every fit).
+  if (!d_meansd || (n != 0 && (!d_y_raw || !d_y))) return fail(OBHIP_ERR_INVALID, "standardise_dev: null argument");
   OB_TRY(require_device());
   if (!comm && n < 2) return fail(OBHIP_ERR_INVALID, "standardise_dev: the standard deviation needs two rows");
   DevBuf<double> st, red;
@@ -95,8 +101,12 @@ int obhip_fit_newton_sharded_dev(obhip_comm *comm, const obhip_basis *b, const o
                                  uint64_t workspace_bytes) {
   if (!b || !tc || !m || !d_y || !d_H || !d_g || !d_theta || !d_workspace)
     return fail(OBHIP_ERR_INVALID, "fit_newton_sharded_dev: null argument");
+  OB_TRY(require_device());
+  // (knots set, same dimensions, no level beyond the model's knots: term_var below indexes the
+  // model's tables with the terms' levels)
+  OB_TRY(check_compat_of(m, tc));
   obhip_terms &t = *const_cast<obhip_terms *>(tc);
-  if (t.d != m->d || b->model != m) return fail(OBHIP_ERR_INVALID, "fit_newton_sharded_dev: model / terms / basis do not belong together");
+  if (b->model != m) return fail(OBHIP_ERR_INVALID, "fit_newton_sharded_dev: model / terms / basis do not belong together");
   const uint64_t p = t.p;
   uint64_t need = 0;
   obhip_newton_workspace_bytes(p, &need);
@@ -134,18 +144,12 @@ int obhip_fit_newton_sharded_dev(obhip_comm *comm, const obhip_basis *b, const o
   }
   // B^T y: taken along by the staging pass of the design matrix when there is one (its
   // products are the entries of B), by its own pass over the basis otherwise
-  obhip_basis &bw = *const_cast<obhip_basis *>(b);
   double *g_dst = comm ? d_exbuf + tri : d_g;
-  bw.fuse_y = d_y;
-  bw.fuse_g = g_dst;
-  bw.fuse_done = false;
-  const int grc = launch_gram_to(*b, t, sink);
-  const bool g_done = bw.fuse_done;
-  bw.fuse_y = nullptr;
-  bw.fuse_g = nullptr;
-  bw.fuse_done = false;
-  OB_TRY(grc);
-  if (!g_done) OB_TRY(launch_tmm(*b, t, d_y, g_dst, false));
+  GramFuse fuse;
+  fuse.y = d_y;
+  fuse.g = g_dst;
+  OB_TRY(launch_gram_to(*b, t, sink, &fuse));
+  if (!fuse.done) OB_TRY(launch_tmm(*b, t, d_y, g_dst, false));
   if (comm) {
     {
       ProfScope ps("exchange");

@@ -39,7 +39,7 @@ namespace {
 // latency-bound (a chain of bisection steps and table reads per dimension; the next dimension's
 // tables and x values are fetched under it), so the register budget is capped for the five
 // blocks per CU the two 16-KB table buffers allow.
-constexpr int kBbTab = 2048;      // doubles of LDS for one dimension's tables
+constexpr int kBbTab = kIntervalTabMax;  // doubles of LDS for one dimension's tables
 
 __device__ __forceinline__ int bb_tab_size(const DimDesc &D) {
   return ((D.m + 1) & ~1) + (D.m + 1) * D.ncol * 6;

@@ -97,7 +97,7 @@ int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p
 
 int launch_gram_mfma4(const obhip_basis &b, obhip_terms &t, const GramSink &sink);
 bool gram_mfma4_supports(const obhip_terms &t);
-int launch_gram_panel(const obhip_basis &b, obhip_terms &t, const GramSink &sink);
+int launch_gram_panel(const obhip_basis &b, obhip_terms &t, const GramSink &sink, GramFuse *fuse);
 
 // 0 / 4 = staged design matrix (whole or in row chunks), 3 = fused kernel
 static int g_gram_backend = 0;
@@ -110,7 +110,7 @@ int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G) {
   return launch_gram_to(b, t, sink);
 }
 
-int launch_gram_to(const obhip_basis &b, obhip_terms &t, const GramSink &sink) {
+int launch_gram_to(const obhip_basis &b, obhip_terms &t, const GramSink &sink, GramFuse *fuse) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   if (g_gram_backend == 3) {
     if (!gram_mfma4_supports(t))
@@ -118,7 +118,7 @@ int launch_gram_to(const obhip_basis &b, obhip_terms &t, const GramSink &sink) {
                   "fused Gram kernel: terms of at most 8 factors on at most 128 used basis columns");
     return launch_gram_mfma4(b, t, sink);
   }
-  return launch_gram_panel(b, t, sink);
+  return launch_gram_panel(b, t, sink, fuse);
 }
 
 }  // namespace obhip

@@ -36,6 +36,7 @@
 //   operands from two LDS panel buffers [16 rows][272], row-split partials reduced by
 //   k_gram_reduce (kernels_gram.hip).  The same body serves C = A^T Bm for two operands
 //   (launch_atb: row norms for predr_std, stored products for the marginal adjustment).
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -492,15 +493,14 @@ struct RowView {
   }
 };
 
-int materialize_any(const obhip_basis &b, obhip_terms &t, double *d_B) {
+int materialize_any(const obhip_basis &b, obhip_terms &t, double *d_B, GramFuse *fuse = nullptr) {
   if (t.Mu > 280 || getenv("OBHIP_FORCE_GENERIC")) return launch_materialize_generic(b, t, d_B);
   static const bool lane_row = getenv("OBHIP_MATERIALIZE_LANE_ROW") != nullptr;
   if (!lane_row && materialize_tl_supports(t)) {
-    // the fit's B^T y rides along (the caller asked through fuse_y / fuse_g; whole basis only)
-    obhip_basis &bw = const_cast<obhip_basis &>(b);
-    const bool fuse = b.fuse_y && b.fuse_g && !b.fuse_done;
-    OB_TRY(launch_materialize_tl(b, t, d_B, fuse ? b.fuse_y : nullptr, fuse ? b.fuse_g : nullptr));
-    if (fuse) bw.fuse_done = true;
+    // the fit's B^T y rides along (whole basis only: the chunked path passes no request)
+    const bool f = fuse && fuse->y && fuse->g && !fuse->done;
+    OB_TRY(launch_materialize_tl(b, t, d_B, f ? fuse->y : nullptr, f ? fuse->g : nullptr));
+    if (f) fuse->done = true;
     return 0;
   }
   switch (t.W / 2) {
@@ -598,15 +598,15 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
 }  // namespace
 
 // d_B: n_pad x p_pad doubles, row-major (= column-major p_pad x n_pad); padding rows are 0
-int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B) {
+int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B, GramFuse *fuse) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   ProfScope ps("materialize_B");
-  return materialize_any(b, t, d_B);
+  return materialize_any(b, t, d_B, fuse);
 }
 
 // b.bmat = row-major design matrix of (b, t); kept until the basis is rebuilt or other
 // terms need the buffer
-int ensure_bmat(obhip_basis &b, obhip_terms &t) {
+int ensure_bmat(obhip_basis &b, obhip_terms &t, GramFuse *fuse) {
   if (b.bmat_terms == t.uid && t.uid != 0) return 0;
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   if (!gram_panel_supports(b, t))
@@ -614,16 +614,16 @@ int ensure_bmat(obhip_basis &b, obhip_terms &t) {
   const size_t need = (size_t)b.n_pad * t.p_pad;
   if (b.bmat.n < need) OB_TRY(b.bmat.alloc(need));
   b.bmat_terms = 0;
-  OB_TRY(launch_materialize_rows(b, t, b.bmat.p));
+  OB_TRY(launch_materialize_rows(b, t, b.bmat.p, fuse));
   b.bmat_terms = t.uid;
   return 0;
 }
 
-int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, const GramSink &sink) {
+int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, const GramSink &sink, GramFuse *fuse) {
   obhip_basis &b = const_cast<obhip_basis &>(bc);
   const uint64_t ntiles = b.n_pad / kTileRows;
   if (gram_panel_supports(b, t)) {
-    OB_TRY(ensure_bmat(b, t));
+    OB_TRY(ensure_bmat(b, t, fuse));
     return gram_of_staged(b, b.bmat.p, ntiles, t, sink, false, true);
   }
   // Not enough memory for all rows at once: stage and contract row chunks one after the
@@ -665,16 +665,34 @@ int launch_atb(int mode, const double *A, uint64_t ldA, uint64_t M, const double
   const uint64_t mt = M / kGT, nt = N / kGT;
   if (mt >= (1ull << 24) || nt >= (1ull << 24)) return fail(OBHIP_ERR_INVALID, "launch_atb: too many tiles");
   // The task table depends on (mt, nt) only and a predictor asks for the same one at every
-  // var() call: built and uploaded once per device and shape, kept for the life of the process
-  // (no per-call upload, no stream synchronisation for a local buffer).
+  // var() call: built and uploaded once per device and shape and kept (no per-call upload, no
+  // stream synchronisation for a local buffer) -- the kAtbCache most recently used shapes, so
+  // that a long-lived process predicting on ever-changing batch sizes does not grow without
+  // bound (a table is mt * nt * 8 bytes: megabytes at 1e6 rows).  Evicting one waits for the
+  // device, because a launch on any stream may still be reading it; that happens once per
+  // kAtbCache new shapes at most.
+  constexpr size_t kAtbCache = 8;
   static std::mutex mu;
   static std::map<std::tuple<int, uint64_t, uint64_t>, DevBuf<uint64_t> *> cache;
+  static std::vector<std::tuple<int, uint64_t, uint64_t>> lru;  // least recently used first
   int dev = 0;
   (void)hipGetDevice(&dev);
   DevBuf<uint64_t> *dtabp = nullptr;
   {
     std::lock_guard<std::mutex> lk(mu);
-    DevBuf<uint64_t> *&slot = cache[std::make_tuple(dev, mt, nt)];
+    const auto key = std::make_tuple(dev, mt, nt);
+    lru.erase(std::remove(lru.begin(), lru.end(), key), lru.end());
+    lru.push_back(key);
+    if (lru.size() > kAtbCache) {
+      auto it = cache.find(lru.front());
+      if (it != cache.end()) {
+        (void)hipDeviceSynchronize();
+        delete it->second;
+        cache.erase(it);
+      }
+      lru.erase(lru.begin());
+    }
+    DevBuf<uint64_t> *&slot = cache[key];
     if (!slot) {
       // units of up to 8 x 8 tiles, column-tile squares of equal k range together, dealt to the
       // XCD with the fewest blocks so far
@@ -692,7 +710,7 @@ int launch_atb(int mode, const double *A, uint64_t ldA, uint64_t M, const double
       std::vector<uint64_t> tab(len * kXcd, kAtbNoTask);
       for (int k = 0; k < kXcd; ++k)
         for (size_t m = 0; m < seq[k].size(); ++m) tab[m * kXcd + k] = seq[k][m];
-      slot = new DevBuf<uint64_t>();  // never freed: outlives every stream that reads it
+      slot = new DevBuf<uint64_t>();  // freed on eviction only (after a device synchronise)
       const int rc = slot->upload(tab.data(), tab.size());
       if (rc) {
         delete slot;

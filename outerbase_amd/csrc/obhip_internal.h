@@ -259,11 +259,6 @@ struct obhip_basis {
   obhip::DevBuf<double> bmat;   // row-major design matrix [n_pad][p_pad], staging of the
                                 // materialised-B Gram kernel (allocated on first use)
   uint64_t bmat_terms = 0;      // uid of the terms bmat currently holds (0: none)
-  // a fit's request to take B^T y along when the design matrix is staged (set by the caller of
-  // launch_gram_to, cleared by it; fuse_done tells whether the staging pass did it)
-  const double *fuse_y = nullptr;
-  double *fuse_g = nullptr;
-  bool fuse_done = false;
   obhip::DevBuf<uint64_t> gram_pairs;  // XCD-aware (tile pair, row split) task order of that kernel
   int gram_pairs_nb = -1, gram_pairs_ns = -1;
   bool gram_pairs_diag4 = false;
@@ -285,6 +280,10 @@ struct obhip_basis {
 namespace obhip {
 
 constexpr int kTileRows = 64;
+// doubles of LDS k_build_basis has for one dimension's interval tables; ModelDev::build makes
+// tables only for dimensions whose tables fit (larger ones would be per-lane global gathers, no
+// faster than the knot loop, and cost the host O(knots^2 x levels) per hyper-parameter update)
+constexpr int kIntervalTabMax = 2048;
 
 // kernels_basis.hip
 int launch_build_basis(obhip_basis &b);
@@ -319,15 +318,23 @@ struct GramSink {
   const double *prec = nullptr;  // p, device
   double *diagH = nullptr;       // p, device, may be null
 };
+// a fit's request to take g = B^T y along when the design matrix is staged (the staging pass
+// forms every entry of B anyway); `done` tells the caller whether that pass ran and did it --
+// not when the staged matrix of these terms was still valid, nor on the chunked / fused paths
+struct GramFuse {
+  const double *y = nullptr;  // n, device
+  double *g = nullptr;        // p, device
+  bool done = false;
+};
 int launch_gram(const obhip_basis &b, obhip_terms &t, double *d_G);
-int launch_gram_to(const obhip_basis &b, obhip_terms &t, const GramSink &sink);
+int launch_gram_to(const obhip_basis &b, obhip_terms &t, const GramSink &sink, GramFuse *fuse = nullptr);
 int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p, const GramSink &sink,
                        bool accumulate, bool last);
 void set_gram_backend(int b);
 int get_gram_backend();
 // kernels_gram_panel.hip
-int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B);
-int ensure_bmat(obhip_basis &b, obhip_terms &t);  // b.bmat = design matrix of (b, t)
+int launch_materialize_rows(const obhip_basis &b, obhip_terms &t, double *d_B, GramFuse *fuse = nullptr);
+int ensure_bmat(obhip_basis &b, obhip_terms &t, GramFuse *fuse = nullptr);  // b.bmat = design matrix of (b, t)
 bool gram_panel_supports(const obhip_basis &b, const obhip_terms &t);
 // C = A^T Bm on the matrix cores (kernels_gram_panel.hip): mode 1 = row norms of C into
 // out[J * ldo + i] per 128-column tile J, mode 2 = C stored row-major with ldo

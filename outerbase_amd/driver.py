@@ -19,6 +19,8 @@ from . import _lib, obmod
 from ._lib import call
 
 KIND_ID = {"mat25": 0, "mat25pow": 1, "mat25ang": 2}
+EXCHANGE_PATH = {0: "none", 1: "ncclReduceScatter + ncclAllGather (in place)", 2: "ncclAllReduce",
+                 3: "host callback", 4: "sim (buf *= ranks on the device)"}
 DEFAULT_RHO = 6.0  # logpr_gauss.cpp:48
 
 
@@ -47,9 +49,15 @@ def make_comm(rank, world, transport=None):
     """obhip_comm of this process.  transport "rccl": an RCCL communicator of libobhip's own
     (the id drawn by rank 0 travels over torch.distributed, which is the launcher's control
     plane only); "host": sums go through torch.distributed on host memory (gloo) -- the
-    one-GPU rehearsal of the tests.  Default: rccl when torch.distributed runs on nccl."""
+    one-GPU rehearsal of the tests; "sim": `world` virtual ranks that all hold this process's
+    shard, every sum one device pass (timing of a rank's step without the wire).  Default:
+    rccl when torch.distributed runs on nccl."""
     if world == 1:
         return None, None
+    if transport == "sim":
+        h = C.c_void_p()
+        call("obhip_comm_init_sim", C.byref(h), world)
+        return h, None
     import torch
     import torch.distributed as dist
     if transport is None:
@@ -83,7 +91,7 @@ class HotPath:
 
     def __init__(self, kinds, knots_per_dim, p, n, rank=0, world=1, backend="newton",
                  seed_train=42, seed_pred=43, rho=DEFAULT_RHO, cg_tol=1e-10, cg_maxit=None,
-                 row0=None, n_total=None, transport=None):
+                 row0=None, n_total=None, transport=None, rotation=None, terms=None):
         self.kinds = list(kinds)
         self.d = len(kinds)
         self.m = knots_per_dim
@@ -98,6 +106,11 @@ class HotPath:
         self.cg_tol = cg_tol
         self.cg_maxit = cg_maxit
         self.transport = transport
+        # parity runs: (rotmat, basisvar, maxlevel) of another eigensolver to inject into the
+        # model (None: the library's own Jacobi solver), and a term set to use instead of the
+        # model's own selectterms(p)
+        self.rotation = rotation
+        self.terms_in = terms
         self.basis = None
         self.comm = None
         self.cg_iters = None
@@ -113,7 +126,10 @@ class HotPath:
         obmod.setcovfs(om, self.kinds)
         obmod.setknot(om, bench_knots(self.kinds, self.m))
         self.om = om
-        self.terms = om.selectterms(self.p)   # deterministic: identical on every rank
+        if self.rotation is not None:
+            om.set_rotation(*self.rotation)
+        # deterministic: identical on every rank
+        self.terms = om.selectterms(self.p) if self.terms_in is None else np.asarray(self.terms_in)
         self.t = obmod._Terms(om, self.terms)
         self.terms_info = self.t.info()
         self.caps = self.t.maxlevels()
@@ -149,9 +165,44 @@ class HotPath:
         nr, rk, tr, rr, rv = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         call("obhip_comm_info", self.comm, C.byref(nr), C.byref(rk), C.byref(tr), C.byref(rr),
              C.byref(rv))
-        return {"transport": {1: "rccl (reduce-scatter + all-gather)", 2: "host"}[tr.value],
+        path, st = C.c_int(), C.c_int()
+        call("obhip_comm_exchange_path", self.comm, self.ex_count, C.byref(path), C.byref(st))
+        return {"transport": {1: "rccl", 2: "host", 3: "sim (virtual ranks, device pass)"}[tr.value],
+                "path": EXCHANGE_PATH[path.value],
+                "selftest": {0: "not run", 1: "passed", 2: "passed after switching to ncclAllReduce"}[st.value],
                 "ranks": nr.value, "rccl_ranks": rr.value, "rccl_version": rv.value,
                 "bytes_per_fit": 8 * self.ex_count + 24}
+
+    def comm_selftest(self):
+        """obhip_comm_selftest_dev on a buffer of the real exchange size (collective: every rank
+        calls it).  Raises when the transport returns wrong sums; switches the communicator to
+        the plain all-reduce in-process when only the reduce-scatter / all-gather pair does."""
+        if self.comm is None:
+            return None
+        res = (C.c_int64 * 4)()
+        call("obhip_comm_selftest_dev", self.comm, self.ex_count, C.cast(res, C.c_void_p))
+        return {"elements": int(self.ex_count), "path_in_use": EXCHANGE_PATH[int(res[0])],
+                "pair_mismatches": int(res[1]), "allreduce_mismatches": int(res[2]),
+                "switched_to_allreduce": bool(res[3])}
+
+    def newton_residual_rel(self):
+        """|| H theta - e^{-2 sigma} B^T y || / || e^{-2 sigma} B^T y || with H applied
+        MATRIX-FREE (k_mm_tl, k_tmm_tl summed over the ranks through the communicator):
+        independent of the Gram and Cholesky kernels.  Collective: every rank calls it."""
+        torch = self.torch
+        e2 = math.exp(-2 * self.sigma)
+        tmp = torch.empty(self.n, dtype=torch.float64, device=self.x.device)
+        hv = torch.empty(self.p, dtype=torch.float64, device=self.x.device)
+        call("obhip_basis_mm_dev", self.basis, self.t._h, self.theta.data_ptr(), tmp.data_ptr(), 0)
+        call("obhip_basis_tmm_dev", self.basis, self.t._h, tmp.data_ptr(), hv.data_ptr(), 0)
+        if self.comm is not None:
+            call("obhip_comm_allreduce_dev", self.comm, hv.data_ptr(), self.p)
+        torch.cuda.synchronize()
+        theta = self.theta.cpu().numpy()
+        prec = 1.0 / (self.om.getvar(self.terms) * math.exp(2 * self.rho))
+        lhs = e2 * hv.cpu().numpy() + prec * theta
+        rhs = e2 * self.g.cpu().numpy()
+        return float(np.linalg.norm(lhs - rhs) / np.linalg.norm(rhs))
 
     def setup_inputs(self):
         """(Re)generate this rank's rows of the synthetic stream in HBM."""

@@ -156,7 +156,7 @@ def test_bench_self_launch_two_ranks(tmp_path):
     import json
     bench = os.path.join(ROOT, "bench.py")
     base = [sys.executable, bench, "--rows", "200000", "--steps", "2", "--warmup", "1",
-            "--no-cpu-baseline", "--no-config3"]
+            "--no-cpu-baseline", "--no-config3", "--no-configs", "--fit-parity-rows", "6000"]
     env = dict(os.environ, OBHIP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
@@ -169,9 +169,20 @@ def test_bench_self_launch_two_ranks(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert line["exchange"]["ranks"] == 2 and line["exchange"]["transport"] == "host"
+    # the first contact with the transport verified itself before the warm-up
+    st = line["exchange"]["selftest_result"]
+    assert line["exchange"]["selftest"] == "passed" and st["allreduce_mismatches"] == 0
+    assert st["elements"] * 8 + 24 == line["exchange"]["bytes_per_fit"]
+    # parity of the 2-rank run itself: rank 0's predictions against the oracle's basis, Newton
+    # stationarity with the matrix-free products summed through the communicator, and the
+    # oracle's own fit on the first rows (sharded over both ranks) with nothing shared
+    pc = line["parity_check"]
+    assert pc["predict_max_rel_err"] < 1e-6 and pc["newton_residual_rel"] < 1e-10
+    assert pc["theta_vs_oracle_rows"] < 1e-6 and pc["fit_vs_oracle"]["shared_rotation"]["predict_max_rel_err"] < 1e-6
+    assert pc["fit_vs_oracle"]["terms_equal_oracle_selection"]
     assert line["config"]["rows_total"] == 200000 and line["config"]["rows_per_gpu"] == 100000
     assert line["value"] > 0 and line["alt_backend"]["max_rel_diff_of_predictions_vs_newton"] < 1e-6
-    r1 = subprocess.run(base + ["--gpus", "1", "--no-alt-backend", "--dump", d1], env=env,
+    r1 = subprocess.run(base + ["--gpus", "1", "--no-alt-backend", "--no-fit-parity", "--dump", d1], env=env,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r1.returncode == 0, r1.stderr.decode(errors="replace")[-3000:]
     two, one = np.load(d2), np.load(d1)

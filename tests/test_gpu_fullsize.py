@@ -28,8 +28,8 @@ def _vec(torch, n):
 
 
 def test_standardised_targets(hot):
-    # standardised over all rows with the one-pass sums the exchange buffer carries
-    # (sum y, sum y^2, n): exact up to eps (1 + mean^2 / var) and the summation order
+    # standardised over all rows by obhip_standardise_dev: two passes like R's sd() -- the mean
+    # from (sum y, n), then the centred sum of squares (24 bytes cross the ranks)
     y = hot.standardised_targets().cpu().numpy()
     assert abs(y.mean()) < 1e-12
     assert abs(y.var(ddof=1) - 1.0) < 1e-11

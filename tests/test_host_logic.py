@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, "declared in include/obhip.h but not exported: %s" % missing
     extra = sorted(s for s in exported if s.startswith("obhip_") and s not in protos)
     assert not extra, "exported but not declared: %s" % extra
-    assert _lib.lib.obhip_abi_version() == 3
+    assert _lib.lib.obhip_abi_version() == 4
 
 
 def test_header_cites_reference_for_every_entry_point():
@@ -333,3 +333,27 @@ def test_glue_covers_the_reference_module_surface():
     assert set(rc) == set(gc)
     for cls, names in rc.items():
         assert names <= gc[cls], (cls, sorted(names - gc[cls]))
+
+
+def test_glue_passes_the_compilers_front_end():
+    """glue/obhip_glue.cpp through g++'s parser and type checker against include/obhip.h and a
+    declaration-only stand-in for <Rcpp.h> (tests/rcpp_stub/Rcpp.h: test infrastructure -- R and
+    Rcpp are not in this image).  Catches misspelt or mis-typed ABI calls and malformed module
+    declarations; it says nothing about Rcpp's real semantics and nothing is linked."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [gxx, "-std=c++11", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "tests", "rcpp_stub"),
+           "-I" + os.path.join(root, "include"), os.path.join(root, "glue", "obhip_glue.cpp")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-4000:]
+    # the check is live: a call with a wrong argument list must be rejected
+    src = open(os.path.join(root, "glue", "obhip_glue.cpp")).read()
+    broken = src.replace("ck(obhip_basis_rebuild(h));", "ck(obhip_basis_rebuild(h, 1));", 1)
+    assert broken != src
+    r = subprocess.run(cmd[:-1] + ["-x", "c++", "-"], input=broken.encode(), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    assert r.returncode != 0 and b"obhip_basis_rebuild" in r.stdout
