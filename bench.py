@@ -157,7 +157,8 @@ def fit_vs_oracle(HotPath, shard_rows, kinds, knots, p, rows, rank, world, trans
                           theta=h.theta.cpu().numpy(), cent=h.y_cent, sca=h.y_sca,
                           H_upper=None, diagH=h.diagH.cpu().numpy())
         if rank == 0:
-            # strict upper triangle of H (the Cholesky factor overwrote the lower one)
+            # H above its diagonal 128 x 128 blocks (the Cholesky factor overwrote the lower
+            # triangle and those blocks); the diagonal of H is kept aside by the fit
             runs[name]["H_upper"] = h.G.cpu().numpy()
         h.close()
         del h
@@ -175,13 +176,14 @@ def fit_vs_oracle(HotPath, shard_rows, kinds, knots, p, rows, rank, world, trans
     xnew, _ = O.synth_xy(43, 0, k, kinds)
     want = cent + sca * O.predict_mean(om, terms, theta_o, xnew)
     out["oracle_seconds"] = time.perf_counter() - t0
-    iu = np.triu_indices(p, 1)
+    blk = np.arange(p) // 128
+    iu = np.nonzero(blk[None, :] > blk[:, None])
     for name, r in runs.items():
         e = {"predict_max_rel_err": float(np.max(np.abs(r["mean"] - want)) / np.max(np.abs(want)))}
         if name == "shared_rotation" or out["terms_equal_between_eigensolvers"]:
             e["hessian_max_rel_err"] = float(max(
-                np.max(np.abs(r["H_upper"][iu] - H_o[iu])), np.max(np.abs(r["diagH"] - np.diag(H_o))))
-                / np.max(np.abs(H_o)))
+                np.max(np.abs(r["H_upper"][iu] - H_o[iu])) if len(iu[0]) else 0.0,
+                np.max(np.abs(r["diagH"] - np.diag(H_o)))) / np.max(np.abs(H_o)))
             e["theta_max_rel_err"] = float(np.max(np.abs(r["theta"] - theta_o)) / np.max(np.abs(theta_o)))
         out[name] = e
     # the figure the tier asks for: device fit + predict vs the reference path's restatement on

@@ -1,0 +1,238 @@
+// B^T (c_a B a + c_b y) in ONE pass over the basis, second generation (k_hm2).
+//
+// The Hessian product of the PCG (loglik_gauss::hessmult, src/lpdfs/loglik_gauss.cpp:137-145:
+// B^T (B p)) and the gradient pass of its update() (loglik_gauss.cpp:117-125: yhat = B theta,
+// B^T (e^{-2 sigma} (y - yhat))), which lpdf::optcg (src/fit.cpp:71-85) calls once per
+// iteration each.  Same algebra as k_hm_tl (kernels_prod.hip): a block holds ALL terms
+// (lane = term, NU terms per lane), takes a 64-row tile in sub-chunks of 4 rows, keeps the
+// NU x 4 term products of a sub-chunk in registers,
+//   1. prod[u][r] by the hand-issued LDS read pipeline (TlPipe), s[r] += a_u prod[u][r];
+//   2. s[r] over the 64 lanes (permlane swaps + DPP) and, through LDS and one s_barrier, over
+//      the waves: tot_r = sum_k a_k prod_k(row r);
+//   3. w_r = c_a s_r^2 tot_r + c_b s_r y_r,  acc[u] += prod[u][r] w_r.
+// What round 3's profile showed (LdsUtil 39 %, VALUBusy 55 % at two waves per SIMD, 50-84
+// spilled VGPRs): the product phase was bound by the few LDS reads a wave can keep in flight,
+// not by the LDS pipe, and every sub-chunk ended in a chain of LDS-pipe round trips
+// (ds_bpermute shuffles) behind the barrier.  Changes here:
+//   * the next tile is prefetched by LDS-direct loads (global_load_lds_dword: 256 contiguous
+//     bytes per wave instruction, two per column at the conflict-free pitch of 65 doubles) into
+//     a SECOND tile buffer -- no prefetch registers (32 VGPRs in k_hm_tl), no staging ds_writes;
+//   * the register budget that frees goes into occupancy: 16 waves x 4 terms per lane at
+//     <= 128 VGPRs (four waves per SIMD, 12 reads in flight each) instead of 8 waves x 8 terms;
+//   * the row weights vA = c_a s^2, vB = c_b s y live in LDS (written once per tile), so the
+//     post-barrier phase is one LDS read of the wave partials, DPP / permlane adds and
+//     v_readlane -- no ds_bpermute.
+// Limits: terms of at most 4 factors (W2 <= 2), p_pad <= WAVES * NU * 64, two tiles of the used
+// columns in LDS (Mu <= 147); anything else takes k_hm_tl or the two-kernel form.
+#include "obhip_internal.h"
+#include "device_common.h"
+
+namespace obhip {
+
+namespace {
+
+constexpr int kHm2Chunk = 4;
+constexpr int kHm2RedSlots = 64;  // [16 waves][4 rows] partial sums of one sub-chunk
+
+template <int W, int NU>
+struct Hm2Ctx {
+  uint32_t ad[NU][W];
+  double av[NU];
+  double acc[NU];
+  double prod[NU][kHm2Chunk];
+  double s[kHm2Chunk];
+  template <int RR>
+  __device__ __forceinline__ void row() {}
+  template <int RR, int UNIT>
+  __device__ __forceinline__ void use(double v) {
+    prod[UNIT][RR] = v;
+    s[RR] = fma(v, av[UNIT], s[RR]);
+  }
+};
+
+// one wave instruction pair: the 512 bytes of a basis column (64 rows) from g to LDS at l
+// (lane l: dword at g + 4 l -> LDS l + 4 l, then the same 256 bytes on)
+__device__ __forceinline__ void hm2_dma_col(const char *g /* uniform */, uint32_t voff /* 4 lane */,
+                                            uint32_t l /* uniform */) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\t"
+               "global_load_lds_dword %0, %1 offset:256"
+               :: "v"(voff), "s"(g), "s"(l) : "memory");
+}
+
+// one sub-chunk of 4 rows (tile rows rc .. rc + 3; the addresses in c.ad point ROW0 rows before)
+template <int W, int NU, int ROW0, int INFL, bool RO>
+__device__ __forceinline__ void hm2_subchunk(Hm2Ctx<W, NU> &c, bool live, int wea, int web, double *red_half,
+                                             const double *wts /* [2][64] of this tile */, int wave, int lane,
+                                             int rc, double &totrow) {
+#pragma unroll
+  for (int r = 0; r < kHm2Chunk; ++r) c.s[r] = 0.0;
+  if (live) {
+    if constexpr (NU == 1) {
+      tl_run_half<W, 1, kHm2Chunk, INFL, 0, ROW0>(c, wea);
+    } else {
+      tl_run_half<W, NU / 2, kHm2Chunk, INFL, 0, ROW0>(c, wea);
+      tl_run_half<W, NU - NU / 2, kHm2Chunk, INFL, NU / 2, ROW0>(c, web);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int r = 0; r < kHm2Chunk; ++r) c.prod[u][r] = 0.0;
+  }
+  // the row weights of the 4 rows (independent of the sums: issued ahead of the barrier)
+  const double vA = wts[rc + (lane & 3)];
+  double vB = 0.0;
+  if (RO) vB = wts[64 + rc + (lane & 3)];
+  // s[0..3] over the 64 lanes: 16-lane row q ends with the sum of s[q]
+  static_assert(kHm2Chunk == 4, "the butterfly below reduces 4 rows");
+  double v = swap16_sum(swap32_sum(c.s[0], c.s[2]), swap32_sum(c.s[1], c.s[3]));
+  v = row16_ror_add<8>(v);
+  v = row16_ror_add<4>(v);
+  v = row16_ror_add<2>(v);
+  v = row16_ror_add<1>(v);
+  if ((lane & 15) == 0) red_half[wave * kHm2Chunk + (lane >> 4)] = v;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (not vmcnt: the next tile's loads stay in flight)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // over the waves: lane l reads the partial of wave l / 4, row l % 4 (slots of absent waves are
+  // zero); afterwards EVERY lane l holds tot of row l % 4
+  double t = red_half[lane];
+  t = row16_ror_add<4>(t);
+  t = row16_ror_add<8>(t);
+  t = swap16_sum(t, t);
+  t = swap32_sum(t, t);
+  const double wl = RO ? fma(vA, t, vB) : vA * t;
+  if (RO && (lane & ~3) == rc) totrow = t;  // lane = row keeps sum_k a_k prod_k of its row
+#pragma unroll
+  for (int r = 0; r < kHm2Chunk; ++r) {
+    const double wv = readlane_f64(wl, r);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) c.acc[u] = fma(c.prod[u][r], wv, c.acc[u]);
+  }
+}
+
+// RO: the update() form (y, yhat, sum of squared residuals); without it the Hessian product
+template <int W2, int NU, int WAVES, int INFL, bool RO>
+__global__ void __launch_bounds__(WAVES * 64, LBW)
+k_hm2(const double *__restrict__ bm, const double *__restrict__ scale, const uint32_t *__restrict__ ucol,
+      int Mu, uint64_t Mc, const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm,
+      const double *__restrict__ a, int p, const double *__restrict__ y, double ca, double cb, uint64_t n,
+      uint64_t ntiles, uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ part,
+      double *__restrict__ yhat, double *__restrict__ sspart) {
+  extern __shared__ double lds[];
+  constexpr int W = 2 * W2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile_doubles = Mu * kTlPitch;
+  double *wts = lds + 2 * (size_t)tile_doubles;  // [2 buffers][vA 64 | vB 64]
+  double *red = wts + 2 * 128;                    // [2 halves][16 waves][4 rows]
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
+  const uint32_t tile_bytes = (uint32_t)tile_doubles * 8u;
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+
+  Hm2Ctx<W, NU> c;
+  int nza = 1, nzb = 1;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const uint64_t slot = tl_slot<NU>(0, wave, u, lane);
+    const bool ok = slot < p_pad;
+    const uint64_t k = ok ? sperm[slot] : 0;
+    c.acc[u] = 0.0;
+    c.av[u] = ok && k < (uint64_t)p ? a[k] : 0.0;
+    uint32_t cw[W2];
+#pragma unroll
+    for (int w = 0; w < W2; ++w) {
+      cw[w] = ok ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+      c.ad[u][2 * w] = lds0 + (cw[w] & 0xffffu) * (kTlPitch * 8);
+      c.ad[u][2 * w + 1] = lds0 + (cw[w] >> 16) * (kTlPitch * 8);
+    }
+    if (NU == 1 || u < NU / 2)
+      nza = max(nza, tl_nnz<W2>(cw));
+    else
+      nzb = max(nzb, tl_nnz<W2>(cw));
+  }
+  const int wea = tl_variant<W>(wave_max_i32(nza)), web = tl_variant<W>(wave_max_i32(nzb));
+  const bool live = ((uint64_t)wave * NU) * 64 < p_pad;  // (whole waves beyond p_pad: zeros)
+  if (threadIdx.x < 2 * kHm2RedSlots) red[threadIdx.x] = 0.0;  // slots of absent waves stay zero
+
+  // next tile -> the other buffer, by LDS-direct loads; the last wave also fetches the row weights
+  // (scale and y are requested BEFORE the LDS-direct loads and only used at the top of the next
+  // tile: the compiler's own vmcnt bookkeeping does not see the inline-asm loads, so a use right
+  // here would wait for all of them)
+  double scn = 0.0, yn = 0.0;
+  auto prefetch = [&](uint64_t tile, int bsel) {
+    if (wave == WAVES - 1) {
+      const uint64_t row = tile * kTileRows + lane;
+      scn = yn = 0.0;
+      if (row < n) {
+        scn = scale[row];
+        if (RO) yn = y[row];
+      }
+    }
+    const char *tb = (const char *)(bm + tile * Mc * kTileRows);
+    const uint32_t l0 = lds0 + (bsel ? tile_bytes : 0u);
+    for (int u = wave; u < Mu; u += WAVES) {
+      const uint32_t col = __builtin_amdgcn_readfirstlane(ucol[u]);
+      hm2_dma_col(tb + (size_t)col * (kTileRows * 8), (uint32_t)lane * 4u, l0 + (uint32_t)u * (kTlPitch * 8));
+    }
+  };
+  if (t0 < t1) prefetch(t0, 0);
+  double ssacc = 0.0;  // wave 0: sum over its rows of (yhat - y)^2
+
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    const int bsel = (int)((tile - t0) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed
+    if (wave == WAVES - 1) {  // per row (lane = row): vA = c_a s^2, vB = c_b s y  ->  w = vA tot + vB
+      wts[bsel * 128 + lane] = ca * scn * scn;
+      if (RO) wts[bsel * 128 + 64 + lane] = cb * scn * yn;
+    }
+    __syncthreads();  // tile and weights complete; every wave is done with the other buffer
+    if (tile + 1 < t1) prefetch(tile + 1, bsel ^ 1);
+    const double *wt = wts + bsel * 128;
+    double totrow = 0.0;  // lane = row: sum_k a_k prod_k of this tile's row
+#pragma unroll 1
+    for (int rc = 0; rc < kTileRows; rc += 2 * kHm2Chunk) {
+      // two sub-chunks per address update: the second reads at immediate row offsets 4 .. 7;
+      // the cross-wave sums alternate between the two halves of red
+      hm2_subchunk<W, NU, 0, INFL, RO>(c, live, wea, web, red, wt, wave, lane, rc, totrow);
+      hm2_subchunk<W, NU, kHm2Chunk, INFL, RO>(c, live, wea, web, red + kHm2RedSlots, wt, wave, lane,
+                                               rc + kHm2Chunk, totrow);
+      // next 8 rows; after the last ones: row 0 of the other buffer
+      const int32_t step = rc + 2 * kHm2Chunk < kTileRows
+                               ? 2 * kHm2Chunk * 8
+                               : -(kTileRows - 2 * kHm2Chunk) * 8 + (bsel ? -(int32_t)tile_bytes : (int32_t)tile_bytes);
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          c.ad[u][j] += (uint32_t)step;
+          asm volatile("" : "+v"(c.ad[u][j]));
+        }
+    }
+    if (RO && wave == 0) {
+      const uint64_t row = tile * kTileRows + lane;
+      if (row < n) {
+        const double yh = scale[row] * totrow;
+        if (yhat != nullptr) yhat[row] = yh;
+        const double dlt = yh - y[row];
+        ssacc = fma(dlt, dlt, ssacc);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const uint64_t slot = tl_slot<NU>(0, wave, u, lane);
+    if (slot < p_pad) part[(uint64_t)blockIdx.x * p_pad + sperm[slot]] = c.acc[u];
+  }
+  if (RO && wave == 0 && sspart != nullptr) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ssacc += __shfl_xor(ssacc, off, 64);
+    if (lane == 0) sspart[blockIdx.x] = ssacc;
+  }
+}
+
+
+template __global__ void k_hm2<2, 4, 8, INFLX, false>(const double *, const double *, const uint32_t *, int, uint64_t, const uint32_t *, const uint32_t *, const double *, int, const double *, double, double, uint64_t, uint64_t, uint64_t, uint64_t, double *, double *, double *);
+}
+}

@@ -1336,15 +1336,27 @@ int run_hm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, const dou
   return run_hm_tl2<W2, NU, false, false>(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, nsplit, ntiles, tps, lds);
 }
 
+// kernels_hm.hip: the second-generation kernel (two tile buffers fed by LDS-direct loads, four
+// waves per SIMD) and the terms it takes
+bool hm2_supports(const obhip_terms &t);
+int launch_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,
+               double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
+               uint64_t tps, int variant);
+
 int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y,
                           double ca, double cb, double *d_out, double *d_yhat, double *d_ss) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   static const bool off = getenv("OBHIP_HESSMULT_FUSED") && atoi(getenv("OBHIP_HESSMULT_FUSED")) == 0;
+  // OBHIP_HM_V1=1: the round-3 kernel (A/B runs); OBHIP_HM2_VARIANT: block shapes of k_hm2
+  static const bool v1 = getenv("OBHIP_HM_V1") && atoi(getenv("OBHIP_HM_V1")) != 0;
+  static const int variant = getenv("OBHIP_HM2_VARIANT") ? atoi(getenv("OBHIP_HM2_VARIANT")) : 0;
   const int w2 = (int)(t.W / 2);
+  const bool use2 = !off && !v1 && !beyond_lds(t) && hm2_supports(t);
   // (8 terms of 6 factors per lane spill and run at half the speed of the two-kernel form: measured)
   const int numax = w2 <= 2 ? 8 : 4;
-  if (off || beyond_lds(t) || w2 < 1 || w2 > kMaxW2 || t.p_pad > (uint64_t)kTlWaves * numax * 64 ||
-      (t.Mu * kTlPitch + 2 * kTlWaves * kHmChunk) * sizeof(double) > 156 * 1024)
+  if (!use2 &&
+      (off || beyond_lds(t) || w2 < 1 || w2 > kMaxW2 || t.p_pad > (uint64_t)kTlWaves * numax * 64 ||
+       (t.Mu * kTlPitch + 2 * kTlWaves * kHmChunk) * sizeof(double) > 156 * 1024))
     return kNotFused;
   int nu = 1;
   while ((uint64_t)kTlWaves * nu * 64 < t.p_pad) nu *= 2;
@@ -1358,7 +1370,10 @@ int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_
   OB_TRY(const_cast<obhip_basis &>(b).workspace((nsplit * t.p_pad + nsplit) * sizeof(double), (void **)&part));
   if ((d_yhat || d_ss) && !d_y) return fail(OBHIP_ERR_INVALID, "hessmult: yhat / residual sum need y");
   double *sspart = d_ss ? part + nsplit * t.p_pad : nullptr;
-  {
+  if (use2) {
+    ProfScope ps("hessmult");
+    OB_TRY(launch_hm2(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps, variant));
+  } else {
     ProfScope ps("hessmult");
 #define OB_HM(W2_, NU_) OB_TRY((run_hm_tl<W2_, NU_>(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps))); break
     switch (w2 * 16 + nu) {

@@ -74,11 +74,14 @@ def test_headline_terms_fit_matches_oracle(case, rotation):
         assert abs(hp.y_cent - o["cent"]) < 1e-12 * abs(o["cent"]) and abs(hp.y_sca - o["sca"]) < 1e-12 * o["sca"]
         mean = hp.mean[:PRED_ROWS].cpu().numpy()
         err_mean = relerr(mean, o["mean"])
-        # H = e^{-2 sigma} B^T B + prior: strict upper triangle of the row-major buffer (the
-        # Cholesky factor overwrote the lower one) and the diagonal kept aside
+        # H = e^{-2 sigma} B^T B + prior as the fit formed it: the Cholesky factor overwrote the
+        # lower triangle AND the diagonal 128 x 128 blocks of the row-major buffer (its trailing
+        # updates work on whole tiles), so H is compared on the blocks strictly above those
+        # (97 % of the upper triangle at p = 4096) and on its diagonal, which the fit keeps aside
         Hd = hp.G.cpu().numpy()
-        iu = np.triu_indices(p, 1)
-        err_H = max(np.max(np.abs(Hd[iu] - o["H"][iu])),
+        blk = np.arange(p) // 128
+        above = blk[None, :] > blk[:, None]
+        err_H = max(np.max(np.abs(Hd - o["H"])[above]) if above.any() else 0.0,
                     np.max(np.abs(hp.diagH.cpu().numpy() - np.diag(o["H"])))) / np.max(np.abs(o["H"]))
         err_theta = relerr(hp.theta.cpu().numpy(), o["theta"])
         print("%s / %s rotation: predictions %.3g, H %.3g, theta %.3g (relative, max norm)"
