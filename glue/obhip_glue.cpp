@@ -7,7 +7,9 @@
 //
 // Built by R CMD INSTALL with the Makevars shown in INTEGRATION.md (needs Rcpp only: no
 // RcppArmadillo, no OpenMP).  R, Rcpp and RcppArmadillo are not in the image this repository
-// is developed in, so this file has not been compiled there; tests/cabi_smoke.c exercises
+// is developed in, so this file has not been built against Rcpp there (its syntax and its calls
+// into the ABI are checked by g++ -fsyntax-only against a declaration-only stand-in for
+// <Rcpp.h>, tests/rcpp_stub/Rcpp.h -- test infrastructure); tests/cabi_smoke.c exercises
 // the same sequence of ABI calls from plain C, and outerbase_amd/obmod.py is the same mapping
 // over ctypes, which the test-suite runs.
 //

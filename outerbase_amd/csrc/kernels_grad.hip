@@ -128,12 +128,147 @@ __device__ __forceinline__ double build_dim_grad(const DimDesc &D, const GradHyp
   return cl;
 }
 
+// ---- interval tables of the gradient basis (mat25 / mat25pow) -------------------------------
+// The same algebra as the value path's tables (device_common.h build_dim_tab, core.cpp): between
+// two neighbouring knots every per-knot quantity of build_dim_grad is e^{-h} (below) or e^{-ah}
+// (above) times a polynomial of degree <= 3 in h = u(x) - u_j:
+//   kv = (1 + |h| + h^2 / 3) e            cov                       covfuncs.cpp:121-124
+//   d0 = (a / 3) h^2 (1 + |h|) e          d cov / d hyp_0           covfuncs.cpp:134-150
+//   d1 = -(b pw / 3) (L - kd_j) h (1 + |h|) e + (b / 3) h^2 (1 + |h|) e   (mat25pow, :220-243;
+//        L = log(x) t(x) is a per-row scalar, kd_j = log(knot_j) t(knot_j))
+// so with t = u(x) - (the largest u_j <= u(x)) the three knot sums per level are
+//   r  = e^{-t} V-(t) + e^{t} V+(t)
+//   t0 = e^{-t} C(t)  + e^{t} D(t)
+//   t1 = e^{-t} (E(t) + L P(t)) + e^{t} (F(t) + L Q(t))
+// with 6 + 8 (+ 8 + 6) host-built coefficients per (interval, level) (build_grad_tab below) -- O(1)
+// per (row, level) where the knot loop spends ~45 instructions per (row, knot, 8 levels).
+struct GradTab {
+  int off;  // offset (doubles) of the dimension's table in the table array, -1: knot loop
+  int nc;   // coefficients per (interval, level): 14 (mat25) or 28 (mat25pow)
+  int size; // doubles
+};
+constexpr int kGradTabMax = 16384;  // doubles of LDS for one dimension's table (128 KB)
+
+// a row's place in a dimension's table: interval, local variable, the two exponentials, L
+struct GradRow {
+  int J;
+  double t, em, ep, L;
+};
+template <int KIND>
+__device__ __forceinline__ GradRow grad_row(const DimDesc &D, const double *__restrict__ tab, double xv) {
+  constexpr bool POW = KIND == OBHIP_COV_MAT25POW;
+  const double ux = (POW ? pow(xv, D.p0) / D.p1 : xv / D.p0) - D.p2;
+  int lo = 0, hi = D.m;  // u_(lo-1) <= ux < u_(hi)
+  for (int it = 0; it < 7; ++it) {  // m <= 127
+    const int mid = (lo + hi) >> 1;
+    const bool open = lo < hi;
+    const bool le = tab[min(mid, D.m - 1)] <= ux;
+    lo = open && le ? mid + 1 : lo;
+    hi = open && !le ? mid : hi;
+  }
+  GradRow g;
+  g.J = lo;
+  g.t = ux - tab[max(g.J - 1, 0)];
+  g.em = g.J == 0 ? 0.0 : exp(-g.t);
+  g.ep = g.J == D.m ? 0.0 : exp(g.t);
+  g.L = POW ? log(xv) * (ux + D.p2) : 0.0;
+  return g;
+}
+template <int KIND>
+__device__ __forceinline__ double build_dim_grad_tab(const DimDesc &D, const GradHyp *__restrict__ hy,
+                                                     const double *__restrict__ tab, const GradRow &g,
+                                                     double *__restrict__ tile_out) {
+  constexpr bool POW = KIND == OBHIP_COV_MAT25POW;
+  constexpr int NC = POW ? 28 : 14;
+  typedef double dd2 __attribute__((ext_vector_type(2)));
+  const double t = g.t, em = g.em, ep = g.ep, L = g.L;
+  const dd2 *__restrict__ cf = (const dd2 *)(tab + ((D.m + 1) & ~1) + (size_t)g.J * D.ncol * NC);
+  double icl = 1.0, cl = 1.0, g00 = 0.0, g10 = 0.0;
+#pragma unroll 1
+  for (int c = 0; c < D.ncol; ++c) {
+    const dd2 *e = cf + c * (NC / 2);
+    const dd2 v0 = e[0], v1 = e[1], v2 = e[2];           // V-0 V-1 | V-2 V+0 | V+1 V+2
+    const dd2 c0 = e[3], c1 = e[4], d0 = e[5], d1 = e[6];  // C0 C1 | C2 C3 | D0 D1 | D2 D3
+    const double r = em * fma(t, fma(t, v1.x, v0.y), v0.x) + ep * fma(t, fma(t, v2.y, v2.x), v1.y);
+    const double s0 = em * fma(t, fma(t, fma(t, c1.y, c1.x), c0.y), c0.x) +
+                      ep * fma(t, fma(t, fma(t, d1.y, d1.x), d0.y), d0.x);
+    double s1 = 0.0;
+    if (POW) {
+      const dd2 e0 = e[7], e1 = e[8], f0 = e[9], f1 = e[10];  // E0 E1 | E2 E3 | F0 F1 | F2 F3
+      const dd2 p0 = e[11], pq = e[12], q1 = e[13];            // P0 P1 | P2 Q0 | Q1 Q2
+      const double lo_ = fma(t, fma(t, fma(t, e1.y, e1.x), e0.y), e0.x) + L * fma(t, fma(t, pq.x, p0.y), p0.x);
+      const double hi_ = fma(t, fma(t, fma(t, f1.y, f1.x), f0.y), f0.x) + L * fma(t, fma(t, q1.y, q1.x), pq.y);
+      s1 = em * lo_ + ep * hi_;
+    }
+    if (c == 0) {
+      cl = r;
+      icl = 1.0 / r;
+      g00 = s0 * icl;
+      g10 = s1 * icl;
+    }
+    const double bv = r * icl, ge0 = s0 * icl, ge1 = s1 * icl;
+    tile_out[(size_t)(hy[0].gecol + c) * kTileRows] = ge0;
+    if (POW) tile_out[(size_t)(hy[1].gecol + c) * kTileRows] = ge1;
+    if (c >= 1) {
+      tile_out[(size_t)(D.ccol0 + c - 1) * kTileRows] = bv;
+      tile_out[(size_t)(hy[0].dcol + c - 1) * kTileRows] = fma(-bv, g00, ge0);
+      if (POW) tile_out[(size_t)(hy[1].dcol + c - 1) * kTileRows] = fma(-bv, g10, ge1);
+    }
+  }
+  return cl;
+}
+
+// 16 waves = 16 row tiles per block; all waves walk the dimensions that have a table together,
+// a dimension's table staged in LDS once per block.  Dimensions without a table (mat25ang, out-of-range
+// hyper-parameters, tables beyond the LDS buffer) are left to k_build_basis_grad, which then ran
+// BEFORE this kernel on those dimensions alone (scale_has_part: scale holds their product).
+__global__ void __launch_bounds__(1024)
+k_build_basis_grad_tab(const DimDesc *__restrict__ dims, const GradHyp *__restrict__ hyps,
+                       const int *__restrict__ hypst, const GradTab *__restrict__ gtabs,
+                       const double *__restrict__ gtab, const double *__restrict__ x, uint64_t n, int d,
+                       uint64_t Mtot, uint64_t ntiles, int scale_has_part, double *__restrict__ bm,
+                       double *__restrict__ scale) {
+  extern __shared__ double ltab[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t tile = (uint64_t)blockIdx.x * 16 + wave;
+  const bool mine = tile < ntiles;  // (wave-uniform)
+  const uint64_t row = tile * kTileRows + lane;
+  const bool valid = mine && row < n;
+  double *tile_out = bm + tile * Mtot * kTileRows + lane;
+  double sc = 1.0;
+  for (int l = 0; l < d; ++l) {
+    const GradTab T = gtabs[l];
+    if (T.off < 0) continue;  // (block-uniform)
+    const DimDesc D = dims[l];
+    // the dimension's table: 16 waves x 1800 clocks of LDS-bound evaluation follow, so the ~1 us the
+    // copy is exposed for is ~10 % (prefetching it through registers made the kernel spill)
+    __syncthreads();  // everyone is done with the previous dimension's table
+    for (int e = threadIdx.x; e < T.size; e += 1024) ltab[e] = gtab[T.off + e];
+    __syncthreads();
+    if (mine) {
+      const GradHyp *hy = hyps + hypst[l];
+      const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
+      if (D.kind == OBHIP_COV_MAT25)
+        sc *= build_dim_grad_tab<OBHIP_COV_MAT25>(D, hy, ltab, grad_row<OBHIP_COV_MAT25>(D, ltab, xv), tile_out);
+      else
+        sc *= build_dim_grad_tab<OBHIP_COV_MAT25POW>(D, hy, ltab, grad_row<OBHIP_COV_MAT25POW>(D, ltab, xv), tile_out);
+    }
+  }
+  if (mine) {
+    tile_out[0] = 1.0;
+    if (scale_has_part) sc *= scale[row];
+    scale[row] = valid ? sc : 0.0;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_build_basis_grad(const DimDesc *__restrict__ dims, const GradHyp *__restrict__ hyps,
                    const int *__restrict__ hypst, const double *__restrict__ ka,
                    const double *__restrict__ kb, const double *__restrict__ kd,
                    const double *__restrict__ rot, const double *__restrict__ rotg,
                    const double *__restrict__ x, uint64_t n, int d, uint64_t Mtot,
+                   const int *__restrict__ dimsel /* d dimensions to take, or null: 0 .. d - 1 */,
                    double *__restrict__ bm, double *__restrict__ scale) {
   __shared__ double part[4][kTileRows];
   const int lane = threadIdx.x & 63;
@@ -143,7 +278,8 @@ k_build_basis_grad(const DimDesc *__restrict__ dims, const GradHyp *__restrict__
   const bool valid = row < n;
   double *tile_out = bm + tile * Mtot * kTileRows + lane;
   double sc = 1.0;
-  for (int l = wave; l < d; l += 4) {
+  for (int li = wave; li < d; li += 4) {
+    const int l = dimsel ? dimsel[li] : li;
     const DimDesc D = dims[l];
     const GradHyp *hy = hyps + hypst[l];
     const int nh = hypst[l + 1] - hypst[l];
@@ -164,6 +300,113 @@ k_build_basis_grad(const DimDesc *__restrict__ dims, const GradHyp *__restrict__
   if (wave == 0) {
     const double s = part[0][lane] * part[1][lane] * part[2][lane] * part[3][lane];
     scale[row] = valid ? s : 0.0;
+  }
+}
+
+// ---- host: the interval tables of one dimension -------------------------------------------------
+// Layout: [m sorted u, padded to an even length][m + 1 intervals][ncol levels][NC] with, per
+// (interval J, level c), the polynomial coefficients (lowest power first) of
+//   V- (3) V+ (3) | C (4) D (4) | E (4) F (4) P (3) Q (3)     (the last 14 for mat25pow only)
+// in the local variable t = u(x) - ref_J, ref_J = u_(J-1) (u_(0) for J = 0): "-" sums the knots
+// below (j < J, h = t + q_j, q_j = ref_J - u_j), "+" the knots above (ah = q_j - t, q_j = u_j -
+// ref_J), each knot weighted by e^{-q_j} <= 1.  Built by two recurrences in extended precision,
+// O(m) per level where a direct sum per interval would be O(m^2): going from interval J to J + 1
+// the local variable moves by D = u_J - u_(J-1), so the "below" polynomial is shifted
+// (P(t + D), a Taylor shift of a cubic) and damped by e^{-D} before knot J enters with q = 0;
+// the "above" polynomials run the same way from the last interval down.  Every factor is <= 1
+// and nothing is ever subtracted that the knot sum itself does not subtract.
+typedef long double ld;
+struct Cubic {
+  ld c[4] = {0, 0, 0, 0};
+  void shift(ld D) {  // P(t) -> P(t + D)
+    const ld p0 = c[0], p1 = c[1], p2 = c[2], p3 = c[3];
+    c[0] = p0 + D * (p1 + D * (p2 + D * p3));
+    c[1] = p1 + D * (2 * p2 + 3 * D * p3);
+    c[2] = p2 + 3 * D * p3;
+  }
+  void scale(ld f) {
+    for (ld &v : c) v *= f;
+  }
+  void add(const Cubic &o, ld f) {
+    for (int k = 0; k < 4; ++k) c[k] += f * o.c[k];
+  }
+  Cubic flipped() const {  // P(t) -> P(-t)
+    Cubic r;
+    r.c[0] = c[0], r.c[1] = -c[1], r.c[2] = c[2], r.c[3] = -c[3];
+    return r;
+  }
+};
+
+// us: the m centred knot positions u_j sorted ascending, ord their original indices; R, G0, G1:
+// rotmat / rotmat_gradhyp columns of level c (indexed by the ORIGINAL knot index); kdv:
+// log(knot_j) t(knot_j).  out: (m + 1) * ncol * NC doubles behind the sorted u.
+void build_grad_tab(int m, int ncol, bool pw, double powv, const std::vector<double> &us,
+                    const std::vector<int> &ord, const double *rot, const double *rotg0,
+                    const double *rotg1, uint64_t ldr, const double *kdv, double *out) {
+  const int NC = pw ? 28 : 14;
+  const ld a3 = 2.0L / 3.0L, b3 = 0.25L / 3.0L, bp3 = 0.25L * (ld)powv / 3.0L;
+  Cubic gkv, gcub, ghq;  // (1 + z + z^2 / 3), z^2 (1 + z), z (1 + z)
+  gkv.c[0] = 1, gkv.c[1] = 1, gkv.c[2] = 1.0L / 3.0L;
+  gcub.c[2] = 1, gcub.c[3] = 1;
+  ghq.c[1] = 1, ghq.c[2] = 1;
+  for (int c = 0; c < ncol; ++c) {
+    const double *R = rot + (size_t)c * ldr, *G0 = rotg0 + (size_t)c * ldr, *G1 = pw ? rotg1 + (size_t)c * ldr : nullptr;
+    // per-knot polynomials in z (z = h below, z = ah above); the sign of the z (1 + z) term flips
+    // above, where h (1 + ah) = -ah (1 + ah)
+    auto knot = [&](int j, bool above, Cubic (&f)[4]) {
+      const int o = ord[j];
+      const ld r = R[o], g0 = G0[o];
+      for (Cubic &q : f) q = Cubic();
+      f[0].add(gkv, r);                       // V
+      f[1].add(gcub, a3 * r), f[1].add(gkv, g0);  // T0
+      if (pw) {
+        const ld sg = above ? -1.0L : 1.0L;
+        f[2].add(ghq, sg * bp3 * (ld)kdv[o] * r), f[2].add(gcub, b3 * r), f[2].add(gkv, (ld)G1[o]);  // E / F
+        f[3].add(ghq, -sg * bp3 * r);                                                                // P / Q
+      }
+    };
+    std::vector<Cubic> below((size_t)(m + 1) * 4), above((size_t)(m + 1) * 4);
+    Cubic cur[4], kn[4];
+    // forward: below(J), J = 1 .. m (below(0) is empty)
+    for (int J = 1; J <= m; ++J) {
+      if (J >= 2) {
+        const ld D = (ld)us[J - 1] - (ld)us[J - 2];
+        const ld e = expl(-D);
+        for (Cubic &q : cur) q.shift(D), q.scale(e);
+      }
+      knot(J - 1, false, kn);  // enters with q = 0: z = t
+      for (int f = 0; f < 4; ++f) cur[f].add(kn[f], 1), below[(size_t)J * 4 + f] = cur[f];
+    }
+    // backward: above(J) for J = m - 1 .. 0 (above(m) is empty), as polynomials in t
+    for (Cubic &q : cur) q = Cubic();
+    for (int J = m - 1; J >= 0; --J) {
+      // local variable of interval J against that of J + 1: t_J = t_(J+1) + D, D = ref_(J+1) - ref_J
+      const ld refJ = us[J >= 1 ? J - 1 : 0], refJ1 = us[J];
+      const ld D = refJ1 - refJ;
+      const ld e = expl(-D);
+      for (Cubic &q : cur) q.shift(-D), q.scale(e);
+      // knot J enters with q_J = u_J - ref_J: polynomial in z = q_J - t -> in t
+      knot(J, true, kn);
+      const ld qJ = (ld)us[J] - refJ;
+      const ld w = expl(-qJ);
+      for (int f = 0; f < 4; ++f) {
+        Cubic g = kn[f];
+        g.shift(qJ);              // g(z = qJ + s)
+        cur[f].add(g.flipped(), w);  // s = -t
+        above[(size_t)J * 4 + f] = cur[f];
+      }
+    }
+    for (int J = 0; J <= m; ++J) {
+      double *e = out + ((size_t)J * ncol + c) * NC;
+      const Cubic *lo = &below[(size_t)J * 4], *hi = &above[(size_t)J * 4];
+      e[0] = (double)lo[0].c[0], e[1] = (double)lo[0].c[1], e[2] = (double)lo[0].c[2];
+      e[3] = (double)hi[0].c[0], e[4] = (double)hi[0].c[1], e[5] = (double)hi[0].c[2];
+      for (int k = 0; k < 4; ++k) e[6 + k] = (double)lo[1].c[k], e[10 + k] = (double)hi[1].c[k];
+      if (pw) {
+        for (int k = 0; k < 4; ++k) e[14 + k] = (double)lo[2].c[k], e[18 + k] = (double)hi[2].c[k];
+        for (int k = 0; k < 3; ++k) e[22 + k] = (double)lo[3].c[k], e[25 + k] = (double)hi[3].c[k];
+      }
+    }
   }
 }
 
@@ -217,6 +460,57 @@ int ensure_gradbasis(obhip_basis &b) {
   OB_TRY(g->kd.upload(hkd.data(), hkd.size()));
   DevBuf<int> dhypst;
   OB_TRY(dhypst.upload(hhypst.data(), hhypst.size()));
+  // interval tables of the mat25 / mat25pow dimensions (OBHIP_GRAD_KNOTLOOP=1: none, the
+  // round-3 kernel -- A/B runs)
+  static const bool knotloop = getenv("OBHIP_GRAD_KNOTLOOP") && atoi(getenv("OBHIP_GRAD_KNOTLOOP")) != 0;
+  std::vector<GradTab> hgt(d);
+  std::vector<int> rest;  // dimensions without a table: the knot loop
+  std::vector<double> htab;
+  bool any_tab = false;
+  for (uint64_t l = 0; l < d; ++l) {
+    const DimDesc &D = b.md.dims_h[l];
+    const uint64_t ml = m.m_of(l), o = m.knotptst[l];
+    const bool pw = m.kinds[l] == OBHIP_COV_MAT25POW;
+    const int nc = pw ? 28 : 14;
+    const uint64_t mu = (ml + 1) / 2 * 2;
+    const uint64_t size = mu + (ml + 1) * (uint64_t)D.ncol * nc;
+    hgt[l] = GradTab{-1, nc, 0};
+    rest.push_back((int)l);
+    // (D.kind differs from the model's kind when the knots spread too far for the separable
+    // exponentials: those dimensions keep the per-knot exp)
+    if (knotloop || (m.kinds[l] != OBHIP_COV_MAT25 && !pw) || D.kind != m.kinds[l] || ml > 127 ||
+        size > (uint64_t)kGradTabMax)
+      continue;
+    rest.pop_back();
+    std::vector<int> ord(ml);
+    std::vector<double> u(ml), us(ml);
+    for (uint64_t j = 0; j < ml; ++j) {
+      ord[j] = (int)j;
+      u[j] = (pw ? std::pow(m.knotpt[o + j], D.p0) / D.p1 : m.knotpt[o + j] / D.p0) - D.p2;
+    }
+    std::stable_sort(ord.begin(), ord.end(), [&](int a2, int b2) { return u[a2] < u[b2]; });
+    for (uint64_t j = 0; j < ml; ++j) us[j] = u[ord[j]];
+    if (htab.size() % 2) htab.push_back(0.0);
+    hgt[l].off = (int)htab.size();
+    hgt[l].size = (int)size;
+    htab.resize(htab.size() + size, 0.0);
+    double *T = &htab[hgt[l].off];
+    for (uint64_t j = 0; j < ml; ++j) T[j] = us[j];
+    for (uint64_t j = ml; j < mu; ++j) T[j] = us[ml - 1];
+    const uint64_t h0 = m.hypst[l];
+    build_grad_tab((int)ml, D.ncol, pw, D.p0, us, ord, &m.rotmat[o * m.mmax],
+                   &m.rotmat_gradhyp[m.gest[h0] * m.mmax], pw ? &m.rotmat_gradhyp[m.gest[h0 + 1] * m.mmax] : nullptr,
+                   m.mmax, &hkd[o], T + mu);
+    any_tab = true;
+  }
+  DevBuf<GradTab> dgt;
+  DevBuf<double> dtab;
+  DevBuf<int> drest;
+  if (any_tab) {
+    OB_TRY(dgt.upload(hgt.data(), hgt.size()));
+    OB_TRY(dtab.upload(htab.data(), htab.size()));
+    if (!rest.empty()) OB_TRY(drest.upload(rest.data(), rest.size()));
+  }
 
   // the combined array as an obhip_basis whose dimension table is extended by two
   // pseudo-dimensions per hyper-parameter: d + h, whose level j >= 1 is gradient level j - 1,
@@ -252,11 +546,24 @@ int ensure_gradbasis(obhip_basis &b) {
   OB_TRY(gb.scale.alloc(b.n_pad));
   {
     ProfScope ps("build_basis_grad");
-    hipLaunchKernelGGL(k_build_basis_grad, dim3((unsigned)tiles), dim3(256), 0, cur_stream(),
-                       b.md.dims.p, g->hyps.p, dhypst.p, b.md.ka.p, b.md.kb.p, g->kd.p, b.md.rot.p,
-                       g->rotg.p, b.x.p, b.n, (int)d, gecol, gb.bm.p, gb.scale.p);
+    if (any_tab) {
+      // the dimensions without a table first (their product goes to scale), then the others
+      if (!rest.empty())
+        hipLaunchKernelGGL(k_build_basis_grad, dim3((unsigned)tiles), dim3(256), 0, cur_stream(),
+                           b.md.dims.p, g->hyps.p, dhypst.p, b.md.ka.p, b.md.kb.p, g->kd.p, b.md.rot.p,
+                           g->rotg.p, b.x.p, b.n, (int)rest.size(), gecol, drest.p, gb.bm.p, gb.scale.p);
+      const size_t lds = (size_t)kGradTabMax * sizeof(double);
+      OB_TRY(ensure_dyn_lds((const void *)k_build_basis_grad_tab, lds));
+      hipLaunchKernelGGL(k_build_basis_grad_tab, dim3((unsigned)((tiles + 15) / 16)), dim3(1024), lds, cur_stream(),
+                         b.md.dims.p, g->hyps.p, dhypst.p, dgt.p, dtab.p, b.x.p, b.n, (int)d, gecol, tiles,
+                         rest.empty() ? 0 : 1, gb.bm.p, gb.scale.p);
+    } else {
+      hipLaunchKernelGGL(k_build_basis_grad, dim3((unsigned)tiles), dim3(256), 0, cur_stream(),
+                         b.md.dims.p, g->hyps.p, dhypst.p, b.md.ka.p, b.md.kb.p, g->kd.p, b.md.rot.p,
+                         g->rotg.p, b.x.p, b.n, (int)d, gecol, (const int *)nullptr, gb.bm.p, gb.scale.p);
+    }
     OB_HIP(hipGetLastError());
-    OB_HIP(hipStreamSynchronize(cur_stream()));  // dhypst is a local
+    OB_HIP(hipStreamSynchronize(cur_stream()));  // dhypst and the tables are locals
   }
   g->model_version = m.version;
   static uint64_t next_id = 1;

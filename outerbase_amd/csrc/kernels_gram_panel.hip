@@ -400,12 +400,17 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
 // (padding tasks exit at once).  At p = 4096: 10 squares x 32 splits = 320 units, 2112 blocks
 // per XCD = 33 rounds of 64.  (The first version dealt every XCD a 66-pair run of the sorted
 // pair list per split: runs straddle squares and touch 16-24 column blocks.)
+//
+// When the units do not pack into the 64 slots of an XCD -- one 34-block square per split at
+// p = 1024: two units are 68 blocks, and the four that do not fit wait for a whole second round --
+// the units are dealt CONTINUOUSLY instead (`continuous`): the task list in unit order is cut
+// into 8 equal runs, a unit may straddle two XCDs (its panels are then fetched by both).
+// gram_xcd_blocks tells the row-split choice what either dealing gives an XCD.
 constexpr int kXcd = 8, kSq = 8;
-void build_task_order(int nb, int nsplit, bool diag4, std::vector<uint64_t> &tab) {
-  struct Unit {
-    int bi, bj, y, size;
-  };
-  std::vector<Unit> units;
+struct GramUnit {
+  int bi, bj, y, size;
+};
+void gram_units(int nb, int nsplit, bool diag4, std::vector<GramUnit> &units) {
   const int nsq = (nb + kSq - 1) / kSq;
   for (int y = 0; y < nsplit; ++y)
     for (int bi = 0; bi < nsq; ++bi)
@@ -416,14 +421,58 @@ void build_task_order(int nb, int nsplit, bool diag4, std::vector<uint64_t> &tab
             if (!(i == j && diag4 && i / 4 * 4 + 3 < nb && i % 4 == 3)) ++size;
         if (size) units.push_back({bi, bj, y, size});
       }
+}
+// blocks of the busiest XCD
+uint64_t gram_xcd_blocks(int nb, int nsplit, bool diag4, bool continuous) {
+  std::vector<GramUnit> units;
+  gram_units(nb, 1, diag4, units);  // (every split has the same units)
+  uint64_t per_split = 0;
+  for (const GramUnit &u : units) per_split += (uint64_t)u.size;
+  if (continuous) return (per_split * (uint64_t)nsplit + kXcd - 1) / kXcd;
+  std::vector<int> sizes;
+  for (int y = 0; y < nsplit; ++y)
+    for (const GramUnit &u : units) sizes.push_back(u.size);
+  std::stable_sort(sizes.begin(), sizes.end(), [](int a, int b) { return a > b; });
+  uint64_t load[kXcd] = {0};
+  for (int s : sizes) {
+    int k = 0;
+    for (int q = 1; q < kXcd; ++q)
+      if (load[q] < load[k]) k = q;
+    load[k] += (uint64_t)s;
+  }
+  return *std::max_element(load, load + kXcd);
+}
+void build_task_order(int nb, int nsplit, bool diag4, bool continuous, std::vector<uint64_t> &tab) {
+  typedef GramUnit Unit;
+  std::vector<Unit> units;
+  gram_units(nb, nsplit, diag4, units);
   // largest units first, each to the XCD with the fewest blocks so far (stable: the order
   // of equal-sized units keeps squares of one split together)
-  std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.size > b.size; });
+  if (!continuous)
+    std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.size > b.size; });
+  uint64_t total = 0;
+  for (const Unit &u : units) total += (uint64_t)u.size;
+  const uint64_t run = (total + kXcd - 1) / kXcd;  // continuous: tasks per XCD
+  uint64_t dealt = 0;
   std::vector<std::vector<uint64_t>> seq(kXcd);
   for (const Unit &u : units) {
     int k = 0;
     for (int q = 1; q < kXcd; ++q)
       if (seq[q].size() < seq[k].size()) k = q;
+    if (continuous) {  // task by task: the unit's tasks go to XCD dealt / run
+      for (int i = u.bi * kSq; i < std::min(nb, (u.bi + 1) * kSq); ++i)
+        for (int j = std::max(i, u.bj * kSq); j < std::min(nb, (u.bj + 1) * kSq); ++j) {
+          if (i == j && diag4) {
+            const int g0 = i / 4 * 4;
+            if (g0 + 3 < nb) {
+              if (i - g0 < 3) seq[(dealt++) / run].push_back(atb_task(i, i + 1, u.y, 1 + (i - g0)));
+              continue;
+            }
+          }
+          seq[(dealt++) / run].push_back(atb_task(i, j, u.y));
+        }
+      continue;
+    }
     for (int i = u.bi * kSq; i < std::min(nb, (u.bi + 1) * kSq); ++i)
       for (int j = std::max(i, u.bj * kSq); j < std::min(nb, (u.bj + 1) * kSq); ++j) {
         if (i == j && diag4) {
@@ -538,25 +587,59 @@ int gram_of_staged(obhip_basis &b, const double *d_B, uint64_t ntiles, obhip_ter
   // more partial of every tile pair to read (128 KB at ~4 TB/s = 0.0022 of the 14.6 us a block
   // takes per row tile).  Both measured at p = 4096 (16 vs 32 splits at 125 000 rows: equal
   // Gram times, half the reduction).
+  // The rounds are those of the busiest XCD (64 of the slots each): the task table hands the XCDs
+  // whole units (build_task_order), and when those do not pack into 64 slots -- p = 1024: one
+  // 34-block unit per split, two of them = 68 -- a whole round is spent on the overhang (measured:
+  // 2.56 ms where the model without XCDs promised 1.5).  Both dealings are priced, the continuous
+  // one 3 % dearer for the panels its straddling units fetch twice.
   double bestc = 1e300;
-  for (uint64_t ns = 1; ns <= max_split; ++ns) {
-    const uint64_t blocks = ns * bps, full = blocks / slots, tail = blocks % slots;
-    const double rounds = (double)full + (tail == 0 ? 0.0 : (2 * tail <= slots ? 0.6 : 1.0));
-    const double cost = rounds * ((double)ntiles / (double)ns + 1.0) + 0.0022 * (double)blocks;
-    if (cost < bestc) {
-      bestc = cost;
-      nsplit = ns;
+  bool continuous = false;
+  const uint64_t xslots = slots / kXcd;
+  // (the choice depends on the shape only: priced once per shape, not once per fit)
+  static std::mutex split_mu;
+  static std::map<std::tuple<int, uint64_t, uint64_t, uint64_t, bool>, std::pair<uint64_t, bool>> split_cache;
+  const auto split_key = std::make_tuple(nb, ntiles, max_split, slots, diag4);
+  bool cached = false;
+  {
+    std::lock_guard<std::mutex> lk(split_mu);
+    auto it = split_cache.find(split_key);
+    if (it != split_cache.end()) {
+      nsplit = it->second.first;
+      continuous = it->second.second;
+      cached = true;
     }
   }
+  for (uint64_t ns = 1; !cached && ns <= max_split; ++ns) {
+    const uint64_t blocks = ns * bps;
+    for (int mode = 0; mode < 2; ++mode) {
+      const uint64_t per = gram_xcd_blocks(nb, (int)ns, diag4, mode == 1);
+      const uint64_t full = per / xslots, tail = per % xslots;
+      const double rounds = (double)full + (tail == 0 ? 0.0 : (2 * tail <= xslots ? 0.6 : 1.0));
+      double cost = rounds * ((double)ntiles / (double)ns + 1.0) + 0.0022 * (double)blocks;
+      if (mode == 1) cost *= 1.03;
+      if (cost < bestc - 1e-9) {
+        bestc = cost;
+        nsplit = ns;
+        continuous = mode == 1;
+      }
+    }
+  }
+  if (!cached) {
+    std::lock_guard<std::mutex> lk(split_mu);
+    split_cache[split_key] = std::make_pair(nsplit, continuous);
+  }
   if (const char *e = getenv("OBHIP_GRAM_NSPLIT")) nsplit = std::max<uint64_t>(1, std::min<uint64_t>(max_split, atoi(e)));
+  if (const char *e = getenv("OBHIP_GRAM_CONTINUOUS")) continuous = atoi(e) != 0;
   double *part = nullptr;
   OB_TRY(b.workspace((size_t)nsplit * npairs * kGT * kGT * sizeof(double) + 256, (void **)&part));
   unsigned long long *dbgout =
       dbg ? (unsigned long long *)(part + (size_t)nsplit * npairs * kGT * kGT) : nullptr;
-  if (b.gram_pairs_nb != nb || b.gram_pairs_ns != (int)nsplit || b.gram_pairs_diag4 != diag4) {
+  if (b.gram_pairs_nb != nb || b.gram_pairs_ns != (int)nsplit || b.gram_pairs_diag4 != diag4 ||
+      b.gram_pairs_cont != continuous) {
     std::vector<uint64_t> tab;
-    build_task_order(nb, (int)nsplit, diag4, tab);
+    build_task_order(nb, (int)nsplit, diag4, continuous, tab);
     b.gram_pairs_diag4 = diag4;
+    b.gram_pairs_cont = continuous;
     OB_TRY(b.gram_pairs.upload(tab.data(), tab.size()));
     b.gram_pairs_nb = nb;
     b.gram_pairs_ns = (int)nsplit;

@@ -261,7 +261,7 @@ struct obhip_basis {
   uint64_t bmat_terms = 0;      // uid of the terms bmat currently holds (0: none)
   obhip::DevBuf<uint64_t> gram_pairs;  // XCD-aware (tile pair, row split) task order of that kernel
   int gram_pairs_nb = -1, gram_pairs_ns = -1;
-  bool gram_pairs_diag4 = false;
+  bool gram_pairs_diag4 = false, gram_pairs_cont = false;
   std::unique_ptr<obhip_gradbasis> grad;  // built on first *_gradhyp call, dropped on rebuild
   int device = 0;
   int workspace(size_t bytes, void **out) {

@@ -381,6 +381,30 @@ def test_cg_fit_matches_oracle_iterations():
     assert relerr(lik.yhat, O.ob_mm(bo, terms, th_n)) < 1e-6
 
 
+@pytest.mark.parametrize("m,cap", [(120, None), (120, 3), (40, None)])
+def test_many_knots_with_and_without_interval_tables(m, cap):
+    """The interval tables of mat25 / mat25pow are built only while a dimension's table fits the
+    LDS buffer of k_build_basis (2048 doubles; round-3 advice: larger ones cost the host
+    O(knots^2 x levels) per hyper-parameter update and were read by per-lane global gathers, no
+    faster than the knot loop).  120 knots with every level kept: the knot loop; capped at 3
+    levels: tables of 121 intervals; 40 knots with every level: the knot loop again.  The
+    well-separated low levels against the oracle either way."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25", "mat25pow", "mat25"]
+    knots = [np.linspace(0.001, 0.976, m)] * 3
+    om_o, om_d = make_pair(kinds, knots)
+    rng = np.random.default_rng(m)
+    x = sample_x(rng, 500, kinds)
+    terms = random_terms(rng, 60, 3, 3, 3)
+    levelcap = None if cap is None else np.full(3, cap, dtype=np.int64)
+    bd = ob.outerbase(om_d, x, levelcap=levelcap)
+    want = O.ob_getmat(O.OuterBase(om_o, x), terms)
+    assert relerr(bd.getmat(terms), want) < 1e-9
+    a = rng.standard_normal(60)
+    assert relerr(bd.matmul(terms, a), want @ a) < 1e-9
+
+
 def test_level_caps_do_not_change_results():
     import outerbase_amd as ob
     kinds = ["mat25"] * 6
@@ -391,7 +415,9 @@ def test_level_caps_do_not_change_results():
     full = ob.outerbase(om_d, x)
     capped = ob.outerbase(om_d, x, levelcap=terms.max(axis=0))
     a = rng.standard_normal(120)
-    assert np.array_equal(full.matmul(terms, a), capped.matmul(terms, a))
+    # (to rounding, not to the bit: with all 30 levels kept a dimension's interval tables no longer
+    # fit k_build_basis's LDS buffer and it takes the knot loop, the capped basis takes the tables)
+    assert relerr(capped.matmul(terms, a), full.matmul(terms, a)) < 1e-10
     with pytest.raises(ob.ObhipError):
         ob.outerbase(om_d, x, levelcap=np.zeros(6, dtype=np.int64)).matmul(terms, a)
 
