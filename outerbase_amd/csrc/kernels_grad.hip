@@ -142,12 +142,19 @@ __device__ __forceinline__ double build_dim_grad(const DimDesc &D, const GradHyp
 //   t1 = e^{-t} (E(t) + L P(t)) + e^{t} (F(t) + L Q(t))
 // with 6 + 8 (+ 8 + 6) host-built coefficients per (interval, level) (build_grad_tab below) -- O(1)
 // per (row, level) where the knot loop spends ~45 instructions per (row, knot, 8 levels).
+// A dimension's table is [mu sorted u][chunk 0][chunk 1] ...: the levels in chunks of `nck`, a chunk
+// = [m + 1 intervals][nck levels][nc] -- as many levels as fit the LDS buffer beside the sorted u
+// (every mat25 / mat25pow dimension of at most 127 knots gets tables: 128 intervals x 28
+// coefficients are 3584 doubles per level).
 struct GradTab {
-  int off;  // offset (doubles) of the dimension's table in the table array, -1: knot loop
-  int nc;   // coefficients per (interval, level): 14 (mat25) or 28 (mat25pow)
-  int size; // doubles
+  int off;      // offset (doubles) of the dimension's table in the table array, -1: knot loop
+  int nc;       // coefficients per (interval, level): 14 (mat25) or 28 (mat25pow)
+  int mu;       // sorted u, padded to an even length
+  int nck;      // levels per chunk
+  int nchunks;  // ceil(ncol / nck)
+  int chunk;    // doubles per chunk = (m + 1) * nck * nc
 };
-constexpr int kGradTabMax = 16384;  // doubles of LDS for one dimension's table (128 KB)
+constexpr int kGradTabMax = 16384;  // doubles of LDS for the sorted u + one chunk (128 KB)
 
 // a row's place in a dimension's table: interval, local variable, the two exponentials, L
 struct GradRow {
@@ -174,19 +181,25 @@ __device__ __forceinline__ GradRow grad_row(const DimDesc &D, const double *__re
   g.L = POW ? log(xv) * (ux + D.p2) : 0.0;
   return g;
 }
+// level 0's values, carried from the first chunk of a dimension to the later ones
+struct GradLevel0 {
+  double cl = 1.0, icl = 1.0, g00 = 0.0, g10 = 0.0;
+};
+// levels [c_lo, c_hi) of one dimension for one row; chunk: the staged chunk [m + 1][nck][NC]
 template <int KIND>
-__device__ __forceinline__ double build_dim_grad_tab(const DimDesc &D, const GradHyp *__restrict__ hy,
-                                                     const double *__restrict__ tab, const GradRow &g,
-                                                     double *__restrict__ tile_out) {
+__device__ __forceinline__ void build_dim_grad_tab(const DimDesc &D, const GradHyp *__restrict__ hy,
+                                                   const double *__restrict__ chunk, int nck, int c_lo,
+                                                   int c_hi, const GradRow &g, GradLevel0 &z,
+                                                   double *__restrict__ tile_out) {
   constexpr bool POW = KIND == OBHIP_COV_MAT25POW;
   constexpr int NC = POW ? 28 : 14;
   typedef double dd2 __attribute__((ext_vector_type(2)));
   const double t = g.t, em = g.em, ep = g.ep, L = g.L;
-  const dd2 *__restrict__ cf = (const dd2 *)(tab + ((D.m + 1) & ~1) + (size_t)g.J * D.ncol * NC);
-  double icl = 1.0, cl = 1.0, g00 = 0.0, g10 = 0.0;
+  const dd2 *__restrict__ cf = (const dd2 *)(chunk + (size_t)g.J * nck * NC);
+  double icl = z.icl, cl = z.cl, g00 = z.g00, g10 = z.g10;
 #pragma unroll 1
-  for (int c = 0; c < D.ncol; ++c) {
-    const dd2 *e = cf + c * (NC / 2);
+  for (int c = c_lo; c < c_hi; ++c) {
+    const dd2 *e = cf + (c - c_lo) * (NC / 2);
     const dd2 v0 = e[0], v1 = e[1], v2 = e[2];           // V-0 V-1 | V-2 V+0 | V+1 V+2
     const dd2 c0 = e[3], c1 = e[4], d0 = e[5], d1 = e[6];  // C0 C1 | C2 C3 | D0 D1 | D2 D3
     const double r = em * fma(t, fma(t, v1.x, v0.y), v0.x) + ep * fma(t, fma(t, v2.y, v2.x), v1.y);
@@ -215,13 +228,14 @@ __device__ __forceinline__ double build_dim_grad_tab(const DimDesc &D, const Gra
       if (POW) tile_out[(size_t)(hy[1].dcol + c - 1) * kTileRows] = fma(-bv, g10, ge1);
     }
   }
-  return cl;
+  z.cl = cl, z.icl = icl, z.g00 = g00, z.g10 = g10;
 }
 
 // 16 waves = 16 row tiles per block; all waves walk the dimensions that have a table together,
-// a dimension's table staged in LDS once per block.  Dimensions without a table (mat25ang, out-of-range
-// hyper-parameters, tables beyond the LDS buffer) are left to k_build_basis_grad, which then ran
-// BEFORE this kernel on those dimensions alone (scale_has_part: scale holds their product).
+// a dimension's sorted u and one chunk of its levels staged in LDS at a time.  Dimensions without a
+// table (mat25ang, out-of-range hyper-parameters, more than 127 knots) are left to
+// k_build_basis_grad, which then ran BEFORE this kernel on those dimensions alone
+// (scale_has_part: scale holds their product).
 __global__ void __launch_bounds__(1024)
 k_build_basis_grad_tab(const DimDesc *__restrict__ dims, const GradHyp *__restrict__ hyps,
                        const int *__restrict__ hypst, const GradTab *__restrict__ gtabs,
@@ -241,19 +255,31 @@ k_build_basis_grad_tab(const DimDesc *__restrict__ dims, const GradHyp *__restri
     const GradTab T = gtabs[l];
     if (T.off < 0) continue;  // (block-uniform)
     const DimDesc D = dims[l];
-    // the dimension's table: 16 waves x 1800 clocks of LDS-bound evaluation follow, so the ~1 us the
+    const GradHyp *hy = hyps + hypst[l];
+    const bool m25 = D.kind == OBHIP_COV_MAT25;
+    GradRow g;
+    GradLevel0 z;
+    // per chunk: ~1800 clocks of LDS-bound evaluation per wave and 8 levels follow, so the ~1 us the
     // copy is exposed for is ~10 % (prefetching it through registers made the kernel spill)
-    __syncthreads();  // everyone is done with the previous dimension's table
-    for (int e = threadIdx.x; e < T.size; e += 1024) ltab[e] = gtab[T.off + e];
-    __syncthreads();
-    if (mine) {
-      const GradHyp *hy = hyps + hypst[l];
-      const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
-      if (D.kind == OBHIP_COV_MAT25)
-        sc *= build_dim_grad_tab<OBHIP_COV_MAT25>(D, hy, ltab, grad_row<OBHIP_COV_MAT25>(D, ltab, xv), tile_out);
+    for (int k = 0; k < T.nchunks; ++k) {
+      __syncthreads();  // everyone is done with what the buffer held
+      if (k == 0)
+        for (int e = threadIdx.x; e < T.mu; e += 1024) ltab[e] = gtab[T.off + e];
+      const double *src = gtab + T.off + T.mu + (size_t)k * T.chunk;
+      for (int e = threadIdx.x; e < T.chunk; e += 1024) ltab[T.mu + e] = src[e];
+      __syncthreads();
+      if (!mine) continue;
+      if (k == 0) {
+        const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
+        g = m25 ? grad_row<OBHIP_COV_MAT25>(D, ltab, xv) : grad_row<OBHIP_COV_MAT25POW>(D, ltab, xv);
+      }
+      const int c_lo = k * T.nck, c_hi = min(D.ncol, c_lo + T.nck);
+      if (m25)
+        build_dim_grad_tab<OBHIP_COV_MAT25>(D, hy, ltab + T.mu, T.nck, c_lo, c_hi, g, z, tile_out);
       else
-        sc *= build_dim_grad_tab<OBHIP_COV_MAT25POW>(D, hy, ltab, grad_row<OBHIP_COV_MAT25POW>(D, ltab, xv), tile_out);
+        build_dim_grad_tab<OBHIP_COV_MAT25POW>(D, hy, ltab + T.mu, T.nck, c_lo, c_hi, g, z, tile_out);
     }
+    sc *= z.cl;
   }
   if (mine) {
     tile_out[0] = 1.0;
@@ -339,8 +365,9 @@ struct Cubic {
 
 // us: the m centred knot positions u_j sorted ascending, ord their original indices; R, G0, G1:
 // rotmat / rotmat_gradhyp columns of level c (indexed by the ORIGINAL knot index); kdv:
-// log(knot_j) t(knot_j).  out: (m + 1) * ncol * NC doubles behind the sorted u.
-void build_grad_tab(int m, int ncol, bool pw, double powv, const std::vector<double> &us,
+// log(knot_j) t(knot_j).  out: the chunks behind the sorted u, level c at chunk c / nck, entry
+// ((J * nck) + c % nck) * NC of it.
+void build_grad_tab(int m, int ncol, int nck, bool pw, double powv, const std::vector<double> &us,
                     const std::vector<int> &ord, const double *rot, const double *rotg0,
                     const double *rotg1, uint64_t ldr, const double *kdv, double *out) {
   const int NC = pw ? 28 : 14;
@@ -397,7 +424,7 @@ void build_grad_tab(int m, int ncol, bool pw, double powv, const std::vector<dou
       }
     }
     for (int J = 0; J <= m; ++J) {
-      double *e = out + ((size_t)J * ncol + c) * NC;
+      double *e = out + (size_t)(c / nck) * ((size_t)(m + 1) * nck * NC) + ((size_t)J * nck + c % nck) * NC;
       const Cubic *lo = &below[(size_t)J * 4], *hi = &above[(size_t)J * 4];
       e[0] = (double)lo[0].c[0], e[1] = (double)lo[0].c[1], e[2] = (double)lo[0].c[2];
       e[3] = (double)hi[0].c[0], e[4] = (double)hi[0].c[1], e[5] = (double)hi[0].c[2];
@@ -462,7 +489,7 @@ int ensure_gradbasis(obhip_basis &b) {
   OB_TRY(dhypst.upload(hhypst.data(), hhypst.size()));
   // interval tables of the mat25 / mat25pow dimensions (OBHIP_GRAD_KNOTLOOP=1: none, the
   // round-3 kernel -- A/B runs)
-  static const bool knotloop = getenv("OBHIP_GRAD_KNOTLOOP") && atoi(getenv("OBHIP_GRAD_KNOTLOOP")) != 0;
+  const bool knotloop = getenv("OBHIP_GRAD_KNOTLOOP") && atoi(getenv("OBHIP_GRAD_KNOTLOOP")) != 0;
   std::vector<GradTab> hgt(d);
   std::vector<int> rest;  // dimensions without a table: the knot loop
   std::vector<double> htab;
@@ -473,14 +500,15 @@ int ensure_gradbasis(obhip_basis &b) {
     const bool pw = m.kinds[l] == OBHIP_COV_MAT25POW;
     const int nc = pw ? 28 : 14;
     const uint64_t mu = (ml + 1) / 2 * 2;
-    const uint64_t size = mu + (ml + 1) * (uint64_t)D.ncol * nc;
-    hgt[l] = GradTab{-1, nc, 0};
+    const uint64_t per_level = (ml + 1) * (uint64_t)nc;
+    hgt[l] = GradTab{-1, nc, (int)mu, 0, 0, 0};
     rest.push_back((int)l);
     // (D.kind differs from the model's kind when the knots spread too far for the separable
     // exponentials: those dimensions keep the per-knot exp)
-    if (knotloop || (m.kinds[l] != OBHIP_COV_MAT25 && !pw) || D.kind != m.kinds[l] || ml > 127 ||
-        size > (uint64_t)kGradTabMax)
-      continue;
+    if (knotloop || (m.kinds[l] != OBHIP_COV_MAT25 && !pw) || D.kind != m.kinds[l] || ml > 127) continue;
+    const uint64_t nck = std::min<uint64_t>((uint64_t)D.ncol, ((uint64_t)kGradTabMax - mu) / per_level);
+    const uint64_t nchunks = ((uint64_t)D.ncol + nck - 1) / nck;
+    const uint64_t size = mu + nchunks * nck * per_level;
     rest.pop_back();
     std::vector<int> ord(ml);
     std::vector<double> u(ml), us(ml);
@@ -492,13 +520,15 @@ int ensure_gradbasis(obhip_basis &b) {
     for (uint64_t j = 0; j < ml; ++j) us[j] = u[ord[j]];
     if (htab.size() % 2) htab.push_back(0.0);
     hgt[l].off = (int)htab.size();
-    hgt[l].size = (int)size;
+    hgt[l].nck = (int)nck;
+    hgt[l].nchunks = (int)nchunks;
+    hgt[l].chunk = (int)(nck * per_level);
     htab.resize(htab.size() + size, 0.0);
     double *T = &htab[hgt[l].off];
     for (uint64_t j = 0; j < ml; ++j) T[j] = us[j];
     for (uint64_t j = ml; j < mu; ++j) T[j] = us[ml - 1];
     const uint64_t h0 = m.hypst[l];
-    build_grad_tab((int)ml, D.ncol, pw, D.p0, us, ord, &m.rotmat[o * m.mmax],
+    build_grad_tab((int)ml, D.ncol, (int)nck, pw, D.p0, us, ord, &m.rotmat[o * m.mmax],
                    &m.rotmat_gradhyp[m.gest[h0] * m.mmax], pw ? &m.rotmat_gradhyp[m.gest[h0 + 1] * m.mmax] : nullptr,
                    m.mmax, &hkd[o], T + mu);
     any_tab = true;
