@@ -428,11 +428,20 @@ __device__ __forceinline__ double swap16_sum(double a, double b) {
                                                    (unsigned)__double2hiint(b), false, false);
   return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
+// v + (v rotated right by ROR lanes within every row of 16 lanes).  The two v_mov_b32_dpp are
+// written out: through __builtin_amdgcn_update_dpp the compiler first zeroes the destination
+// (two more VALU instructions per call) although row_ror with full row / bank masks writes every
+// lane.  s_nop 1: a DPP read of a VGPR needs two wait states behind the VALU write of it.
 template <int ROR>
 __device__ __forceinline__ double row16_ror_add(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + ROR, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + ROR, 0xf, 0xf, false);
-  return v + __hiloint2double(hi, lo);
+  static_assert(ROR >= 1 && ROR <= 15, "row_ror:1 .. row_ror:15");
+  int rl, rh;
+  asm volatile("s_nop 1\n\t"
+               "v_mov_b32_dpp %0, %2 row_ror:%4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_mov_b32_dpp %1, %3 row_ror:%4 row_mask:0xf bank_mask:0xf"
+               : "=&v"(rl), "=&v"(rh)
+               : "v"(__double2loint(v)), "v"(__double2hiint(v)), "n"(ROR));
+  return v + __hiloint2double(rh, rl);
 }
 
 

@@ -81,9 +81,13 @@ __device__ __forceinline__ void hm2_dma_col(const char *g /* uniform */, uint32_
                :: "v"(voff), "s"(g), "s"(l) : "memory");
 }
 
-// one sub-chunk of 4 rows (tile rows rc .. rc + 3; the addresses in c.ad point ROW0 rows before)
-template <int W, int NU, int ROW0, int INFL, bool RO, bool SIN>
-__device__ __forceinline__ void hm2_subchunk(Hm2Ctx<W, NU, SIN> &c, bool live, int wea, int web, double *red_half,
+// one sub-chunk of 4 rows (tile rows rc .. rc + 3; the addresses in c.ad point ROW0 rows before).
+// WEA / WEB: column reads per term of the first / second half of the lane's units -- compile-time
+// here (k_tmm_tl picks the pipeline variant with a branch per chunk; in this kernel the registers
+// of prod / acc / s differed between the branches and every join cost ~10 v_mov_b64, 13 % of the
+// kernel's VALU instructions: the choice is made once per tile instead, hm2_tile)
+template <int W, int NU, int ROW0, int INFL, bool RO, bool SIN, int WEA, int WEB>
+__device__ __forceinline__ void hm2_subchunk(Hm2Ctx<W, NU, SIN> &c, bool live, double *red_half,
                                              const double *wts /* [2][64] of this tile */,
                                              const double *avl /* !SIN: a of this lane's unit 0 */, int avstride,
                                              int wave, int lane, int rc, double &totrow) {
@@ -91,10 +95,10 @@ __device__ __forceinline__ void hm2_subchunk(Hm2Ctx<W, NU, SIN> &c, bool live, i
   for (int r = 0; r < kHm2Chunk; ++r) c.s[r] = 0.0;
   if (live) {  // (a wave without terms keeps prod = 0)
     if constexpr (NU == 1) {
-      tl_run_half<W, 1, kHm2Chunk, INFL, 0, ROW0>(c, wea);
+      TlPipe<WEA, W, 1, kHm2Chunk, INFL, 0, ROW0>::run(c);
     } else {
-      tl_run_half<W, NU / 2, kHm2Chunk, INFL, 0, ROW0>(c, wea);
-      tl_run_half<W, NU - NU / 2, kHm2Chunk, INFL, NU / 2, ROW0>(c, web);
+      TlPipe<WEA, W, NU / 2, kHm2Chunk, INFL, 0, ROW0>::run(c);
+      TlPipe<WEB, W, NU - NU / 2, kHm2Chunk, INFL, NU / 2, ROW0>::run(c);
     }
   }
   if constexpr (!SIN) {  // s[r] = sum_u a_u prod[u][r] of this lane's terms, coefficients from LDS
@@ -108,10 +112,11 @@ __device__ __forceinline__ void hm2_subchunk(Hm2Ctx<W, NU, SIN> &c, bool live, i
 #pragma unroll
       for (int r = 0; r < kHm2Chunk; ++r) c.s[r] = fma(av[u], c.prod[u][r], c.s[r]);
   }
-  // the row weights of the 4 rows (independent of the sums: issued ahead of the barrier)
-  const double vA = wts[rc + (lane & 3)];
+  // the row weights of the 4 rows, row r in the 16-lane row r (independent of the sums: issued
+  // ahead of the barrier)
+  const double vA = wts[rc + (lane >> 4)];
   double vB = 0.0;
-  if (RO) vB = wts[64 + rc + (lane & 3)];
+  if (RO) vB = wts[64 + rc + (lane >> 4)];
   // s[0..3] over the 64 lanes: 16-lane row q ends with the sum of s[q]
   static_assert(kHm2Chunk == 4, "the butterfly below reduces 4 rows");
   double v = swap16_sum(swap32_sum(c.s[0], c.s[2]), swap32_sum(c.s[1], c.s[3]));
@@ -119,21 +124,48 @@ __device__ __forceinline__ void hm2_subchunk(Hm2Ctx<W, NU, SIN> &c, bool live, i
   v = row16_ror_add<4>(v);
   v = row16_ror_add<2>(v);
   v = row16_ror_add<1>(v);
-  if ((lane & 15) == 0) red_half[wave * kHm2Chunk + (lane >> 4)] = v;
+  if ((lane & 15) == 0) red_half[(lane >> 4) * 16 + wave] = v;  // [row][wave]
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (not vmcnt: the next tile's loads stay in flight)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  // over the waves: lane l reads the partial of wave l / 4, row l % 4 (slots of absent waves are
-  // zero); afterwards EVERY lane l holds tot of row l % 4
+  // over the waves: lane l reads the partial of row l / 16, wave l % 16 (slots of absent waves are
+  // zero): four rotate-adds within the rows of 16 lanes and EVERY lane l holds tot of row l / 16
   double t = red_half[lane];
-  t = row16_ror_add<4>(t);
   t = row16_ror_add<8>(t);
-  t = swap16_sum(t, t);
-  t = swap32_sum(t, t);
+  t = row16_ror_add<4>(t);
+  t = row16_ror_add<2>(t);
+  t = row16_ror_add<1>(t);
   const double wl = RO ? fma(vA, t, vB) : vA * t;
-  if (RO && (lane & ~3) == rc) totrow = t;  // lane = row keeps sum_k a_k prod_k of its row
+  if (RO) {  // lane = row keeps sum_k a_k prod_k of its row: row j's total sits in lanes 16 j ..
+    const double tj = __shfl(t, 16 * (lane & 3), 64);
+    if ((lane & ~3) == rc) totrow = tj;
+  }
 #pragma unroll
-  for (int r = 0; r < kHm2Chunk; ++r) c.wprev[r] = readlane_f64(wl, r);
+  for (int r = 0; r < kHm2Chunk; ++r) c.wprev[r] = readlane_f64(wl, 16 * r);
+}
+
+// the 64 rows of the staged tile: 8 x two sub-chunks; step_last moves the addresses to row 0 of the
+// other tile buffer after the last rows
+template <int W, int NU, int INFL, bool RO, bool SIN, int WEA, int WEB>
+__device__ __forceinline__ void hm2_tile(Hm2Ctx<W, NU, SIN> &c, bool live, double *red, const double *wt,
+                                         const double *avl, int avstride, int wave, int lane,
+                                         int32_t step_last, double &totrow) {
+#pragma unroll 1
+  for (int rc = 0; rc < kTileRows; rc += 2 * kHm2Chunk) {
+    // two sub-chunks per address update: the second reads at immediate row offsets 4 .. 7; the
+    // cross-wave sums alternate between the two halves of red
+    hm2_subchunk<W, NU, 0, INFL, RO, SIN, WEA, WEB>(c, live, red, wt, avl, avstride, wave, lane, rc, totrow);
+    hm2_subchunk<W, NU, kHm2Chunk, INFL, RO, SIN, WEA, WEB>(c, live, red + kHm2RedSlots, wt, avl, avstride,
+                                                            wave, lane, rc + kHm2Chunk, totrow);
+    const int32_t step = rc + 2 * kHm2Chunk < kTileRows ? 2 * kHm2Chunk * 8 : step_last;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        c.ad[u][j] += (uint32_t)step;
+        asm volatile("" : "+v"(c.ad[u][j]));
+      }
+  }
 }
 
 // RO: the update() form (y, yhat, sum of squared residuals); without it the Hessian product
@@ -150,7 +182,7 @@ k_hm2(const double *__restrict__ bm, const double *__restrict__ scale, const uin
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile_doubles = Mu * kTlPitch;
   double *wts = lds + 2 * (size_t)tile_doubles;  // [2 buffers][vA 64 | vB 64]
-  double *red = wts + 2 * 128;                    // [2 halves][16 waves][4 rows]
+  double *red = wts + 2 * 128;                    // [2 halves][4 rows][16 waves]
   double *avs = red + 2 * kHm2RedSlots;           // !SIN: [NU][WAVES * 64], a of the term in slot (wave, u, lane)
   constexpr int avstride = WAVES * 64;
   const double *avl = avs + wave * 64 + lane;
@@ -228,25 +260,32 @@ k_hm2(const double *__restrict__ bm, const double *__restrict__ scale, const uin
     if (tile + 1 < t1) prefetch(tile + 1, bsel ^ 1);
     const double *wt = wts + bsel * 128;
     double totrow = 0.0;  // lane = row: sum_k a_k prod_k of this tile's row
-#pragma unroll 1
-    for (int rc = 0; rc < kTileRows; rc += 2 * kHm2Chunk) {
-      // two sub-chunks per address update: the second reads at immediate row offsets 4 .. 7;
-      // the cross-wave sums alternate between the two halves of red
-      hm2_subchunk<W, NU, 0, INFL, RO, SIN>(c, live, wea, web, red, wt, avl, avstride, wave, lane, rc, totrow);
-      hm2_subchunk<W, NU, kHm2Chunk, INFL, RO, SIN>(c, live, wea, web, red + kHm2RedSlots, wt, avl, avstride,
-                                                    wave, lane, rc + kHm2Chunk, totrow);
-      // next 8 rows; after the last ones: row 0 of the other buffer
-      const int32_t step = rc + 2 * kHm2Chunk < kTileRows
-                               ? 2 * kHm2Chunk * 8
-                               : -(kTileRows - 2 * kHm2Chunk) * 8 + (bsel ? -(int32_t)tile_bytes : (int32_t)tile_bytes);
-#pragma unroll
-      for (int u = 0; u < NU; ++u)
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          c.ad[u][j] += (uint32_t)step;
-          asm volatile("" : "+v"(c.ad[u][j]));
-        }
-    }
+    // after the last rows: row 0 of the other buffer
+    const int32_t step_last = -(kTileRows - 2 * kHm2Chunk) * 8 + (bsel ? -(int32_t)tile_bytes : (int32_t)tile_bytes);
+    // the pipeline variants of this wave's two halves (wave-uniform, the same for every tile): a
+    // pair that reads more column slots than the terms need is always right (the leading slots of
+    // shorter terms are the ones column), so the combinations not instantiated round up
+#define OB_HM2_TILE(A_, B_) \
+  hm2_tile<W, NU, INFL, RO, SIN, (A_) < 1 ? 1 : (A_), (B_) < 1 ? 1 : (B_)>(c, live, red, wt, avl, avstride, wave, lane, step_last, totrow)
+    if (web == W)
+      OB_HM2_TILE(W, W);
+    else if (wea == W && web == W - 1)
+      OB_HM2_TILE(W, W - 1);
+    else if (wea == W)
+      OB_HM2_TILE(W, W);
+    else if (web == W - 1)
+      OB_HM2_TILE(W - 1, W - 1);
+    else if (wea == W - 1 && web == W - 2)
+      OB_HM2_TILE(W - 1, W - 2);
+    else if (wea == W - 1)
+      OB_HM2_TILE(W - 1, W - 1);
+    else if (web == W - 2)
+      OB_HM2_TILE(W - 2, W - 2);
+    else if (wea == W - 2)
+      OB_HM2_TILE(W - 2, W - 3);
+    else
+      OB_HM2_TILE(W - 3, W - 3);
+#undef OB_HM2_TILE
     if (RO && wave == 0) {
       const uint64_t row = tile * kTileRows + lane;
       if (row < n) {
