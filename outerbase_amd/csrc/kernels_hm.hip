@@ -82,12 +82,13 @@ __device__ __forceinline__ void hm2_dma_col(const char *g /* uniform */, uint32_
 }
 
 // one sub-chunk of 4 rows (tile rows rc .. rc + 3; the addresses in c.ad point ROW0 rows before).
-// WEA / WEB: column reads per term of the first / second half of the lane's units -- compile-time
-// here (k_tmm_tl picks the pipeline variant with a branch per chunk; in this kernel the registers
-// of prod / acc / s differed between the branches and every join cost ~10 v_mov_b64, 13 % of the
-// kernel's VALU instructions: the choice is made once per tile instead, hm2_tile)
-template <int W, int NU, int ROW0, int INFL, bool RO, bool SIN, int WEA, int WEB>
-__device__ __forceinline__ void hm2_subchunk(Hm2Ctx<W, NU, SIN> &c, bool live, double *red_half,
+// wea / web: column reads per term of the first / second half of the lane's units (the pipeline
+// variant is picked by a wave-uniform branch per sub-chunk, as in k_tmm_tl.  The joins of those
+// branches cost ~10 v_mov_b64 each, 13 % of the kernel's VALU instructions; making the choice once
+// per tile instead -- nine instantiations of the whole row loop behind one dispatch -- was built and
+// measured: 70-200 spilled registers, some reloaded inside the loops, 1.43 -> 2.19 ms.)
+template <int W, int NU, int ROW0, int INFL, bool RO, bool SIN>
+__device__ __forceinline__ void hm2_subchunk(Hm2Ctx<W, NU, SIN> &c, bool live, int wea, int web, double *red_half,
                                              const double *wts /* [2][64] of this tile */,
                                              const double *avl /* !SIN: a of this lane's unit 0 */, int avstride,
                                              int wave, int lane, int rc, double &totrow) {
@@ -95,10 +96,10 @@ __device__ __forceinline__ void hm2_subchunk(Hm2Ctx<W, NU, SIN> &c, bool live, d
   for (int r = 0; r < kHm2Chunk; ++r) c.s[r] = 0.0;
   if (live) {  // (a wave without terms keeps prod = 0)
     if constexpr (NU == 1) {
-      TlPipe<WEA, W, 1, kHm2Chunk, INFL, 0, ROW0>::run(c);
+      tl_run_half<W, 1, kHm2Chunk, INFL, 0, ROW0>(c, wea);
     } else {
-      TlPipe<WEA, W, NU / 2, kHm2Chunk, INFL, 0, ROW0>::run(c);
-      TlPipe<WEB, W, NU - NU / 2, kHm2Chunk, INFL, NU / 2, ROW0>::run(c);
+      tl_run_half<W, NU / 2, kHm2Chunk, INFL, 0, ROW0>(c, wea);
+      tl_run_half<W, NU - NU / 2, kHm2Chunk, INFL, NU / 2, ROW0>(c, web);
     }
   }
   if constexpr (!SIN) {  // s[r] = sum_u a_u prod[u][r] of this lane's terms, coefficients from LDS
@@ -146,17 +147,17 @@ __device__ __forceinline__ void hm2_subchunk(Hm2Ctx<W, NU, SIN> &c, bool live, d
 
 // the 64 rows of the staged tile: 8 x two sub-chunks; step_last moves the addresses to row 0 of the
 // other tile buffer after the last rows
-template <int W, int NU, int INFL, bool RO, bool SIN, int WEA, int WEB>
-__device__ __forceinline__ void hm2_tile(Hm2Ctx<W, NU, SIN> &c, bool live, double *red, const double *wt,
+template <int W, int NU, int INFL, bool RO, bool SIN>
+__device__ __forceinline__ void hm2_tile(Hm2Ctx<W, NU, SIN> &c, bool live, int wea, int web, double *red, const double *wt,
                                          const double *avl, int avstride, int wave, int lane,
                                          int32_t step_last, double &totrow) {
 #pragma unroll 1
   for (int rc = 0; rc < kTileRows; rc += 2 * kHm2Chunk) {
     // two sub-chunks per address update: the second reads at immediate row offsets 4 .. 7; the
     // cross-wave sums alternate between the two halves of red
-    hm2_subchunk<W, NU, 0, INFL, RO, SIN, WEA, WEB>(c, live, red, wt, avl, avstride, wave, lane, rc, totrow);
-    hm2_subchunk<W, NU, kHm2Chunk, INFL, RO, SIN, WEA, WEB>(c, live, red + kHm2RedSlots, wt, avl, avstride,
-                                                            wave, lane, rc + kHm2Chunk, totrow);
+    hm2_subchunk<W, NU, 0, INFL, RO, SIN>(c, live, wea, web, red, wt, avl, avstride, wave, lane, rc, totrow);
+    hm2_subchunk<W, NU, kHm2Chunk, INFL, RO, SIN>(c, live, wea, web, red + kHm2RedSlots, wt, avl, avstride,
+                                                  wave, lane, rc + kHm2Chunk, totrow);
     const int32_t step = rc + 2 * kHm2Chunk < kTileRows ? 2 * kHm2Chunk * 8 : step_last;
 #pragma unroll
     for (int u = 0; u < NU; ++u)
@@ -243,7 +244,13 @@ k_hm2(const double *__restrict__ bm, const double *__restrict__ scale, const uin
     const uint32_t l0 = lds0 + (bsel ? tile_bytes : 0u);
     for (int u = wave; u < Mu; u += WAVES) {
       const uint32_t col = __builtin_amdgcn_readfirstlane(ucol[u]);
-      hm2_dma_col(tb + (size_t)col * (kTileRows * 8), (uint32_t)lane * 4u, l0 + (uint32_t)u * (kTlPitch * 8));
+      // (the address is wave-uniform; said explicitly, so that it reaches the "s" operands of the
+      // asm in scalar registers whatever the optimiser made of the surrounding code)
+      const uint64_t ga = (uint64_t)(tb + (size_t)col * (kTileRows * 8));
+      const uint64_t gu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ga >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ga);
+      hm2_dma_col((const char *)gu, (uint32_t)lane * 4u,
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(l0 + (uint32_t)u * (kTlPitch * 8))));
     }
   };
   if (t0 < t1) prefetch(t0, 0);
@@ -262,30 +269,7 @@ k_hm2(const double *__restrict__ bm, const double *__restrict__ scale, const uin
     double totrow = 0.0;  // lane = row: sum_k a_k prod_k of this tile's row
     // after the last rows: row 0 of the other buffer
     const int32_t step_last = -(kTileRows - 2 * kHm2Chunk) * 8 + (bsel ? -(int32_t)tile_bytes : (int32_t)tile_bytes);
-    // the pipeline variants of this wave's two halves (wave-uniform, the same for every tile): a
-    // pair that reads more column slots than the terms need is always right (the leading slots of
-    // shorter terms are the ones column), so the combinations not instantiated round up
-#define OB_HM2_TILE(A_, B_) \
-  hm2_tile<W, NU, INFL, RO, SIN, (A_) < 1 ? 1 : (A_), (B_) < 1 ? 1 : (B_)>(c, live, red, wt, avl, avstride, wave, lane, step_last, totrow)
-    if (web == W)
-      OB_HM2_TILE(W, W);
-    else if (wea == W && web == W - 1)
-      OB_HM2_TILE(W, W - 1);
-    else if (wea == W)
-      OB_HM2_TILE(W, W);
-    else if (web == W - 1)
-      OB_HM2_TILE(W - 1, W - 1);
-    else if (wea == W - 1 && web == W - 2)
-      OB_HM2_TILE(W - 1, W - 2);
-    else if (wea == W - 1)
-      OB_HM2_TILE(W - 1, W - 1);
-    else if (web == W - 2)
-      OB_HM2_TILE(W - 2, W - 2);
-    else if (wea == W - 2)
-      OB_HM2_TILE(W - 2, W - 3);
-    else
-      OB_HM2_TILE(W - 3, W - 3);
-#undef OB_HM2_TILE
+    hm2_tile<W, NU, INFL, RO, SIN>(c, live, wea, web, red, wt, avl, avstride, wave, lane, step_last, totrow);
     if (RO && wave == 0) {
       const uint64_t row = tile * kTileRows + lane;
       if (row < n) {
