@@ -404,7 +404,7 @@ def kernel_profile(hp, _lib, torch, nprof=2):
         hp.step()
     torch.cuda.synchronize()
     prof = {}
-    for name in ["build_basis", "materialize_B", "gram", "gram_reduce", "tmm", "mm", "sqtmm", "hessmult",
+    for name in ["build_basis", "materialize_B", "gram", "gram_reduce", "tmm", "mm", "sqtmm", "tmm_dual", "hessmult",
                  "exchange", "unpack_form", "form_hessian", "cholesky", "backsolve", "predict"]:
         cnt, ms = C.c_uint64(0), C.c_double(0)
         _lib.call("obhip_profile_get", name.encode(), C.byref(cnt), C.byref(ms))

@@ -514,7 +514,9 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
   double logsd = 0;  // sum(log(coeffsd * sca)), logpr_gauss.cpp:101
   for (uint64_t k = 0; k < p; ++k) logsd += std::log(std::sqrt(tv[k]) * std::exp(rho));
 
-  DevBuf<double> yhat, r, tmp, dpv, vec, dprec, scal;
+  DevBuf<double> yhat, r, tmp, dpv, vec, dprec, scal, ddiag;
+  OB_TRY(ddiag.alloc(p));
+  bool diag_done = false;  // the cold start takes sqcolsums along with B^T r (k_tmm_tl<DUAL>)
   OB_TRY(yhat.alloc(n));
   OB_TRY(r.alloc(n));
   OB_TRY(tmp.alloc(n));
@@ -559,7 +561,14 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
       else
         OB_TRY(launch_mm(*b, t, v.theta, yhat.p, false));      // loglik_gauss.cpp:117
       OB_TRY(launch_resid(yhat.p, d_y, n, e2, r.p, tmp.p));    // :118-124
-      OB_TRY(launch_tmm(*b, t, r.p, dpv.p, false));            // :125
+      // :125, and on the first update the preconditioner's sqcolsums in the same pass
+      int dual = diag_done ? kNotFused : launch_tmm_dual(*b, t, r.p, dpv.p, nullptr, ddiag.p);
+      if (dual != kNotFused) {
+        OB_TRY(dual);
+        diag_done = true;
+      } else {
+        OB_TRY(launch_tmm(*b, t, r.p, dpv.p, false));
+      }
       OB_TRY(launch_sum_sumsq(tmp.p, n, dpv.p + p, red));
     }
     theta_zero = false;
@@ -585,10 +594,12 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
 
   OB_TRY(update());
   // m = diaghess(): e^{-2 sigma} sqcolsums + prior (loglik_gauss.cpp:154-157)
-  OB_TRY(launch_fill(tmp.p, n, 1.0));
-  OB_TRY(launch_tmm(*b, t, tmp.p, dpv.p, true));
-  if (many) OB_TRY(comm_allreduce(comm, dpv.p, p));
-  hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(kCgThreads), 0, st, v, dpv.p, e2, scal.p);
+  if (!diag_done) {
+    OB_TRY(launch_fill(tmp.p, n, 1.0));
+    OB_TRY(launch_tmm(*b, t, tmp.p, ddiag.p, true));
+  }
+  if (many) OB_TRY(comm_allreduce(comm, ddiag.p, p));
+  hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(kCgThreads), 0, st, v, ddiag.p, e2, scal.p);
   OB_HIP(hipGetLastError());
   double hs[S_COUNT];
   OB_TRY(d2h(hs, scal.p, sizeof hs));

@@ -275,25 +275,31 @@ k_tmm(const double *__restrict__ bm, const double *__restrict__ scale,
 // NPAIR x 2 x 64 consecutive slots of a wave then hold terms of nearly one length, and the wave
 // runs the pipeline instantiated for that length (TlPipe<WE, ...>): at the benchmark size
 // 25 instead of 32 column reads per lane and row.
-template <int W, int NU>
+// DUAL: B^T a and (B^2)^T a2 in one pass -- the products are formed once, the squares are one more
+// multiply and multiply-add per (term, row): the cold start of the PCG needs e^{-2 sigma} B^T y
+// and the preconditioner's sqcolsums (loglik_gauss.cpp:125,154-157), which were two passes.
+template <int W, int NU, bool DUAL = false>
 struct TmmCtx {
   uint32_t ad[NU][W];
   double acc[NU];
-  double vs;  // weight of row = lane
-  double vr;  // weight of the current row, wave-uniform
-  int rc;     // first row of the chunk
+  double acc2[DUAL ? NU : 1];
+  double vs, vs2;  // weights of row = lane (vs2: of the squared products)
+  double vr, vr2;  // weights of the current row, wave-uniform
+  int rc;          // first row of the chunk
   template <int RR>
   __device__ __forceinline__ void row() {
     vr = readlane_f64(vs, rc + RR);
+    if constexpr (DUAL) vr2 = readlane_f64(vs2, rc + RR);
   }
   template <int RR, int UNIT>
   __device__ __forceinline__ void use(double v) {
     acc[UNIT] = fma(v, vr, acc[UNIT]);
+    if constexpr (DUAL) acc2[UNIT] = fma(v * v, vr2, acc2[UNIT]);
   }
 };
 
-template <int W, int NU>
-__device__ __forceinline__ void tmm_tile(TmmCtx<W, NU> &c, int wea, int web) {
+template <int W, int NU, bool DUAL>
+__device__ __forceinline__ void tmm_tile(TmmCtx<W, NU, DUAL> &c, int wea, int web) {
   // 8 units x W addresses already fill the register budget: 8 reads in flight instead of 12
   constexpr int kInflight = NU * W >= 32 ? 8 : 12;
 #pragma unroll 1
@@ -317,13 +323,15 @@ __device__ __forceinline__ void tmm_tile(TmmCtx<W, NU> &c, int wea, int web) {
   }
 }
 
-template <int W2, bool SQ, int NPAIR, bool PREFETCH>
+template <int W2, bool SQ, int NPAIR, bool PREFETCH, bool DUAL = false>
 __global__ void __launch_bounds__(kTlThreads, 4)
 k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
          const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc,
          const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm,
          const double *__restrict__ a, uint64_t n, uint64_t ntiles, uint64_t tiles_per_split,
-         uint64_t p_pad, double *__restrict__ part) {
+         uint64_t p_pad, double *__restrict__ part, const double *__restrict__ a2 = nullptr,
+         double *__restrict__ part2 = nullptr) {
+  static_assert(!(DUAL && SQ), "DUAL forms the squares from the plain products");
   extern __shared__ double lds[];
   constexpr int W = 2 * W2, NU = NPAIR * kTlGP;
   const int lane = threadIdx.x & 63;
@@ -333,7 +341,7 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
 
   // my terms: NU * 64 consecutive slots of the sorted order (tl_slot); the two halves of the
   // units get their own pipeline width
-  TmmCtx<W, NU> c;
+  TmmCtx<W, NU, DUAL> c;
   int nza = 1, nzb = 1;
   bool live = false;
 #pragma unroll
@@ -343,6 +351,7 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
     live = live || ok;
     const uint64_t k = ok ? sperm[slot] : 0;
     c.acc[u] = 0.0;
+    if constexpr (DUAL) c.acc2[u] = 0.0;
     uint32_t cw[W2];
 #pragma unroll
     for (int w = 0; w < W2; ++w) {
@@ -368,13 +377,15 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
       lu[q] = u < Mu ? __builtin_amdgcn_readfirstlane((int)ucol[u] * kTileRows) : 0;
     }
   }
-  double vsn = 0.0;
+  double vsn = 0.0, vs2n = 0.0;
   auto weight = [&](uint64_t tile) {
     const uint64_t row = tile * kTileRows + lane;
     double v = 0.0;
+    vs2n = 0.0;
     if (row < n) {
       const double sc = scale[row];
       v = a[row] * (SQ ? sc * sc : sc);  // b = basescale % a, linalg.cpp:305
+      if (DUAL) vs2n = (a2 ? a2[row] : 1.0) * sc * sc;
     }
     return v;
   };
@@ -398,6 +409,7 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
         if (u < Mu) lds[u * kTlPitch + lane] = SQ ? pre[q] * pre[q] : pre[q];
       }
       c.vs = vsn;
+      c.vs2 = vs2n;
     } else {
       const double *src = bm + tile * Mc * kTileRows + lane;
       for (int u = wave; u < Mu; u += kTlWaves) {
@@ -405,16 +417,20 @@ k_tmm_tl(const double *__restrict__ bm, const double *__restrict__ scale,
         lds[u * kTlPitch + lane] = SQ ? v * v : v;
       }
       c.vs = weight(tile);
+      c.vs2 = vs2n;
     }
     __syncthreads();
     if (PREFETCH && tile + 1 < t1) fetch(tile + 1);
     if (!live) continue;  // (whole waves beyond p_pad in the last block along p)
-    tmm_tile<W, NU>(c, wea, web);
+    tmm_tile<W, NU, DUAL>(c, wea, web);
   }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const uint64_t slot = tl_slot<NU>(blockIdx.y, wave, u, lane);
-    if (slot < p_pad) part[(uint64_t)blockIdx.x * p_pad + sperm[slot]] = c.acc[u];
+    if (slot < p_pad) {
+      part[(uint64_t)blockIdx.x * p_pad + sperm[slot]] = c.acc[u];
+      if constexpr (DUAL) part2[(uint64_t)blockIdx.x * p_pad + sperm[slot]] = c.acc2[u];
+    }
   }
 }
 
@@ -1248,6 +1264,54 @@ int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B, con
                        ypart, (int)nsplit, t.p_pad, (int)t.p, d_g);
     OB_HIP(hipGetLastError());
   }
+  return 0;
+}
+
+// d_out (p) = B^T a and d_out2 (p) = (B^2)^T a2 (a2 null: ones -> sqcolsums) in ONE pass of
+// k_tmm_tl<DUAL>; kNotFused when the terms do not fit that instantiation (more than 4 factors, a
+// tile beyond the prefetch registers): the caller then makes the two passes.
+int launch_tmm_dual(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, const double *d_a2,
+                    double *d_out2) {
+  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  static const bool off = getenv("OBHIP_TMM_DUAL") && atoi(getenv("OBHIP_TMM_DUAL")) == 0;
+  const int w2 = (int)(t.W / 2);
+  if (off || beyond_lds(t) || !tmm_tl_supports(t) || w2 > 2 || t.Mu > (uint64_t)kTlWaves * kTlPre) return kNotFused;
+  const uint64_t ntiles = b.n_pad / kTileRows, p_pad = t.p_pad;
+  int npair = 1;
+  while (npair < 4 && (uint64_t)kTlWaves * npair * kTlGP * 64 < p_pad) npair *= 2;
+  const uint64_t tpb = (uint64_t)kTlWaves * npair * kTlGP * 64;
+  const uint64_t pblocks = (p_pad + tpb - 1) / tpb;
+  uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)device_cus(b.device) * 2 / pblocks);
+  nsplit = std::min(nsplit, std::max<uint64_t>(1, ntiles / 4));
+  const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  double *part = nullptr;
+  OB_TRY(const_cast<obhip_basis &>(b).workspace(2 * nsplit * p_pad * sizeof(double), (void **)&part));
+  double *part2 = part + nsplit * p_pad;
+  const dim3 grid((unsigned)nsplit, (unsigned)pblocks);
+  const size_t lds = t.Mu * kTlPitch * sizeof(double);
+  {
+    ProfScope ps("tmm_dual");
+#define OB_TD(W2_, NP_)                                                                                      \
+  do {                                                                                                       \
+    OB_TRY(set_lds(k_tmm_tl<W2_, false, NP_, true, true>, lds));                                             \
+    hipLaunchKernelGGL((k_tmm_tl<W2_, false, NP_, true, true>), grid, dim3(kTlThreads), lds, cur_stream(),   \
+                       b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,          \
+                       t.sperm.p, d_a, b.n, ntiles, tps, p_pad, part, d_a2, part2);                          \
+  } while (0)
+    if (w2 == 1) {
+      if (npair == 4) OB_TD(1, 4); else if (npair == 2) OB_TD(1, 2); else OB_TD(1, 1);
+    } else {
+      if (npair == 4) OB_TD(2, 4); else if (npair == 2) OB_TD(2, 2); else OB_TD(2, 1);
+    }
+#undef OB_TD
+    OB_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0, cur_stream(), part,
+                     (int)nsplit, p_pad, (int)t.p, d_out);
+  hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0, cur_stream(), part2,
+                     (int)nsplit, p_pad, (int)t.p, d_out2);
+  OB_HIP(hipGetLastError());
   return 0;
 }
 

@@ -300,6 +300,9 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a,
 constexpr int kNotFused = -1;
 int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y,
                           double ca, double cb, double *d_out, double *d_yhat, double *d_ss);
+// d_out = B^T a and d_out2 = (B^2)^T a2 (a2 null: ones) in one pass; kNotFused: make two passes
+int launch_tmm_dual(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, const double *d_a2,
+                    double *d_out2);
 // kernels_generic.hip: any number of used columns / factors, columns read from HBM
 int launch_mm_generic(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, int mode,
                       uint64_t ld);

@@ -1179,14 +1179,18 @@ def test_term_per_lane_variants(max_nnz, p, maxlev):
             assert relerr(lik.hessmult(a), e2 * (Bd.T @ (Bd @ a))) < 1e-11
             if n <= 1100 and maxlev < 12:
                 sig0 = float(lik.para[0])
-                th_o, it_o, _ = O.fit_cg(O.OuterBase(om_o, x), terms, v, sigma=sig0, tol=1e-30, maxit=3)
+                th_o, it_o, m_o = O.fit_cg(O.OuterBase(om_o, x), terms, v, sigma=sig0, tol=1e-30, maxit=3)
                 th = np.zeros(terms.shape[0])
+                dh = np.empty(terms.shape[0])
                 its = C.c_uint64(0)
                 yv = np.ascontiguousarray(v)
                 call("obhip_fit_cg", bd._h, tt._h, om_d._h, ptr(yv), sig0, 6.0, 1e-30, 3, ptr(th),
-                     C.byref(its), None, None)
+                     C.byref(its), ptr(dh), None)
                 assert its.value == it_o == 3
                 assert relerr(th, th_o) < (1e-5 if maxlev >= 5 else 1e-8)
+                # the preconditioner e^{-2 sigma} sqcolsums + prior (fit.cpp:51): since round 4 taken
+                # along with B^T r by the cold start's one pass (k_tmm_tl<DUAL>) where the terms allow
+                assert relerr(dh, m_o) < 1e-10
 
 
 @pytest.mark.parametrize("seed", range(16))
