@@ -230,6 +230,20 @@ def test_no_gpu_fails_loudly():
     from outerbase_amd import _lib
     p = C.c_void_p()
     assert _lib.lib.obhip_malloc(C.byref(p), 64) == 2
+    # the communicator entry points of ABI 4: virtual ranks need the device too; argument errors
+    # come back as OBHIP_ERR_INVALID, never as a crash
+    h = C.c_void_p()
+    assert _lib.lib.obhip_comm_init_sim(C.byref(h), 8) == 2
+    assert _lib.lib.obhip_comm_selftest_dev(None, 100, None) == 1
+    assert _lib.lib.obhip_comm_exchange_path(None, 100, None, None) == 1
+    # a host communicator needs no device to exist; its exchange path is reported, its self-test
+    # (device buffers) is refused without a GPU
+    assert _lib.lib.obhip_comm_init_host(C.byref(h), 1, 0, None, None) == 0
+    path, st = C.c_int(-1), C.c_int(-1)
+    assert _lib.lib.obhip_comm_exchange_path(h, 1 << 20, C.byref(path), C.byref(st)) == 0
+    assert (path.value, st.value) == (3, 0)
+    assert _lib.lib.obhip_comm_selftest_dev(h, 100, None) == 2
+    _lib.lib.obhip_comm_destroy(h)
 
 
 def test_product_path_never_imports_the_oracle():

@@ -1,7 +1,9 @@
 """Prints the figures of a bench.py line that one looks at first (aid for gpurun output)."""
 import json
 import sys
-d = json.load(open(sys.argv[1]))
+# (a launcher's own chatter may share the file -- gloo prints its connections to stdout: the bench
+# line is the one that starts with a brace)
+d = json.loads([ln for ln in open(sys.argv[1]) if ln.startswith("{")][-1])
 print("value %.4g %s  ms_per_step %.2f  n_gpus %d" % (d["value"], d["unit"], d["ms_per_step"], d["n_gpus"]))
 r = d.get("roofline") or {}
 print("roofline: %s frac %.4f achieved %.2f %s traffic %s mfma_util %s l2 %s" % (
