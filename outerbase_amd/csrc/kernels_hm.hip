@@ -323,17 +323,26 @@ int run_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const doubl
 
 }  // namespace
 
-// two tile buffers, the row weights, the wave partials, and the coefficient vector of the forms
-// that keep it in LDS (one slot per lane and unit: p_pad rounded up to the largest block shape)
-size_t hm2_lds_bytes(const obhip_terms &t) {
-  const size_t slots = (t.p_pad + 1023) / 1024 * 1024 * 3 / 2;  // (12 waves x 6 units cover 4608)
+// two tile buffers, the row weights, the wave partials and -- for the instantiations that keep
+// it in LDS (launch_hm2 below: 4 terms per lane in the update() form or with 6-factor terms) -- the
+// coefficient vector, one slot per lane and unit
+size_t hm2_lds_bytes(const obhip_terms &t, bool ro, int variant) {
+  const int w2 = (int)(t.W / 2);
+  const int nu = t.p_pad <= 1024 ? 1 : (t.p_pad <= 2048 ? 2 : 4);
+  size_t slots = 0;
+  if (variant == 2 || variant == 3)
+    slots = ro ? 4608 : 0;  // (12 waves x 6 units, 8 x 8: the experiments at 4-factor terms)
+  else if (nu == 4 && (ro || w2 == 3 || variant == 5))
+    slots = 4096;
   return ((size_t)2 * t.Mu * kTlPitch + 2 * 128 + 2 * kHm2RedSlots + slots) * sizeof(double);
 }
 
-// the terms this kernel takes (launch_hessmult_fused asks before it falls back to k_hm_tl)
-bool hm2_supports(const obhip_terms &t) {
+// the terms this kernel takes in the form asked for (launch_hessmult_fused asks before it falls
+// back to k_hm_tl): up to 147 used columns for the Hessian product at 4-factor terms, 118 where the
+// coefficients live in LDS too
+bool hm2_supports(const obhip_terms &t, bool ro, int variant) {
   const int w2 = (int)(t.W / 2);
-  return w2 >= 1 && w2 <= 3 && t.p_pad <= 4096 && hm2_lds_bytes(t) <= (size_t)156 * 1024;
+  return w2 >= 1 && w2 <= 3 && t.p_pad <= 4096 && hm2_lds_bytes(t, ro, variant) <= (size_t)156 * 1024;
 }
 
 // variant: 0 = automatic; experiments at 4-factor terms (OBHIP_HM2_VARIANT): 2 = 12 waves x 6
@@ -342,7 +351,7 @@ bool hm2_supports(const obhip_terms &t) {
 int launch_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,
                double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
                uint64_t tps, int variant) {
-  const size_t lds = hm2_lds_bytes(t);
+  const size_t lds = hm2_lds_bytes(t, d_y != nullptr, variant);
   const int w2 = (int)(t.W / 2);
   const uint64_t pp = t.p_pad;
 #define OB_HM2(W2_, NU_, WAVES_, INFL_, SIN_) \

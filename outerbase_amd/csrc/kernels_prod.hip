@@ -1402,7 +1402,7 @@ int run_hm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, const dou
 
 // kernels_hm.hip: the second-generation kernel (two tile buffers fed by LDS-direct loads, four
 // waves per SIMD) and the terms it takes
-bool hm2_supports(const obhip_terms &t);
+bool hm2_supports(const obhip_terms &t, bool ro, int variant);
 int launch_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,
                double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
                uint64_t tps, int variant);
@@ -1415,7 +1415,7 @@ int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_
   static const bool v1 = getenv("OBHIP_HM_V1") && atoi(getenv("OBHIP_HM_V1")) != 0;
   static const int variant = getenv("OBHIP_HM2_VARIANT") ? atoi(getenv("OBHIP_HM2_VARIANT")) : 0;
   const int w2 = (int)(t.W / 2);
-  const bool use2 = !off && !v1 && !beyond_lds(t) && hm2_supports(t);
+  const bool use2 = !off && !v1 && !beyond_lds(t) && hm2_supports(t, d_y != nullptr, variant);
   // (8 terms of 6 factors per lane spill and run at half the speed of the two-kernel form: measured)
   const int numax = w2 <= 2 ? 8 : 4;
   if (!use2 &&

@@ -1193,6 +1193,43 @@ def test_term_per_lane_variants(max_nnz, p, maxlev):
                 assert relerr(dh, m_o) < 1e-10
 
 
+@pytest.mark.parametrize("d,maxlev,want_mu", [(26, 5, 131), (30, 4, 121), (16, 6, 97)])
+def test_fused_hessian_product_between_its_two_lds_limits(d, maxlev, want_mu):
+    """k_hm2 keeps two tiles of the used columns in LDS: up to 147 columns for the Hessian product
+    at 4 terms per lane, 118 for its update() form (which also keeps the coefficients there).
+    131 columns: the Hessian products take k_hm2, the update() passes fall back to k_hm_tl;
+    121: likewise; 97: both take k_hm2.  loglik_gauss$hessmult against B^T (B a) from getmat, and
+    three iterations of the device PCG (update() at the start, Hessian products after) against
+    the oracle's lpdf::optcg."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    from outerbase_amd._lib import call, ptr
+    kinds = ["mat25"] * d
+    om_o, om_d = make_pair(kinds, knots_for(kinds, 20))
+    rng = np.random.default_rng(d)
+    n, p = 700, 3000
+    x = sample_x(rng, n, kinds)
+    terms = random_terms(rng, p, d, maxlev, 4)
+    for l in range(d):                      # every level of every dimension is used somewhere
+        terms[1 + l * maxlev:1 + (l + 1) * maxlev, :] = 0
+        terms[1 + l * maxlev:1 + (l + 1) * maxlev, l] = np.arange(1, maxlev + 1)
+    tt = ob.obmod._Terms(om_d, terms)
+    assert 1 + int(tt.maxlevels().sum()) == want_mu
+    v = rng.standard_normal(n)
+    a = rng.standard_normal(p)
+    lik = ob.loglik_gauss(om_d, terms, v, x)
+    Bd = lik.ob.getmat(terms)
+    e2 = math.exp(-2 * lik.para[0])
+    assert relerr(lik.hessmult(a), e2 * (Bd.T @ (Bd @ a))) < 1e-11
+    sig0 = float(lik.para[0])
+    th_o, it_o, m_o = O.fit_cg(O.OuterBase(om_o, x), terms, v, sigma=sig0, tol=1e-30, maxit=3)
+    th, dh, its = np.zeros(p), np.empty(p), C.c_uint64(0)
+    call("obhip_fit_cg", lik.ob._h, tt._h, om_d._h, ptr(np.ascontiguousarray(v)), sig0, 6.0, 1e-30, 3,
+         ptr(th), C.byref(its), ptr(dh), None)
+    assert its.value == it_o == 3
+    assert relerr(th, th_o) < 1e-7 and relerr(dh, m_o) < 1e-10
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_random_lpdf_level_quantities(seed):
     """Third fuzz: the lpdf-level values and gradients (loglik_gauss / loglik_std /
