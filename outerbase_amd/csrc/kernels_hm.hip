@@ -19,11 +19,14 @@
 //     a SECOND tile buffer -- no prefetch registers (32 VGPRs in k_hm_tl), no staging ds_writes;
 //   * the register budget that frees goes into occupancy: 16 waves x 4 terms per lane at
 //     <= 128 VGPRs (four waves per SIMD, 12 reads in flight each) instead of 8 waves x 8 terms;
-//   * the row weights vA = c_a s^2, vB = c_b s y live in LDS (written once per tile), so the
-//     post-barrier phase is one LDS read of the wave partials, DPP / permlane adds and
-//     v_readlane -- no ds_bpermute.
-// Limits: terms of at most 4 factors (W2 <= 2), p_pad <= WAVES * NU * 64, two tiles of the used
-// columns in LDS (Mu <= 147); anything else takes k_hm_tl or the two-kernel form.
+//   * the row weights vA = c_a s^2, vB = c_b s y live in LDS (written once per tile) and the wave
+//     partials are laid out [row][wave], so the post-barrier phase is one LDS read, four DPP
+//     rotate-adds and v_readlane -- no ds_bpermute;
+//   * steps 1 and 3 ride in the read pipeline (Hm2Ctx below).
+// Measured at the headline terms: 1.70 -> 1.43 ms, of which the read
+// pipelines alone are 0.99 ms (LDS pipe ~80 % busy) and the reduction / exchange phases alone 0.52.
+// Limits: terms of at most 6 factors (W2 <= 3), p_pad <= 4096, two tiles of the used columns in
+// LDS (hm2_supports below); anything else takes k_hm_tl or the two-kernel form.
 #include "obhip_internal.h"
 #include "device_common.h"
 
@@ -32,12 +35,8 @@ namespace obhip {
 namespace {
 
 constexpr int kHm2Chunk = 4;
-constexpr int kHm2RedSlots = 64;  // [16 waves][4 rows] partial sums of one sub-chunk
+constexpr int kHm2RedSlots = 64;  // [4 rows][16 waves] partial sums of one sub-chunk
 
-// (the coefficients a_u of a lane's terms live in LDS, not in registers, and are applied after
-// the read pipeline of a sub-chunk has drained: 16 + 8 VGPRs less at the pipeline's peak, which is
-// what lets 4 terms per lane fit the 128 VGPRs of a 16-wave block without spills)
-//
 // Step 3 of sub-chunk i (acc[u] += prod[u][r] w_r) is not done behind the barrier: the weights
 // stay in four scalar register pairs (wprev) and every product of sub-chunk i is accumulated
 // immediately before the read pipeline of sub-chunk i + 1 overwrites it -- 16 multiply-adds per
@@ -72,6 +71,7 @@ struct Hm2Ctx {
 // one from the short end) was measured SLOWER, 1.484 -> 1.521 ms at the headline terms: with all
 // waves equally long their reduction phases coincide and the LDS pipe idles through them, whereas
 // unequal waves reduce while the long ones still read.)
+
 // one wave instruction pair: the 512 bytes of a basis column (64 rows) from g to LDS at l
 // (lane l: dword at g + 4 l -> LDS l + 4 l, then the same 256 bytes on)
 __device__ __forceinline__ void hm2_dma_col(const char *g /* uniform */, uint32_t voff /* 4 lane */,
