@@ -579,8 +579,13 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
     return 0;
   };
   // q = lpdfvec::hessmult(pv): loglik_gauss.cpp:137-145 + logpr_gauss.cpp:113-115
-  auto hessmult = [&]() -> int {
-    const int fused = launch_hessmult_fused(*b, t, v.pv, nullptr, 1.0, 0.0, dpv.p, nullptr, nullptr);
+  // spec: enqueued BEFORE the host has read the break conditions of the step that precedes it (the
+  // GPU then works through the host round trip); the kernel itself returns at once when the step
+  // said stop (S_DONE) or that the next iteration would stop at its opening test (S_NEXT)
+  const bool can_spec = hessmult_fused_skippable(*b, t);
+  auto hessmult = [&](bool spec = false) -> int {
+    const int fused = launch_hessmult_fused(*b, t, v.pv, nullptr, 1.0, 0.0, dpv.p, nullptr, nullptr,
+                                            spec ? scal.p + S_DONE : nullptr, spec ? scal.p + S_NEXT : nullptr);
     if (fused != kNotFused) OB_TRY(fused);
     if (fused == kNotFused) {
       OB_TRY(launch_mm(*b, t, v.pv, yhat.p, false));
@@ -633,6 +638,8 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
         hipLaunchKernelGGL(k_cg_iter<2>, dim3(1), dim3(kCgThreads), 0, st, v, tol, scal.p);
         OB_HIP(hipGetLastError());
       }
+      const bool spec = can_spec && !full;
+      if (spec) OB_TRY(hessmult(true));
       OB_TRY(d2h(hs, scal.p, (S_NEXT + 1) * sizeof(double)));  // the host sync of an iteration
       if (hs[S_DONE] != 0.0) break;
       exact = full;
@@ -640,7 +647,7 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
         ++k;                    // and its Hessian product is not needed
         break;
       }
-      OB_TRY(hessmult());
+      if (!spec) OB_TRY(hessmult());
     }
     // the value reported is a true evaluation (callers that re-evaluate anyway pass
     // val_out = NULL and save the two passes)

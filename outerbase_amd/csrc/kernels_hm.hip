@@ -176,7 +176,12 @@ k_hm2(const double *__restrict__ bm, const double *__restrict__ scale, const uin
       int Mu, uint64_t Mc, const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm,
       const double *__restrict__ a, int p, const double *__restrict__ y, double ca, double cb, uint64_t n,
       uint64_t ntiles, uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ part,
-      double *__restrict__ yhat, double *__restrict__ sspart) {
+      double *__restrict__ yhat, double *__restrict__ sspart, const double *__restrict__ stop0,
+      const double *__restrict__ stop1) {
+  // a launch enqueued before the host has read the step's break conditions (the PCG loop of
+  // api.cpp does that, to keep the GPU busy through the host round trip): nothing to do when the
+  // iteration it was meant for will not happen
+  if (stop0 != nullptr && (*stop0 != 0.0 || *stop1 != 0.0)) return;
   extern __shared__ double lds[];
   constexpr int W = 2 * W2;
   const int lane = threadIdx.x & 63;
@@ -300,7 +305,7 @@ k_hm2(const double *__restrict__ bm, const double *__restrict__ scale, const uin
 template <int W2, int NU, int WAVES, int INFL, bool SIN>
 int run_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca, double cb,
             double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles, uint64_t tps,
-            size_t lds) {
+            size_t lds, const double *stop0, const double *stop1) {
   // (the update() form carries y, yhat and the residual sum: 8 reads in flight keep it free of spills)
 #define OB_HM2_LAUNCH(RO_)                                                                                  \
   do {                                                                                                      \
@@ -310,7 +315,7 @@ int run_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const doubl
     hipLaunchKernelGGL((k_hm2<W2, NU, WAVES, IF, RO_, SI>), dim3(nsplit), dim3(WAVES * 64), lds, cur_stream(), \
                        b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,         \
                        t.sperm.p, d_a, (int)t.p, d_y, ca, cb, b.n, ntiles, tps, t.p_pad, part, d_yhat,      \
-                       sspart);                                                                             \
+                       sspart, stop0, stop1);                                                               \
   } while (0)
   if (d_y != nullptr)
     OB_HM2_LAUNCH(true);
@@ -350,12 +355,13 @@ bool hm2_supports(const obhip_terms &t, bool ro, int variant) {
 // 6 = 16 x 4, sums in the pipeline, 12 reads in flight (2 spilled registers)
 int launch_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,
                double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
-               uint64_t tps, int variant) {
+               uint64_t tps, int variant, const double *stop0, const double *stop1) {
   const size_t lds = hm2_lds_bytes(t, d_y != nullptr, variant);
   const int w2 = (int)(t.W / 2);
   const uint64_t pp = t.p_pad;
 #define OB_HM2(W2_, NU_, WAVES_, INFL_, SIN_) \
-  return run_hm2<W2_, NU_, WAVES_, INFL_, SIN_>(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, nsplit, ntiles, tps, lds)
+  return run_hm2<W2_, NU_, WAVES_, INFL_, SIN_>(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, nsplit, ntiles, tps, lds, \
+                                                stop0, stop1)
   if (w2 == 2) {
     if (variant == 2 && pp <= 12 * 6 * 64) OB_HM2(2, 6, 12, 12, true);
     if (variant == 3 && pp <= 8 * 8 * 64) OB_HM2(2, 8, 8, 12, true);

@@ -1405,17 +1405,37 @@ int run_hm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, const dou
 bool hm2_supports(const obhip_terms &t, bool ro, int variant);
 int launch_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,
                double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
-               uint64_t tps, int variant);
+               uint64_t tps, int variant, const double *stop0, const double *stop1);
+
+namespace {
+bool hm2_wanted() {
+  static const bool off = getenv("OBHIP_HESSMULT_FUSED") && atoi(getenv("OBHIP_HESSMULT_FUSED")) == 0;
+  static const bool v1 = getenv("OBHIP_HM_V1") && atoi(getenv("OBHIP_HM_V1")) != 0;
+  return !off && !v1;
+}
+int hm2_variant() {
+  static const int variant = getenv("OBHIP_HM2_VARIANT") ? atoi(getenv("OBHIP_HM2_VARIANT")) : 0;
+  return variant;
+}
+}  // namespace
+
+// whether a Hessian product of these terms can be enqueued speculatively (it takes k_hm2, which
+// honours the stop flags of launch_hessmult_fused)
+bool hessmult_fused_skippable(const obhip_basis &b, obhip_terms &t) {
+  if (t.prepare(b.md.cap, b.md.dims_h) != 0) return false;
+  return hm2_wanted() && !beyond_lds(t) && hm2_supports(t, false, hm2_variant());
+}
 
 int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y,
-                          double ca, double cb, double *d_out, double *d_yhat, double *d_ss) {
+                          double ca, double cb, double *d_out, double *d_yhat, double *d_ss,
+                          const double *d_stop0, const double *d_stop1) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   static const bool off = getenv("OBHIP_HESSMULT_FUSED") && atoi(getenv("OBHIP_HESSMULT_FUSED")) == 0;
   // OBHIP_HM_V1=1: the round-3 kernel (A/B runs); OBHIP_HM2_VARIANT: block shapes of k_hm2
-  static const bool v1 = getenv("OBHIP_HM_V1") && atoi(getenv("OBHIP_HM_V1")) != 0;
-  static const int variant = getenv("OBHIP_HM2_VARIANT") ? atoi(getenv("OBHIP_HM2_VARIANT")) : 0;
+  const int variant = hm2_variant();
   const int w2 = (int)(t.W / 2);
-  const bool use2 = !off && !v1 && !beyond_lds(t) && hm2_supports(t, d_y != nullptr, variant);
+  const bool use2 = hm2_wanted() && !beyond_lds(t) && hm2_supports(t, d_y != nullptr, variant);
+  if (d_stop0 && !use2) return fail(OBHIP_ERR_STATE, "hessmult: stop flags need the k_hm2 path");
   // (8 terms of 6 factors per lane spill and run at half the speed of the two-kernel form: measured)
   const int numax = w2 <= 2 ? 8 : 4;
   if (!use2 &&
@@ -1436,7 +1456,8 @@ int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_
   double *sspart = d_ss ? part + nsplit * t.p_pad : nullptr;
   if (use2) {
     ProfScope ps("hessmult");
-    OB_TRY(launch_hm2(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps, variant));
+    OB_TRY(launch_hm2(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps, variant,
+                      d_stop0, d_stop1));
   } else {
     ProfScope ps("hessmult");
 #define OB_HM(W2_, NU_) OB_TRY((run_hm_tl<W2_, NU_>(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps))); break

@@ -298,8 +298,13 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a,
 // sum (B a - y)^2 when asked for.  Returns kNotFused (nothing done) when the terms do not fit the
 // fused kernel: the caller then composes launch_mm / launch_tmm.
 constexpr int kNotFused = -1;
+// d_stop0 / d_stop1 (device scalars, may be null): the launch does nothing when either is non-zero
+// at the time it RUNS -- for launches enqueued before the host knows whether they are needed; only
+// where hessmult_fused_skippable says so
 int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y,
-                          double ca, double cb, double *d_out, double *d_yhat, double *d_ss);
+                          double ca, double cb, double *d_out, double *d_yhat, double *d_ss,
+                          const double *d_stop0 = nullptr, const double *d_stop1 = nullptr);
+bool hessmult_fused_skippable(const obhip_basis &b, obhip_terms &t);
 // d_out = B^T a and d_out2 = (B^2)^T a2 (a2 null: ones) in one pass; kNotFused: make two passes
 int launch_tmm_dual(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, const double *d_a2,
                     double *d_out2);
