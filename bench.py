@@ -443,6 +443,10 @@ def secondary_rooflines(hp, prof):
     hbm("materialize_B", "k_materialize_tl", n * 8 * (Mc + 1 + p), lambda ms: {"bound": "hbm write"})
     hbm("tmm", "k_tmm_tl", n * 8 * (Mc + 2), lds)
     hbm("mm", "k_mm_tl", n * 8 * (Mc + 2), lds)
+    # the PCG's fused Hessian product / update() pass: one read of the basis, ONE set of column
+    # reads (the two-kernel form makes two)
+    hbm("hessmult", "k_hm2 (k_hm_tl for terms it does not take)", n * 8 * (Mc + 2), lds)
+    hbm("tmm_dual", "k_tmm_tl<DUAL>", n * 8 * (Mc + 2), lds)
     hbm("predict", "k_predict_tl", n * 8 * (d + 1), lds)
     if "cholesky" in prof:
         ms = prof["cholesky"]["avg_ms"]
