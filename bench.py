@@ -15,10 +15,17 @@ already resident in HBM (BASELINE.md sections 2-3):
 Default workload: BASELINE.json configs[2] = d=20, n=1e6, p=4096, Matern-5/2 in every
 dimension, 40 knots per dimension.  With --gpus N the SAME n = 1e6 rows are sharded over
 the N ranks ("scaling": "strong", what the metric "d=20 n=1e6 p=4096 at 1/2/4/8 MI355X"
-says); the line also carries `config3`, BASELINE.json configs[3]'s shape (1.25e6 rows per
-GPU, weak).  `python bench.py --gpus N` launches its own N ranks (one process per GPU,
-torch.distributed.run) when it is not already running under a launcher.  Prints ONE JSON
-line on rank 0.
+says); the line also carries `configs`: the other BASELINE.json configurations that fit one
+GPU, timed after the headline through the same loop (configs[1] per GPU, configs[3]'s 1.25e6
+rows per GPU -- also under the old key `config3` --, configs[4]'s 125 000-row shard per GPU).
+Before the warm-up a job with more than one rank verifies its transport
+(obhip_comm_selftest_dev); after the timed region every run is checked, at any rank count:
+`parity_check` = rank 0's predictions against the oracle's basis, Newton stationarity with the
+matrix-free kernels summed through the communicator, and `fit_vs_oracle` -- Gram + Cholesky +
+predict of the device against the oracle's own fit on the first 20 000 rows.
+`python bench.py --gpus N` launches its own N ranks (one process per GPU,
+torch.distributed.run) when it is not already running under a launcher; `--sim-ranks N` times
+on ONE GPU the step a rank of an N-GPU job runs.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
