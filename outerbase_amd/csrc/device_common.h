@@ -431,12 +431,14 @@ __device__ __forceinline__ double swap16_sum(double a, double b) {
 // v + (v rotated right by ROR lanes within every row of 16 lanes).  The two v_mov_b32_dpp are
 // written out: through __builtin_amdgcn_update_dpp the compiler first zeroes the destination
 // (two more VALU instructions per call) although row_ror with full row / bank masks writes every
-// lane.  s_nop 1: a DPP read of a VGPR needs two wait states behind the VALU write of it.
+// lane.  s_nop 4: a DPP read of a VGPR needs two wait states behind the VALU write of it, and a
+// DPP instruction five behind a VALU write of EXEC (v_cmpx) -- the compiler's hazard recognizer
+// does not look inside inline asm, so the larger of the two is paid here (3 more cycles).
 template <int ROR>
 __device__ __forceinline__ double row16_ror_add(double v) {
   static_assert(ROR >= 1 && ROR <= 15, "row_ror:1 .. row_ror:15");
   int rl, rh;
-  asm volatile("s_nop 1\n\t"
+  asm volatile("s_nop 4\n\t"
                "v_mov_b32_dpp %0, %2 row_ror:%4 row_mask:0xf bank_mask:0xf\n\t"
                "v_mov_b32_dpp %1, %3 row_ror:%4 row_mask:0xf bank_mask:0xf"
                : "=&v"(rl), "=&v"(rh)
