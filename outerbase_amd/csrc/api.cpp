@@ -503,7 +503,7 @@ namespace obhip {
 int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_model *m,
                     const double *d_y, double sigma, double rho, double tol, uint64_t maxit,
                     double *d_theta, uint64_t *iters_out, double *d_diagH, double *val_out,
-                    obhip_comm *comm, int *finite_out) {
+                    obhip_comm *comm, int *finite_out, double *d_sqcolsums_out) {
   if (!b || !tc || !m || !d_y || !d_theta) return fail(OBHIP_ERR_INVALID, "fit_cg_dev: null argument");
   OB_TRY(check_compat(m, tc));
   obhip_terms &t = *const_cast<obhip_terms *>(tc);
@@ -604,6 +604,10 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
     OB_TRY(launch_tmm(*b, t, tmp.p, ddiag.p, true));
   }
   if (many) OB_TRY(comm_allreduce(comm, ddiag.p, p));
+  // (the likelihood's diaghess / diaghessgradpara are multiples of these sums: lpdfvec::optcg
+  // hands them on instead of two more passes over the basis)
+  if (d_sqcolsums_out)
+    OB_HIP(hipMemcpyAsync(d_sqcolsums_out, ddiag.p, p * sizeof(double), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(kCgThreads), 0, st, v, ddiag.p, e2, scal.p);
   OB_HIP(hipGetLastError());
   double hs[S_COUNT];

@@ -57,7 +57,13 @@ size_t g_pool_bytes = 0;
 size_t pool_cap() {
   static const size_t cap = [] {
     const char *e = getenv("OBHIP_POOL_MB");
-    return (size_t)(e ? std::max(0, atoi(e)) : 8192) << 20;
+    if (e) return (size_t)std::max(0, atoi(e)) << 20;
+    // an eighth of the device's memory (36 GB of the MI355X's 288), at least 8 GB: obfit frees
+    // and re-allocates the gradient basis of its rows (6.5 GB at n = 1e6, 8 dimensions) on every
+    // function evaluation, and a block of more than half the cap goes back to the driver
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0;
+    return std::max<size_t>((size_t)8192 << 20, tot / 8);
   }();
   return cap;
 }

@@ -325,9 +325,14 @@ __device__ __forceinline__ void tl_waitn(double (&b)[12]) {
 //   uint32_t ad[NU][W]                       LDS byte addresses of row 0 of the chunk
 //   template <int RR> void row()             once per row, before its first unit
 //   template <int RR, int UNIT> void use(v)  the product of unit UNIT at row RR
-template <int WE, int W, int NU, int ROWS, int INFLIGHT = 12, int U0 = 0, int ROW0 = 0>
+// TAIL > 0: the last TAIL factors of a unit are NOT multiplied in but handed over one by one,
+//   template <int RR, int UNIT, int S, bool LEAD> void use_tail(v, buf)
+// with v the product of the WE - TAIL leading factors (LEAD false: there are none, v = 1) and
+// buf[S .. S + TAIL) the others (the gradient passes of kernels_grad.hip: a term's factor in one
+// dimension and that dimension's delta columns)
+template <int WE, int W, int NU, int ROWS, int INFLIGHT = 12, int U0 = 0, int ROW0 = 0, int TAIL = 0>
 struct TlPipe {
-  static_assert(WE >= 1 && WE <= W && W <= 8 && INFLIGHT <= 12, "");
+  static_assert(WE >= 1 && WE <= W && W <= 8 && INFLIGHT <= 12 && TAIL <= WE, "");
   static constexpr int D = (INFLIGHT / WE) > 0 ? INFLIGHT / WE : 1;
   static constexpr int TOT = ROWS * NU;
 
@@ -345,10 +350,19 @@ struct TlPipe {
       if constexpr (unit == 0) c.template row<rr>();
       constexpr int newer = (TOT - 1 - U) < (D - 1) ? (TOT - 1 - U) : (D - 1);
       tl_waitn<newer * WE, WE, s>(buf);
-      double v = buf[s];
+      if constexpr (TAIL == 0) {
+        double v = buf[s];
 #pragma unroll
-      for (int j = 1; j < WE; ++j) v *= buf[s + j];
-      c.template use<rr, U0 + unit>(v);
+        for (int j = 1; j < WE; ++j) v *= buf[s + j];
+        c.template use<rr, U0 + unit>(v);
+      } else if constexpr (WE == TAIL) {
+        c.template use_tail<rr, U0 + unit, s, false>(1.0, buf);
+      } else {
+        double v = buf[s];
+#pragma unroll
+        for (int j = 1; j < WE - TAIL; ++j) v *= buf[s + j];
+        c.template use_tail<rr, U0 + unit, s + WE - TAIL, true>(v, buf);
+      }
       steps<U + 1>(c, buf);
     }
   }
@@ -382,6 +396,23 @@ __device__ __forceinline__ void tl_run_half(C &c, int we) {
   } else {
     TlPipe<(W >= 4 ? W - 3 : 1), W, NUH, ROWS, INFLIGHT, U0, ROW0>::run(c);
   }
+}
+// the same with TAIL factors handed over singly: variants W .. max(TAIL, W - 3)
+template <int W, int NUH, int ROWS, int INFLIGHT, int U0, int TAIL, typename C>
+__device__ __forceinline__ void tl_run_tail(C &c, int we) {
+  if (we == W || W - 1 < TAIL) {
+    TlPipe<W, W, NUH, ROWS, INFLIGHT, U0, 0, TAIL>::run(c);
+  } else if (we == W - 1 || W - 2 < TAIL) {
+    TlPipe<(W - 1 >= TAIL ? W - 1 : W), W, NUH, ROWS, INFLIGHT, U0, 0, TAIL>::run(c);
+  } else if (we == W - 2 || W - 3 < TAIL) {
+    TlPipe<(W - 2 >= TAIL ? W - 2 : W), W, NUH, ROWS, INFLIGHT, U0, 0, TAIL>::run(c);
+  } else {
+    TlPipe<(W - 3 >= TAIL ? W - 3 : W), W, NUH, ROWS, INFLIGHT, U0, 0, TAIL>::run(c);
+  }
+}
+template <int W, int TAIL>
+__device__ __forceinline__ int tl_variant_tail(int nzmax) {
+  return max(nzmax, max(TAIL, W - 3));
 }
 template <int W>
 __device__ __forceinline__ int tl_variant(int nzmax) {  // smallest variant that covers nzmax

@@ -847,8 +847,9 @@ __device__ __forceinline__ void ge_tile(GeCtx<W, NHB> &c, int we) {
   }
 }
 
-template <int W2, int NHB>
-__global__ void __launch_bounds__(kTlThreads, 4)
+// NW: waves per block (16 where the tile leaves room for only one block per CU)
+template <int W2, int NHB, bool SQ, int NW>
+__global__ void __launch_bounds__(NW * 64, 4)
 k_tmm_ge0(const double *__restrict__ bm, const double *__restrict__ scale,
           const uint32_t *__restrict__ ucol, int Mu, uint64_t Mtot,
           const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm,
@@ -866,7 +867,7 @@ k_tmm_ge0(const double *__restrict__ bm, const double *__restrict__ scale,
   int nzmax = 1;
 #pragma unroll
   for (int g = 0; g < kGeNU; ++g) {
-    const uint64_t slot = ((uint64_t)blockIdx.y * kTlWaves + wave) * 64 + g * 16 + t16;
+    const uint64_t slot = ((uint64_t)blockIdx.y * NW + wave) * 64 + g * 16 + t16;
     const bool ok = slot < p_pad;
     const uint64_t k = ok ? sperm[slot] : 0;
     uint32_t cw[W2];
@@ -883,18 +884,29 @@ k_tmm_ge0(const double *__restrict__ bm, const double *__restrict__ scale,
 #pragma unroll
   for (int hb = 0; hb < NHB; ++hb) c.aw[hb] = (uint32_t)(Mu + hb * 16 + t16) * (kTlPitch * 8) + r4 * 8;
   const int we = tl_variant<W>(wave_max_i32(nzmax));
-  const bool live = ((uint64_t)blockIdx.y * kTlWaves + wave) * 64 < p_pad;
+  const bool live = ((uint64_t)blockIdx.y * NW + wave) * 64 < p_pad;
 
   for (uint64_t tile = t0; tile < t1; ++tile) {
     __syncthreads();  // every wave is done with the previous tile
     {
       const double *src = bm + tile * Mtot * kTileRows + lane;
-      for (int u = wave; u < Mu; u += kTlWaves) lds[u * kTlPitch + lane] = src[(size_t)ucol[u] * kTileRows];
+      // SQ: the squared stores formed while staging (basematsq = basemat^2, its level-0 gradient
+      // column 2 ge[h, 0], scale^2: k_square_gradbasis) -- no second copy of the gradient basis
+      for (int u = wave; u < Mu; u += NW) {
+        const double v = src[(size_t)ucol[u] * kTileRows];
+        lds[u * kTlPitch + lane] = SQ ? v * v : v;
+      }
       const uint64_t row = tile * kTileRows + lane;
-      const double wr = row < n ? a[row] * scale[row] : 0.0;
-      for (int h = wave; h < HS; h += kTlWaves) {
+      double wr = 0.0;
+      if (row < n) {
+        const double sc = scale[row];
+        wr = a[row] * (SQ ? sc * sc : sc);
+      }
+      for (int h = wave; h < HS; h += NW) {
         const int col = h0 + h < nhyp ? ge0abs[h0 + h] : -1;
-        lds[(Mu + h) * kTlPitch + lane] = col >= 0 ? wr * src[(size_t)col * kTileRows] : 0.0;
+        double gv = col >= 0 ? src[(size_t)col * kTileRows] : 0.0;
+        if (SQ) gv = 2.0 * gv;
+        lds[(Mu + h) * kTlPitch + lane] = col >= 0 ? wr * gv : 0.0;
       }
     }
     __syncthreads();
@@ -904,7 +916,7 @@ k_tmm_ge0(const double *__restrict__ bm, const double *__restrict__ scale,
   // (lane >> 4) + 4 * reg
 #pragma unroll
   for (int g = 0; g < kGeNU; ++g) {
-    const uint64_t slot = ((uint64_t)blockIdx.y * kTlWaves + wave) * 64 + g * 16 + t16;
+    const uint64_t slot = ((uint64_t)blockIdx.y * NW + wave) * 64 + g * 16 + t16;
     if (slot >= p_pad) continue;
     const uint64_t k = sperm[slot];
 #pragma unroll
@@ -926,6 +938,17 @@ __global__ void k_ge0_reduce(const double *__restrict__ part, int nsplit, int hs
   out[(uint64_t)h * p + k] = s;
 }
 
+// out[r0 + y][k] = sum of the row-split partials laid out [split][nc][p_pad], rows r0 + blockIdx.y
+__global__ void k_d3_reduce(const double *__restrict__ part, int nsplit, int nc, int r0, uint64_t p_pad,
+                            int p, double *__restrict__ out /* [nc][p] */) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = r0 + blockIdx.y;
+  if (k >= (uint64_t)p) return;
+  double s = 0.0;
+  for (int r = 0; r < nsplit; ++r) s += part[((uint64_t)r * nc + h) * p_pad + k];
+  out[(uint64_t)h * p + k] = s;
+}
+
 // D[h0 + h][k] = sum of the row-split partials
 __global__ void k_btu_reduce(const double *__restrict__ part, int nsplit, uint64_t p_pad, int p,
                              int nh, double *__restrict__ out /* [nh][p] */) {
@@ -940,17 +963,27 @@ __global__ void k_btu_reduce(const double *__restrict__ part, int nsplit, uint64
 }  // namespace
 
 namespace {
-template <int W2, int NHB>
-int run_tmm_ge0(const obhip_basis &src, obhip_terms &t, const int *d_c0, int nhyp, int h0,
-                const double *d_a, dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
+template <int W2, int NHB, bool SQ, int NW>
+int run_tmm_ge0_sq(const obhip_basis &src, obhip_terms &t, const int *d_c0, int nhyp, int h0,
+                   const double *d_a, dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
   const size_t lds = (t.Mu + 16 * NHB) * kTlPitch * sizeof(double);
   if (lds > 64 * 1024)
-    OB_TRY(ensure_dyn_lds((const void *)k_tmm_ge0<W2, NHB>, lds));
-  hipLaunchKernelGGL((k_tmm_ge0<W2, NHB>), grid, dim3(kTlThreads), lds, cur_stream(), src.bm.p,
+    OB_TRY(ensure_dyn_lds((const void *)k_tmm_ge0<W2, NHB, SQ, NW>, lds));
+  hipLaunchKernelGGL((k_tmm_ge0<W2, NHB, SQ, NW>), grid, dim3(NW * 64), lds, cur_stream(), src.bm.p,
                      src.scale.p, t.ucol.p, (int)t.Mu, src.md.Mc, (const uint32_t *)t.cols.p,
                      t.sperm.p, d_c0, nhyp, h0, d_a, src.n, ntiles, tps, t.p_pad, part);
   OB_HIP(hipGetLastError());
   return 0;
+}
+template <int W2, int NHB>
+int run_tmm_ge0(bool sq, int nw, const obhip_basis &src, obhip_terms &t, const int *d_c0, int nhyp, int h0,
+                const double *d_a, dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
+  if (nw == 16) {
+    if (sq) return run_tmm_ge0_sq<W2, NHB, true, 16>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+    return run_tmm_ge0_sq<W2, NHB, false, 16>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+  }
+  if (sq) return run_tmm_ge0_sq<W2, NHB, true, 8>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+  return run_tmm_ge0_sq<W2, NHB, false, 8>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
 }
 }  // namespace
 
@@ -960,21 +993,26 @@ bool tmm_ge0_supports(const obhip_terms &t) {
   return w2 >= 1 && w2 <= 4 && (t.Mu + 32) * kTlPitch * sizeof(double) <= 156 * 1024;
 }
 
-// d_out: p x nhyp column-major (device) = sum_i a_i ge[h, 0]_i B_ik (squared: the squared stores)
+// d_out: p x nhyp column-major (device) = sum_i a_i ge[h, 0]_i B_ik (squared: the squared stores,
+// formed from the gradient basis while staging -- gbsq is not needed)
 int launch_tmm_ge0(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a, double *d_out) {
   obhip_gradbasis &g = *b.grad;
-  const obhip_basis &src = squared ? *g.gbsq : *g.gb;
+  const obhip_basis &src = *g.gb;
   const int nhyp = (int)b.model->nhyp();
   std::vector<int> c0(nhyp);
   for (int h = 0; h < nhyp; ++h) c0[h] = g.hyps_h[h].gecol;  // absolute column in the combined array
   DevBuf<int> dc0;
   OB_TRY(dc0.upload(c0.data(), c0.size()));
   const uint64_t ntiles = b.n_pad / kTileRows;
-  const uint64_t pblocks = (t.p_pad + 511) / 512;
-  int ncu = 256;
-  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b.device) != hipSuccess || ncu <= 0)
-    ncu = 256;
-  uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)ncu * 2 / pblocks);
+  // a tile of more than half the LDS leaves one block per CU: 16 waves in it instead of 8
+  // (OBHIP_GE0_WAVES=8|16 forces either: A/B runs)
+  static const int force_nw = getenv("OBHIP_GE0_WAVES") ? atoi(getenv("OBHIP_GE0_WAVES")) : 0;
+  const bool one_per_cu = (t.Mu + 16) * kTlPitch * sizeof(double) > 80 * 1024;
+  const int nw = force_nw == 8 || force_nw == 16 ? force_nw : (one_per_cu ? 16 : 8);
+  const uint64_t tpb = (uint64_t)nw * 64;
+  const uint64_t pblocks = (t.p_pad + tpb - 1) / tpb;
+  const int ncu = device_cus(b.device);
+  uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)ncu * (one_per_cu ? 1 : 2) / pblocks);
   nsplit = std::min(nsplit, ntiles);
   const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
   nsplit = (ntiles + tps - 1) / tps;
@@ -988,10 +1026,10 @@ int launch_tmm_ge0(obhip_basis &b, obhip_terms &t, bool squared, const double *d
     double *part = nullptr;
     OB_TRY(b.workspace(nsplit * hs * t.p_pad * sizeof(double), (void **)&part));
     switch (t.W / 2) {
-      case 1: OB_TRY((run_tmm_ge0<1, 1>(src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
-      case 2: OB_TRY((run_tmm_ge0<2, 1>(src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
-      case 3: OB_TRY((run_tmm_ge0<3, 1>(src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
-      default: OB_TRY((run_tmm_ge0<4, 1>(src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      case 1: OB_TRY((run_tmm_ge0<1, 1>(squared, nw, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      case 2: OB_TRY((run_tmm_ge0<2, 1>(squared, nw, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      case 3: OB_TRY((run_tmm_ge0<3, 1>(squared, nw, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      default: OB_TRY((run_tmm_ge0<4, 1>(squared, nw, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
     }
     hipLaunchKernelGGL(k_ge0_reduce, dim3((unsigned)((t.p + 255) / 256), (unsigned)nh), dim3(256), 0,
                        cur_stream(), part, (int)nsplit, hs, t.p_pad, (int)t.p, nh,
@@ -1037,6 +1075,255 @@ int launch_bt_times_ge0(obhip_basis &b, obhip_terms &t, bool squared, const doub
   }
   OB_HIP(hipGetLastError());
   OB_HIP(hipStreamSynchronize(cur_stream()));  // dc0 is a local
+  return 0;
+}
+
+namespace {
+
+// ---- the sparse part of both hyper-gradient contractions in ONE pass per dimension group --------
+// What the likelihoods need of the terms that HAVE a hyper-parameter's dimension l (levels t > 0
+// there) is, with o = the product of the term's OTHER factors, b = its factor in l and
+// delta_h = ge_h[t] - b ge_h[0] (so that dB/dhyp_h = ge_h[0] B + o delta_h, mm_gradhyp_dev):
+//   u1[k, h] = sum_i w1_i s_i   o delta_h           (B_delta^T w1: gradhyp = yhat_gradhyp^T r,
+//                                                    loglik_gauss.cpp:127; tmatmul_gradhyp)
+//   u2[k, h] = sum_i w2_i s_i^2 (o delta_h) (o b)   (half the delta part of d(B^2)/dhyp: the squared
+//                                                    stores' delta_sq = 2 b delta, basematsq_gradhyp
+//                                                    modandbase.cpp:588-590; diaghessgradhyp :158-161)
+// Rounds 1-3 ran one restricted k_mm / k_tmm pass per hyper-parameter and store for this, each
+// re-reading the other factors: 4 |A| column reads per (term with |A| factors, dimension of two
+// hyper-parameters, row).  Here a view-term reads its |A| - 1 other factors, b and the delta
+// columns of both hyper-parameters ONCE -- |A| + 2 reads -- and feeds four lane accumulators.
+// Skeleton (tile staging, lane = term, hand-issued reads) as k_tmm_tl; the pipeline hands the
+// last 1 + NH factors over singly (TlPipe<..., TAIL>).  MODE bit 0: u1, bit 1: u2.
+template <int W, int NU, int NH, int MODE>
+struct D3Ctx {
+  uint32_t ad[NU][W];
+  double acc1[NU][NH], acc2[NU][NH];
+  double vs, vs2;  // weights of row = lane
+  double vr, vr2;  // weights of the current row, wave-uniform
+  int rc;
+  template <int RR>
+  __device__ __forceinline__ void row() {
+    if constexpr ((MODE & 1) != 0) vr = readlane_f64(vs, rc + RR);
+    if constexpr ((MODE & 2) != 0) vr2 = readlane_f64(vs2, rc + RR);
+  }
+  // buf[S] = the dimension's own factor, buf[S + 1 + h] = the delta column of hyper-parameter h
+  template <int RR, int UNIT, int S, bool LEAD>
+  __device__ __forceinline__ void use_tail(double o, double (&buf)[12]) {
+    double t2 = 0.0;
+    if constexpr ((MODE & 2) != 0) t2 = (LEAD ? o * buf[S] : buf[S]) * vr2;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const double g = LEAD ? o * buf[S + 1 + h] : buf[S + 1 + h];
+      if constexpr ((MODE & 1) != 0) acc1[UNIT][h] = fma(g, vr, acc1[UNIT][h]);
+      if constexpr ((MODE & 2) != 0) acc2[UNIT][h] = fma(g, t2, acc2[UNIT][h]);
+    }
+  }
+};
+
+constexpr int kD3Pre = 20;  // prefetch registers per thread => Mu <= 8 * 20 columns per group
+
+// slot of unit u: the runs of 64 sorted view-terms are dealt to the blocks along p in turn (wave w of
+// block y takes runs (w gridDim.y + y) NU ...), so that every block holds the same mix of long and
+// short terms -- with tl_slot the first block held the longest and set the time of the launch
+template <int NU>
+__device__ __forceinline__ uint64_t d3_slot(int wave, int u, int lane) {
+  return (((uint64_t)wave * gridDim.y + blockIdx.y) * NU + u) * 64 + lane;
+}
+
+template <int W2, int NH, int NU, int MODE, bool PF, int NW>
+__global__ void __launch_bounds__(NW * 64, NW / 2)
+k_tmm_d3(const double *__restrict__ bm, const double *__restrict__ scale,
+         const uint32_t *__restrict__ ucol, int Mu, uint64_t Mc,
+         const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm,
+         const double *__restrict__ w1, const double *__restrict__ w2, uint64_t n, uint64_t ntiles,
+         uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ part /* [split][2 NH][p_pad] */) {
+  extern __shared__ double lds[];
+  constexpr int W = 2 * W2, TAIL = 1 + NH, PRE = kD3Pre * 8 / NW;
+  static_assert(TAIL <= W, "");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+
+  D3Ctx<W, NU, NH, MODE> c;
+  int nza = TAIL, nzb = TAIL;
+  bool live = false;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const uint64_t slot = d3_slot<NU>(wave, u, lane);
+    const bool ok = slot < p_pad;
+    live = live || ok;
+    const uint64_t k = ok ? sperm[slot] : 0;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) c.acc1[u][h] = c.acc2[u][h] = 0.0;
+    uint32_t cw[W2];
+#pragma unroll
+    for (int w = 0; w < W2; ++w) {
+      cw[w] = ok ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+      c.ad[u][2 * w] = (cw[w] & 0xffffu) * (kTlPitch * 8);
+      c.ad[u][2 * w + 1] = (cw[w] >> 16) * (kTlPitch * 8);
+    }
+    if (NU == 1 || u < NU / 2)
+      nza = max(nza, tl_nnz<W2>(cw));
+    else
+      nzb = max(nzb, tl_nnz<W2>(cw));
+  }
+  const int wea = tl_variant_tail<W, TAIL>(wave_max_i32(nza)), web = tl_variant_tail<W, TAIL>(wave_max_i32(nzb));
+  live = wave_max_i32(live ? 1 : 0) != 0;
+
+  // this wave stages columns u = wave + 8 q of every tile: their tile offsets, wave-uniform
+  int lu[PF ? PRE : 1];
+  double pre[PF ? PRE : 1];
+  if (PF) {
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+      const int u = wave + NW * q;
+      lu[q] = u < Mu ? __builtin_amdgcn_readfirstlane((int)ucol[u] * kTileRows) : 0;
+    }
+  }
+  double vsn = 0.0, vs2n = 0.0;
+  auto weights = [&](uint64_t tile) {
+    const uint64_t row = tile * kTileRows + lane;
+    vsn = vs2n = 0.0;
+    if (row < n) {
+      const double sc = scale[row];
+      if ((MODE & 1) != 0) vsn = w1[row] * sc;
+      if ((MODE & 2) != 0) vs2n = (w2 ? w2[row] : 1.0) * sc * sc;
+    }
+  };
+  auto fetch = [&](uint64_t tile) {
+    const double *src = bm + tile * Mc * kTileRows + lane;
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+      const int u = wave + NW * q;
+      pre[q] = u < Mu ? src[lu[q]] : 0.0;
+    }
+    weights(tile);
+  };
+  if (PF && t0 < t1) fetch(t0);
+
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    __syncthreads();  // every wave is done with the previous tile
+    if (PF) {
+#pragma unroll
+      for (int q = 0; q < PRE; ++q) {
+        const int u = wave + NW * q;
+        if (u < Mu) lds[u * kTlPitch + lane] = pre[q];
+      }
+    } else {  // (the other block of the CU computes meanwhile)
+      const double *src = bm + tile * Mc * kTileRows + lane;
+      for (int u = wave; u < Mu; u += NW) lds[u * kTlPitch + lane] = src[(size_t)ucol[u] * kTileRows];
+      weights(tile);
+    }
+    c.vs = vsn;
+    c.vs2 = vs2n;
+    __syncthreads();
+    if (PF && tile + 1 < t1) fetch(tile + 1);
+    if (!live) continue;  // (whole waves beyond p_pad in the last block along p)
+    constexpr int kInflight = NU * W >= 32 ? 8 : 12;
+#pragma unroll 1
+    for (int rc = 0; rc < kTileRows; rc += kTlChunk) {
+      c.rc = rc;
+      if constexpr (NU <= 2) {  // one run: the row weights are read once per row, not per half
+        tl_run_tail<W, NU, kTlChunk, kInflight, 0, TAIL>(c, max(wea, web));
+      } else {
+        tl_run_tail<W, NU / 2, kTlChunk, kInflight, 0, TAIL>(c, wea);
+        tl_run_tail<W, NU / 2, kTlChunk, kInflight, NU / 2, TAIL>(c, web);
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          c.ad[u][j] += (rc + kTlChunk < kTileRows) ? kTlChunk * 8 : -(kTileRows - kTlChunk) * 8;
+          asm volatile("" : "+v"(c.ad[u][j]));
+        }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const uint64_t slot = d3_slot<NU>(wave, u, lane);
+    if (slot < p_pad) {
+      const uint64_t k = sperm[slot];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if ((MODE & 1) != 0) part[((uint64_t)blockIdx.x * 2 * NH + h) * p_pad + k] = c.acc1[u][h];
+        if ((MODE & 2) != 0) part[((uint64_t)blockIdx.x * 2 * NH + NH + h) * p_pad + k] = c.acc2[u][h];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+namespace {
+template <int W2, int NH, int NU, int MODE, bool PF, int NW>
+int run_tmm_d3(const obhip_basis &src, const obhip_terms &v, const double *d_w1, const double *d_w2, dim3 grid,
+               uint64_t ntiles, uint64_t tps, double *part) {
+  const size_t lds = v.Mu * kTlPitch * sizeof(double);
+  if (lds > 64 * 1024) OB_TRY(ensure_dyn_lds((const void *)k_tmm_d3<W2, NH, NU, MODE, PF, NW>, lds));
+  hipLaunchKernelGGL((k_tmm_d3<W2, NH, NU, MODE, PF, NW>), grid, dim3(NW * 64), lds, cur_stream(), src.bm.p,
+                     src.scale.p, v.ucol.p, (int)v.Mu, src.md.Mc, (const uint32_t *)v.cols.p, v.sperm.p, d_w1,
+                     d_w2, src.n, ntiles, tps, v.p_pad, part);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
+template <int W2, int NH, int NU, bool PF, int NW>
+int run_tmm_d3_mode(int mode, const obhip_basis &src, const obhip_terms &v, const double *d_w1, const double *d_w2,
+                    dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
+  if (mode == 1) return run_tmm_d3<W2, NH, NU, 1, PF, NW>(src, v, d_w1, d_w2, grid, ntiles, tps, part);
+  if (mode == 2) return run_tmm_d3<W2, NH, NU, 2, PF, NW>(src, v, d_w1, d_w2, grid, ntiles, tps, part);
+  return run_tmm_d3<W2, NH, NU, 3, PF, NW>(src, v, d_w1, d_w2, grid, ntiles, tps, part);
+}
+}  // namespace
+
+// d_out (device, [2 nh][v.p]: u1 of the group's first hyper-parameter, of its second, u2 likewise;
+// the rows a mode does not compute are left alone) for one group of build_d3_groups
+int launch_tmm_d3(obhip_basis &b, const obhip_terms::GeD3 &g, int mode, const double *d_w1, const double *d_w2,
+                  double *d_out) {
+  const obhip_basis &src = *b.grad->gb;
+  const obhip_terms &v = *g.v;
+  const uint64_t ntiles = b.n_pad / kTileRows;
+  // 8 waves x 2 view-terms per lane, the tile prefetched into registers while the previous one is
+  // worked on.  OBHIP_D3_VARIANT=1 (A/B runs): 4 per lane, the tile loaded between the barriers
+  // (with the prefetch registers it spills 77) -- 1.26 against 1.32 ms per launch at d = 8.  Also
+  // measured: 2 per lane without prefetch 1.27, 16 waves x 1 per lane 1.42 (twice the row-weight
+  // v_readlanes per view-term: the kernel is bound by its VALU work, VALUBusy 60 %, LdsUtil 55 %).
+  static const int variant = getenv("OBHIP_D3_VARIANT") ? atoi(getenv("OBHIP_D3_VARIANT")) : 0;
+  const int nw = 8;
+  const int nu = variant == 1 && v.p_pad > 1024 ? 4 : 2;
+  const uint64_t tpb = (uint64_t)nw * nu * 64;
+  const uint64_t pblocks = (v.p_pad + tpb - 1) / tpb;
+  uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)device_cus(b.device) * 2 / pblocks);
+  nsplit = std::min(nsplit, std::max<uint64_t>(1, ntiles / 4));
+  const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  const int nc = 2 * g.nh;
+  double *part = nullptr;
+  OB_TRY(b.workspace(nsplit * nc * v.p_pad * sizeof(double), (void **)&part));
+  const dim3 grid((unsigned)nsplit, (unsigned)pblocks);
+  {
+    ProfScope ps("tmm_d3");
+#define OB_D3(W2_, NH_)                                                                                      \
+  do {                                                                                                       \
+    if (nu == 4)                                                                                             \
+      OB_TRY((run_tmm_d3_mode<W2_, NH_, 4, false, 8>(mode, src, v, d_w1, d_w2, grid, ntiles, tps, part)));   \
+    else                                                                                                     \
+      OB_TRY((run_tmm_d3_mode<W2_, NH_, 2, true, 8>(mode, src, v, d_w1, d_w2, grid, ntiles, tps, part)));    \
+  } while (0)
+    const int w2 = (int)(v.W / 2);
+    if (g.nh == 1) {
+      if (w2 == 2) OB_D3(2, 1); else if (w2 == 3) OB_D3(3, 1); else OB_D3(4, 1);
+    } else {
+      if (w2 == 2) OB_D3(2, 2); else if (w2 == 3) OB_D3(3, 2); else OB_D3(4, 2);
+    }
+#undef OB_D3
+  }
+  // the rows of the other mode hold whatever the workspace held: reduce only what was computed
+  const int r0 = (mode & 1) ? 0 : g.nh, r1 = (mode & 2) ? nc : g.nh;
+  hipLaunchKernelGGL(k_d3_reduce, dim3((unsigned)((v.p + 255) / 256), (unsigned)(r1 - r0)), dim3(256), 0,
+                     cur_stream(), part, (int)nsplit, nc, r0, v.p_pad, (int)v.p, d_out);
+  OB_HIP(hipGetLastError());
   return 0;
 }
 
@@ -1092,48 +1379,168 @@ static void build_sparse_views(obhip_terms &t, const obhip_basis &b) {
   // prefetch, 16.5 ms per call at p = 4096, 16 hyper-parameters.
   const char *ge = getenv("OBHIP_GRAD_GROUP_MU");
   const size_t mu_cap = ge ? (size_t)std::max(1, atoi(ge)) : 128;
-  t.ge_sgroups.clear();
-  std::set<std::pair<uint32_t, uint32_t>> used;  // (dimension of the view, level > 0)
-  auto close_group = [&](obhip_terms::GeGroup &g) {
-    if (g.hyps.empty()) return;
-    auto v = std::make_unique<obhip_terms>();
-    v->p = g.off.back();
-    v->d = de;
-    v->lev.resize(v->p * de);
-    v->maxlev.assign(de, 0);
-    for (size_t j = 0; j < g.hyps.size(); ++j) {
-      const obhip_terms *sv = t.ge_sviews[g.hyps[j]].get();
-      std::copy(sv->lev.begin(), sv->lev.end(), v->lev.begin() + g.off[j] * de);
-      for (uint64_t q = 0; q < de; ++q) v->maxlev[q] = std::max(v->maxlev[q], sv->maxlev[q]);
-      v->nnz_total += sv->nnz_total;
-      v->max_nnz = std::max(v->max_nnz, sv->max_nnz);
+  auto group_views = [&](const std::vector<std::unique_ptr<obhip_terms>> &views,
+                         std::vector<obhip_terms::GeGroup> &groups) {
+    groups.clear();
+    std::set<std::pair<uint32_t, uint32_t>> used;  // (dimension of the view, level > 0)
+    auto close_group = [&](obhip_terms::GeGroup &g) {
+      if (g.hyps.empty()) return;
+      auto v = std::make_unique<obhip_terms>();
+      v->p = g.off.back();
+      v->d = de;
+      v->lev.resize(v->p * de);
+      v->maxlev.assign(de, 0);
+      for (size_t j = 0; j < g.hyps.size(); ++j) {
+        const obhip_terms *sv = views[g.hyps[j]].get();
+        std::copy(sv->lev.begin(), sv->lev.end(), v->lev.begin() + g.off[j] * de);
+        for (uint64_t q = 0; q < de; ++q) v->maxlev[q] = std::max(v->maxlev[q], sv->maxlev[q]);
+        v->nnz_total += sv->nnz_total;
+        v->max_nnz = std::max(v->max_nnz, sv->max_nnz);
+      }
+      g.v = std::move(v);
+      groups.push_back(std::move(g));
+    };
+    obhip_terms::GeGroup cur;
+    cur.off.push_back(0);
+    for (uint64_t hh = 0; hh < nh; ++hh) {
+      const obhip_terms *sv = views[hh].get();
+      if (!sv) continue;
+      std::set<std::pair<uint32_t, uint32_t>> mine;
+      for (uint64_t j = 0; j < sv->p; ++j)
+        for (uint64_t q = 0; q < de; ++q)
+          if (sv->lev[j * de + q] > 0) mine.insert({(uint32_t)q, sv->lev[j * de + q]});
+      std::set<std::pair<uint32_t, uint32_t>> both = used;
+      both.insert(mine.begin(), mine.end());
+      if (!cur.hyps.empty() && both.size() + 1 > mu_cap) {
+        close_group(cur);
+        cur = obhip_terms::GeGroup();
+        cur.off.push_back(0);
+        used = mine;
+      } else {
+        used.swap(both);
+      }
+      cur.hyps.push_back(hh);
+      cur.off.push_back(cur.off.back() + sv->p);
     }
-    g.v = std::move(v);
-    t.ge_sgroups.push_back(std::move(g));
+    close_group(cur);
   };
-  obhip_terms::GeGroup cur;
-  cur.off.push_back(0);
-  for (uint64_t hh = 0; hh < nh; ++hh) {
-    const obhip_terms *sv = t.ge_sviews[hh].get();
-    if (!sv) continue;
-    std::set<std::pair<uint32_t, uint32_t>> mine;
-    for (uint64_t j = 0; j < sv->p; ++j)
-      for (uint64_t q = 0; q < de; ++q)
-        if (sv->lev[j * de + q] > 0) mine.insert({(uint32_t)q, sv->lev[j * de + q]});
-    std::set<std::pair<uint32_t, uint32_t>> both = used;
-    both.insert(mine.begin(), mine.end());
-    if (!cur.hyps.empty() && both.size() + 1 > mu_cap) {
-      close_group(cur);
-      cur = obhip_terms::GeGroup();
-      cur.off.push_back(0);
-      used = mine;
-    } else {
-      used.swap(both);
+  group_views(t.ge_sviews, t.ge_sgroups);
+  group_views(t.ge_dviews, t.ge_dgroups);  // the same for the delta views (grad_mm_dot_dev)
+}
+
+// The groups of the fused gradient passes (obhip_terms::GeD3, k_tmm_d3) for the column layout of
+// b's gradient basis; false when some view does not fit the kernel (more than 8 column slots, a
+// tile beyond the prefetch registers): the callers then take the per-hyper-parameter passes.
+static bool build_d3_groups(obhip_terms &t, const obhip_basis &b) {
+  if (t.ge_d3_cap == b.md.cap) return t.ge_d3_ok;
+  HostTimer ht("build_d3_groups (rebuild)");
+  build_sparse_views(t, b);
+  const obhip_model &m = *b.model;
+  const obhip_gradbasis &g = *b.grad;
+  const std::vector<DimDesc> &dims = b.md.dims_h;
+  const uint64_t d = t.d;
+  t.ge_d3.clear();
+  t.ge_d3_cap = b.md.cap;
+  t.ge_d3_ok = false;
+  static const bool off = getenv("OBHIP_GRAD_D3") && atoi(getenv("OBHIP_GRAD_D3")) == 0;  // A/B runs
+  if (off) return false;
+  // two blocks per CU: 2 x Mu x 65 x 8 B <= 160 KB
+  constexpr size_t kMuCap = 152;
+  static_assert(kMuCap <= (size_t)kTlWaves * kD3Pre, "the tile is prefetched into registers");
+  struct Member {
+    uint64_t l, h0;
+    int nh;
+    std::set<uint32_t> cols;
+    uint64_t maxw = 0;
+  };
+  std::vector<Member> mem;
+  for (uint64_t l = 0; l < d; ++l)
+    for (uint64_t h0 = m.hypst[l]; h0 < m.hypst[l + 1]; h0 += 2) {
+      Member M;
+      M.l = l;
+      M.h0 = h0;
+      M.nh = (int)std::min<uint64_t>(2, m.hypst[l + 1] - h0);
+      const std::vector<uint32_t> &ix = t.ge_sidx[h0];
+      if (ix.empty()) continue;
+      for (uint32_t k : ix) {
+        uint64_t w = 1 + (uint64_t)M.nh;
+        for (uint64_t q = 0; q < d; ++q) {
+          const uint32_t lv = t.lev[(uint64_t)k * d + q];
+          if (lv == 0) continue;
+          M.cols.insert((uint32_t)(dims[q].ccol0 + lv - 1));
+          if (q == l)
+            for (int j = 0; j < M.nh; ++j) M.cols.insert((uint32_t)(g.hyps_h[h0 + j].dcol + lv - 1));
+          else
+            ++w;
+        }
+        M.maxw = std::max(M.maxw, w);
+      }
+      if (M.cols.size() + 1 > kMuCap || M.maxw > 8) return false;
+      mem.push_back(std::move(M));
     }
-    cur.hyps.push_back(hh);
-    cur.off.push_back(cur.off.back() + sv->p);
+  // consecutive members with the same number of delta columns share a launch while their columns fit
+  size_t i = 0;
+  while (i < mem.size()) {
+    std::set<uint32_t> used = mem[i].cols;
+    uint64_t maxw = mem[i].maxw;
+    size_t j = i + 1;
+    while (j < mem.size() && mem[j].nh == mem[i].nh) {
+      std::set<uint32_t> both = used;
+      both.insert(mem[j].cols.begin(), mem[j].cols.end());
+      if (both.size() + 1 > kMuCap) break;
+      used.swap(both);
+      maxw = std::max(maxw, mem[j].maxw);
+      ++j;
+    }
+    obhip_terms::GeD3 G;
+    G.nh = mem[i].nh;
+    G.off.push_back(0);
+    for (size_t q = i; q < j; ++q) {
+      G.hyp0.push_back(mem[q].h0);
+      G.off.push_back(G.off.back() + t.ge_sidx[mem[q].h0].size());
+    }
+    auto v = std::make_unique<obhip_terms>();
+    v->p = G.off.back();
+    v->d = 0;
+    v->p_pad = (v->p + 255) / 256 * 256;
+    v->W = std::max<uint64_t>(4, (maxw + 1) / 2 * 2);
+    std::vector<uint32_t> ul(1, 0u);  // the ones column first
+    ul.insert(ul.end(), used.begin(), used.end());
+    v->Mu = ul.size();
+    std::map<uint32_t, uint16_t> pos;
+    for (size_t u = 0; u < ul.size(); ++u) pos[ul[u]] = (uint16_t)u;
+    const uint64_t W = v->W;
+    std::vector<uint16_t> hc(v->p_pad * W, 0);
+    std::vector<uint32_t> nz(v->p, 0), order(v->p_pad);
+    for (size_t q = i; q < j; ++q) {
+      const Member &M = mem[q];
+      const std::vector<uint32_t> &ix = t.ge_sidx[M.h0];
+      for (size_t e = 0; e < ix.size(); ++e) {
+        const uint64_t k = ix[e], vt = G.off[q - i] + e;
+        uint64_t others = 0;
+        for (uint64_t a = 0; a < d; ++a) others += a != M.l && t.lev[k * d + a] > 0;
+        uint64_t w = W - (others + 1 + (uint64_t)M.nh);
+        nz[vt] = (uint32_t)(others + 1 + (uint64_t)M.nh);
+        for (uint64_t a = 0; a < d; ++a) {  // the other factors keep their dimension order
+          const uint32_t lv = t.lev[k * d + a];
+          if (a != M.l && lv > 0) hc[vt * W + w++] = pos[(uint32_t)(dims[a].ccol0 + lv - 1)];
+        }
+        const uint32_t lv = t.lev[k * d + M.l];
+        hc[vt * W + w++] = pos[(uint32_t)(dims[M.l].ccol0 + lv - 1)];
+        for (int a = 0; a < M.nh; ++a) hc[vt * W + w++] = pos[(uint32_t)(g.hyps_h[M.h0 + a].dcol + lv - 1)];
+      }
+    }
+    for (uint64_t k = 0; k < v->p_pad; ++k) order[k] = (uint32_t)k;
+    std::stable_sort(order.begin(), order.begin() + v->p, [&](uint32_t a, uint32_t c) { return nz[a] > nz[c]; });
+    if (v->cols.upload(hc.data(), hc.size()) || v->sperm.upload(order.data(), order.size()) ||
+        v->ucol.upload(ul.data(), ul.size()))
+      return false;
+    G.v = std::move(v);
+    t.ge_d3.push_back(std::move(G));
+    i = j;
   }
-  close_group(cur);
+  t.ge_d3_ok = true;
+  return true;
 }
 
 obhip_terms *grad_view_sparse(obhip_terms &t, const obhip_basis &b, uint64_t h,
@@ -1212,6 +1619,7 @@ int check_grad_args(const obhip_basis *b, const obhip_terms *t) {
 // the terms that have its dimension (delta view), then out[:, h] = ge[h, 0] M + that.
 int mm_gradhyp_dev(obhip_basis &b, obhip_terms &t, bool squared, const double *a, const double *d_a,
                    double *d_M, DevBuf<double> &dge) {
+  HostTimer ht("mm_gradhyp_dev");
   obhip_gradbasis &g = *b.grad;
   const obhip_basis &src = squared ? *g.gbsq : *g.gb;
   const uint64_t nh = b.model->nhyp(), n = b.n;
@@ -1281,6 +1689,98 @@ __global__ void k_wdot2(const double *__restrict__ part, int nblk, double *__res
   out[h] = s;
 }
 
+// part[h][blk] = partial sums of w_i M_i ge[h, 0]_i (the level-0 gradient column of hyper-parameter
+// h in the tiled gradient basis)
+__global__ void __launch_bounds__(256)
+k_wdot_ge0(const double *__restrict__ bm, uint64_t Mtot, const int *__restrict__ ge0col,
+           const double *__restrict__ M, const double *__restrict__ w, uint64_t n,
+           double *__restrict__ part) {
+  __shared__ double red[256];
+  const uint64_t c = (uint64_t)ge0col[blockIdx.y];
+  double s = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    s = fma(w[i] * M[i], bm[((i >> 6) * Mtot + c) * kTileRows + (i & 63)], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
+// out_host[h] = w^T d(B a)/dhyp_h without the n x nhyp matrix.  d(B a)/dhyp_h = ge[h, 0] % (B a) +
+// B_delta,h a_h (mm_gradhyp_dev), and the likelihoods only ever contract it with one row vector
+// (loglik_gauss.cpp:127, loglik_std.cpp:143, loglik_gda.cpp:141: gradhyp = yhat_gradhyp^T r), so
+//   out[h] = sum_i w_i ge[h, 0]_i M_i  +  a_h^T (B_delta,h^T w):
+// one pass of the term-per-lane B^T kernel per group of concatenated delta views (accumulators
+// stay in the lanes: no cross-lane sum per row, which is what the nhyp restricted k_mm passes of
+// mm_gradhyp_dev pay) and one streaming pass for the level-0 columns.  d_M = B a.
+int mm_gradhyp_dot_dev(obhip_basis &b, obhip_terms &t, const double *a, const double *d_M,
+                       const double *d_w, double *out_host) {
+  HostTimer ht("mm_gradhyp_dot_dev");
+  obhip_gradbasis &g = *b.grad;
+  const obhip_basis &src = *g.gb;
+  const uint64_t nh = b.model->nhyp(), n = b.n;
+  if (nh == 0) return 0;
+  constexpr int nblk = 256;
+  std::vector<int> c0(nh);
+  for (uint64_t h = 0; h < nh; ++h) c0[h] = g.hyps_h[h].gecol;
+  DevBuf<int> dc0;
+  DevBuf<double> dpart, dres, dall;
+  OB_TRY(dc0.upload(c0.data(), c0.size()));
+  OB_TRY(dpart.alloc(nh * nblk));
+  OB_TRY(dres.alloc(nh));
+  ProfScope ps("mm_gradhyp_dot");
+  hipLaunchKernelGGL(k_wdot_ge0, dim3(nblk, (unsigned)nh), dim3(256), 0, cur_stream(), src.bm.p,
+                     src.md.Mc, dc0.p, d_M, d_w, n, dpart.p);
+  hipLaunchKernelGGL(k_wdot2, dim3((unsigned)nh), dim3(64), 0, cur_stream(), dpart.p, nblk, dres.p);
+  OB_HIP(hipGetLastError());
+  OB_TRY(d2h(out_host, dres.p, nh * sizeof(double)));
+  const std::vector<uint32_t> *idx = nullptr;
+  grad_view_delta(t, b, 0, &idx);  // builds the views and their groups
+  std::vector<double> tmp;
+  auto contract = [&](uint64_t h, const double *v) {  // out[h] += a_h^T v over the view's terms
+    const std::vector<uint32_t> &ix = t.ge_sidx[h];
+    long double s = 0;
+    for (size_t q = 0; q < ix.size(); ++q) s += (long double)a[ix[q]] * v[q];
+    out_host[h] += (double)s;
+  };
+  if (build_d3_groups(t, b)) {  // one pass per group of dimensions (k_tmm_d3)
+    for (const obhip_terms::GeD3 &grp : t.ge_d3) {
+      const uint64_t vp = grp.v->p;
+      OB_TRY(dall.alloc(std::max<uint64_t>(2 * grp.nh * vp, dall.n)));
+      OB_TRY(launch_tmm_d3(b, grp, 1, d_w, nullptr, dall.p));
+      tmp.resize(grp.nh * vp);
+      OB_TRY(d2h(tmp.data(), dall.p, tmp.size() * sizeof(double)));
+      for (size_t j = 0; j < grp.hyp0.size(); ++j)
+        for (int hh = 0; hh < grp.nh; ++hh) contract(grp.hyp0[j] + hh, tmp.data() + hh * vp + grp.off[j]);
+    }
+    return 0;
+  }
+  for (obhip_terms::GeGroup &grp : t.ge_dgroups) {
+    obhip_terms *all = grp.v.get();
+    if (all->prepare(src.md.cap, src.md.dims_h) == 0 && all->Mu <= 296) {
+      OB_TRY(dall.alloc(std::max<uint64_t>(all->p, dall.n)));
+      OB_TRY(launch_tmm(src, *all, d_w, dall.p, false));
+      tmp.resize(all->p);
+      OB_TRY(d2h(tmp.data(), dall.p, tmp.size() * sizeof(double)));
+      for (size_t j = 0; j < grp.hyps.size(); ++j) contract(grp.hyps[j], tmp.data() + grp.off[j]);
+      continue;
+    }
+    for (uint64_t h : grp.hyps) {  // beyond one LDS tile: hyper-parameter by hyper-parameter
+      obhip_terms *v = grad_view_delta(t, b, h, &idx);
+      if (!v) continue;
+      OB_TRY(dall.alloc(std::max<uint64_t>(v->p, dall.n)));
+      OB_TRY(launch_tmm(src, *v, d_w, dall.p, false));
+      tmp.resize(v->p);
+      OB_TRY(d2h(tmp.data(), dall.p, tmp.size() * sizeof(double)));
+      contract(h, tmp.data());
+    }
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1324,21 +1824,14 @@ int obhip_basis_mm_gradhyp_dot(const obhip_basis *bc, const obhip_terms *tc, con
   obhip_basis &b = *const_cast<obhip_basis *>(bc);
   obhip_terms &t = *const_cast<obhip_terms *>(tc);
   OB_TRY(ensure_gradbasis(b));
-  const uint64_t nh = b.model->nhyp();
-  constexpr int nblk = 256;
-  DevBuf<double> da, dw, dout, dge, dpart, dres;
+  DevBuf<double> da, dw, dout;
   OB_TRY(da.upload(a, t.p));
   OB_TRY(dw.upload(w, b.n));
   OB_TRY(dout.alloc(b.n));
-  OB_TRY(dpart.alloc(nh * nblk));
-  OB_TRY(dres.alloc(nh));
-  OB_TRY(mm_gradhyp_dev(b, t, false, a, da.p, dout.p, dge));
-  hipLaunchKernelGGL(k_wdot1, dim3(nblk, (unsigned)nh), dim3(256), 0, cur_stream(), dge.p, dw.p, b.n,
-                     dpart.p);
-  hipLaunchKernelGGL(k_wdot2, dim3((unsigned)nh), dim3(64), 0, cur_stream(), dpart.p, nblk, dres.p);
-  OB_HIP(hipGetLastError());
+  OB_TRY(launch_mm(b, t, da.p, dout.p, false));
+  OB_TRY(mm_gradhyp_dot_dev(b, t, a, dout.p, dw.p, out_dot));
   if (out) OB_TRY(d2h(out, dout.p, b.n * sizeof(double)));
-  return d2h(out_dot, dres.p, nh * sizeof(double));
+  return 0;
 }
 
 static int tmm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a,
@@ -1354,7 +1847,8 @@ static int sq_gradhyp(const obhip_basis *bc, const obhip_terms *tc, const double
     return fail(OBHIP_ERR_INVALID, "sq*_gradhyp: null argument");
   obhip_basis &b = *const_cast<obhip_basis *>(bc);
   obhip_terms &t = *const_cast<obhip_terms *>(tc);
-  OB_TRY(ensure_gradbasis_sq(b));
+  // (the transposed product asks for the squared store itself, where it needs it)
+  OB_TRY(transposed ? ensure_gradbasis(b) : ensure_gradbasis_sq(b));
   const uint64_t nin = transposed ? b.n : t.p, nout = transposed ? t.p : b.n;
   DevBuf<double> da, dout;
   if (a) {
@@ -1412,13 +1906,18 @@ int obhip_basis_residvar_gradhyp(const obhip_basis *b, const obhip_terms *t, con
 // for those with it; one k_tmm pass per hyper-parameter when the design matrix does not fit
 static int tmm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a,
                            double *out_gradhyp) {
+  HostTimer ht("tmm_gradhyp_all");
   const uint64_t nh = b.model->nhyp(), p = t.p;
-  const obhip_basis &src = squared ? *b.grad->gbsq : *b.grad->gb;
   DevBuf<double> dout;
   OB_TRY(dout.alloc(p * nh));
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   static const bool stream_b = getenv("OBHIP_GRAD_STREAM_B") != nullptr;  // the older dense pass
   const bool onfly = tmm_ge0_supports(t) && !stream_b;
+  // the squared store of the gradient basis (a second array of its size) only where the older
+  // passes run: k_tmm_ge0 and k_tmm_d3 form the squares themselves
+  const bool fused = onfly && build_d3_groups(t, b);
+  if (squared && !fused) OB_TRY(ensure_gradbasis_sq(b));
+  const obhip_basis &src = squared && !fused ? *b.grad->gbsq : *b.grad->gb;
   if (!onfly && !gram_panel_supports(b, t)) {
     for (uint64_t h = 0; h < nh; ++h) {
       OB_TRY(launch_tmm(src, *grad_view(t, b, h), d_a, dout.p, false));
@@ -1431,10 +1930,30 @@ static int tmm_gradhyp_all(obhip_basis &b, obhip_terms &t, bool squared, const d
   else
     OB_TRY(launch_bt_times_ge0(b, t, squared, d_a, dout.p));
   OB_TRY(d2h(out_gradhyp, dout.p, p * nh * sizeof(double)));
-  // the terms that have the hyper-parameter's dimension: one pass per group of restricted
-  // views (build_sparse_views)
   std::vector<double> tmp;
   const std::vector<uint32_t> *idx = nullptr;
+  if (fused) {
+    // the dense pass treated EVERY term as if it lacked the dimension (ge[h, 0] B, squared:
+    // 2 ge[h, 0] B^2); the terms that have it add their delta part, squared: 2 u2 (k_tmm_d3)
+    DevBuf<double> dall;
+    for (const obhip_terms::GeD3 &grp : t.ge_d3) {
+      const uint64_t vp = grp.v->p;
+      OB_TRY(dall.alloc(std::max<uint64_t>(2 * grp.nh * vp, dall.n)));
+      OB_TRY(launch_tmm_d3(b, grp, squared ? 2 : 1, d_a, d_a, dall.p));
+      tmp.resize(grp.nh * vp);
+      OB_TRY(d2h(tmp.data(), dall.p + (squared ? grp.nh * vp : 0), tmp.size() * sizeof(double)));
+      for (size_t j = 0; j < grp.hyp0.size(); ++j)
+        for (int hh = 0; hh < grp.nh; ++hh) {
+          const uint64_t h = grp.hyp0[j] + hh;
+          const std::vector<uint32_t> &ix = t.ge_sidx[h];
+          const double *u = tmp.data() + hh * vp + grp.off[j];
+          for (size_t q = 0; q < ix.size(); ++q) out_gradhyp[h * p + ix[q]] += squared ? 2.0 * u[q] : u[q];
+        }
+    }
+    return 0;
+  }
+  // the terms that have the hyper-parameter's dimension: one pass per group of restricted
+  // views (build_sparse_views), overwriting the dense pass' entries
   grad_view_sparse(t, b, 0, &idx);  // builds the views
   for (obhip_terms::GeGroup &g : t.ge_sgroups) {
     obhip_terms *all = g.v.get();
@@ -1496,6 +2015,77 @@ int grad_mm_dev(obhip_basis &b, obhip_terms &t, bool squared, const double *a_ho
   return mm_gradhyp_dev(b, t, squared, a_host, d_a, d_M, dge);
 }
 
+// out_host[h] = w^T d(B a)/dhyp_h from d_M = B a (mm_gradhyp_dot_dev)
+int grad_mm_dot_dev(obhip_basis &b, obhip_terms &t, const double *a_host, const double *d_M,
+                    const double *d_w, double *out_host) {
+  OB_TRY(check_grad_args(&b, &t));
+  OB_TRY(ensure_gradbasis(b));
+  return mm_gradhyp_dot_dev(b, t, a_host, d_M, d_w, out_host);
+}
+
+// Both hyper-gradient contractions of a likelihood in one sweep (k_tmm_d3 MODE 3):
+//   out_dot (nhyp)       = w1^T d(B a)/dhyp            (grad_mm_dot_dev; d_M = B a)
+//   out_sq  (p x nhyp)   = sum_i w2_i d(B^2)_ik/dhyp   (grad_tmm_host squared; d_w2 null: ones)
+// kNotFused when the terms do not fit the fused kernels: the caller then asks for the two singly.
+int grad_dual_dev(obhip_basis &b, obhip_terms &t, const double *a_host, const double *d_M, const double *d_w1,
+                  const double *d_w2, double *out_dot, double *out_sq) {
+  HostTimer ht("grad_dual_dev");
+  OB_TRY(check_grad_args(&b, &t));
+  OB_TRY(ensure_gradbasis(b));
+  OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
+  if (!tmm_ge0_supports(t) || !build_d3_groups(t, b)) return kNotFused;
+  obhip_gradbasis &g = *b.grad;
+  const obhip_basis &src = *g.gb;
+  const uint64_t nh = b.model->nhyp(), n = b.n, p = t.p;
+  if (nh == 0) return 0;
+  DevBuf<double> ones, dout, dall;
+  if (!d_w2) {
+    OB_TRY(ones.alloc(n));
+    OB_TRY(launch_fill(ones.p, n, 1.0));
+    d_w2 = ones.p;
+  }
+  {  // level-0 columns: sum_i w1_i ge[h, 0]_i M_i
+    constexpr int nblk = 256;
+    std::vector<int> c0(nh);
+    for (uint64_t h = 0; h < nh; ++h) c0[h] = g.hyps_h[h].gecol;
+    DevBuf<int> dc0;
+    DevBuf<double> dpart, dres;
+    OB_TRY(dc0.upload(c0.data(), c0.size()));
+    OB_TRY(dpart.alloc(nh * nblk));
+    OB_TRY(dres.alloc(nh));
+    hipLaunchKernelGGL(k_wdot_ge0, dim3(nblk, (unsigned)nh), dim3(256), 0, cur_stream(), src.bm.p, src.md.Mc,
+                       dc0.p, d_M, d_w1, n, dpart.p);
+    hipLaunchKernelGGL(k_wdot2, dim3((unsigned)nh), dim3(64), 0, cur_stream(), dpart.p, nblk, dres.p);
+    OB_HIP(hipGetLastError());
+    OB_TRY(d2h(out_dot, dres.p, nh * sizeof(double)));
+  }
+  OB_TRY(dout.alloc(p * nh));
+  OB_TRY(launch_tmm_ge0(b, t, true, d_w2, dout.p));
+  OB_TRY(d2h(out_sq, dout.p, p * nh * sizeof(double)));
+  std::vector<double> tmp;
+  for (const obhip_terms::GeD3 &grp : t.ge_d3) {
+    const uint64_t vp = grp.v->p;
+    OB_TRY(dall.alloc(std::max<uint64_t>(2 * grp.nh * vp, dall.n)));
+    OB_TRY(launch_tmm_d3(b, grp, 3, d_w1, d_w2, dall.p));
+    tmp.resize(2 * grp.nh * vp);
+    OB_TRY(d2h(tmp.data(), dall.p, tmp.size() * sizeof(double)));
+    for (size_t j = 0; j < grp.hyp0.size(); ++j)
+      for (int hh = 0; hh < grp.nh; ++hh) {
+        const uint64_t h = grp.hyp0[j] + hh;
+        const std::vector<uint32_t> &ix = t.ge_sidx[h];
+        const double *u1 = tmp.data() + hh * vp + grp.off[j];
+        const double *u2 = tmp.data() + (grp.nh + hh) * vp + grp.off[j];
+        long double s = 0;
+        for (size_t q = 0; q < ix.size(); ++q) {
+          s += (long double)a_host[ix[q]] * u1[q];
+          out_sq[h * p + ix[q]] += 2.0 * u2[q];
+        }
+        out_dot[h] += (double)s;
+      }
+  }
+  return 0;
+}
+
 // out_host[c] = sum_i w_i G[i + c n], c < ncol (G: n x ncol column-major, device)
 int grad_wdot_dev(const double *d_G, const double *d_w, uint64_t n, uint64_t ncol, double *out_host) {
   if (ncol == 0) return 0;
@@ -1513,7 +2103,7 @@ int grad_wdot_dev(const double *d_G, const double *d_w, uint64_t n, uint64_t nco
 // out_host (p x nhyp column-major) = sum_i a_i dB_ik/dhyp_h (squared: of B^2)
 int grad_tmm_host(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a, double *out_host) {
   OB_TRY(check_grad_args(&b, &t));
-  OB_TRY(squared ? ensure_gradbasis_sq(b) : ensure_gradbasis(b));
+  OB_TRY(ensure_gradbasis(b));  // (tmm_gradhyp_all asks for the squared store where it needs it)
   return tmm_gradhyp_all(b, t, squared, d_a, out_host);
 }
 

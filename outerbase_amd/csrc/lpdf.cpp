@@ -335,8 +335,18 @@ struct Loglik : obhip_lpdf {
   double n_total = 0;  // rows of all ranks
   DevBuf<double> xch;  // staging of the host-side results that are summed
   DevBuf<double> y, yhat, r, tmp, ones, dcoeff, dpv;
-  DevBuf<double> yhatge;      // n x nhyp, kept for gradhyp
   DevBuf<double> red;         // scratch of the two-stage sums
+  DevBuf<double> yhatge_ab;   // n x nhyp, only with OBHIP_GRADHYP_MATRIX (A/B aid)
+  // sum_i d(B^2)_ik/dhyp_h (p x nhyp, this rank's rows, unscaled) when backward() formed it in the
+  // same sweep as gradhyp (grad_dual_dev); diaghessgradhyp() of the one-noise-level likelihoods
+  // then only scales it.  want_dhg: set by lpdfvec around the update() that needs both.
+  std::vector<double> dhg_cache;
+  bool dhg_valid = false, want_dhg = false, dhg_ones = false;
+  // sqcolsums = (B^2)^T 1 summed over the ranks, kept until the basis or the terms change:
+  // diaghess and diaghessgradpara of the one-noise-level likelihoods are multiples of it
+  // (loglik_gauss.cpp:154-157, 169-172), and the device PCG forms it for its preconditioner
+  std::vector<double> sqcs;
+  bool sqcs_valid = false;
 
   ~Loglik() override {
     if (ob) obhip_basis_destroy(ob);
@@ -416,8 +426,12 @@ struct Loglik : obhip_lpdf {
     return 0;
   }
   double yvar_total = 0;
-  int updateom() override { return obhip_basis_rebuild(ob); }
+  int updateom() override {
+    dhg_valid = sqcs_valid = false;
+    return obhip_basis_rebuild(ob);
+  }
   int updateterms(const uint64_t *tt, uint64_t p) override {
+    dhg_valid = sqcs_valid = false;
     // new terms may use other levels: the basis is rebuilt with their caps (the reference
     // keeps all levels and only swaps the umat, loglik_gauss.cpp:99-102)
     DevBuf<double> xkeep;
@@ -429,15 +443,16 @@ struct Loglik : obhip_lpdf {
     OB_HIP(hipStreamSynchronize(cur_stream()));
     return 0;
   }
-  // yhat = B c (and its hyper-parameter gradient when asked for)
+  // yhat = B c
   int forward(const double *c) {
     const uint64_t p = nterms;
     coeff.assign(c, c + p);
     OB_TRY(dcoeff.upload(c, p));
-    if (compute_gradhyp) return grad_mm_dev(*ob, *t, false, c, dcoeff.p, yhat.p, yhatge);
     return launch_mm(*ob, *t, dcoeff.p, yhat.p, false);
   }
-  // grad = B^T r and, when asked for, gradhyp = r^T yhatge
+  // grad = B^T r and, when asked for, gradhyp = yhat_gradhyp^T r -- the reference forms the
+  // n x nhyp matrix yhat_gradhyp = matmul_gradhyp(terms, coeff) first (loglik_gauss.cpp:120-127);
+  // it is only ever contracted with r, which grad_mm_dot_dev does without forming it
   int backward() {
     const uint64_t p = nterms;
     OB_TRY(dpv.alloc(p));
@@ -447,9 +462,33 @@ struct Loglik : obhip_lpdf {
     OB_TRY(d2h(grad.data(), dpv.p, p * sizeof(double)));
     if (compute_gradhyp) {
       gradhyp.assign(nhyp(), 0.0);
-      OB_TRY(grad_wdot_dev(yhatge.p, r.p, n, nhyp(), gradhyp.data()));
+      static const bool matrix_form = getenv("OBHIP_GRADHYP_MATRIX") != nullptr;  // A/B aid
+      if (matrix_form) {  // rounds 1-3: the matrix, then its product with r (one more B c pass)
+        OB_TRY(grad_mm_dev(*ob, *t, false, coeff.data(), dcoeff.p, tmp.p, yhatge_ab));
+        OB_TRY(grad_wdot_dev(yhatge_ab.p, r.p, n, nhyp(), gradhyp.data()));
+      } else {
+        int fused = kNotFused;
+        if (want_dhg && dhg_ones && !dhg_valid) {
+          dhg_cache.resize(nterms * nhyp());
+          fused = grad_dual_dev(*ob, *t, coeff.data(), yhat.p, r.p, nullptr, gradhyp.data(), dhg_cache.data());
+          if (fused != kNotFused) {
+            OB_TRY(fused);
+            dhg_valid = true;
+          }
+        }
+        if (fused == kNotFused) OB_TRY(grad_mm_dot_dev(*ob, *t, coeff.data(), yhat.p, r.p, gradhyp.data()));
+      }
       OB_TRY(sum_ranks(gradhyp.data(), nhyp()));
     }
+    return 0;
+  }
+  int sqcolsums_host(const double **out) {
+    if (!sqcs_valid || sqcs.size() != nterms) {
+      sqcs.resize(nterms);
+      OB_TRY(tmm_host(ones.p, true, sqcs.data()));
+      sqcs_valid = true;
+    }
+    *out = sqcs.data();
     return 0;
   }
   // out (p, host) = B^T v (squared store: B^2)
@@ -468,6 +507,7 @@ struct LoglikGauss : Loglik {
   int init(int kind_, const obhip_model *m, const uint64_t *tt, uint64_t p, const double *yh,
            const double *x, uint64_t n_, uint64_t ldx) {
     kind = kind_;
+    dhg_ones = true;  // diaghessgradhyp weighs every row alike
     OB_TRY(init_common(m, tt, p, yh, x, n_, ldx));
     npara = 1;
     para0 = {std::log(0.01 * sample_var(yh, n_))};  // loglik_std.cpp:51, loglik_gauss.cpp:48
@@ -519,22 +559,27 @@ struct LoglikGauss : Loglik {
     return tmm_host(tmp.p, false, out);
   }
   int diaghess(double *out) override {  // loglik_gauss.cpp:154-157
-    OB_TRY(tmm_host(ones.p, true, out));
+    const double *sq = nullptr;
+    OB_TRY(sqcolsums_host(&sq));
     const double e2 = std::exp(-2.0 * para[0]);
-    for (uint64_t k = 0; k < nterms; ++k) out[k] *= e2;
+    for (uint64_t k = 0; k < nterms; ++k) out[k] = sq[k] * e2;
     return 0;
   }
   int diaghessgradhyp(double *out) override {  // loglik_gauss.cpp:158-161
-    OB_TRY(grad_tmm_host(*ob, *t, true, ones.p, out));
+    if (dhg_valid && dhg_cache.size() == nterms * nhyp())
+      std::copy(dhg_cache.begin(), dhg_cache.end(), out);
+    else
+      OB_TRY(grad_tmm_host(*ob, *t, true, ones.p, out));
     OB_TRY(sum_ranks(out, nterms * nhyp()));
     const double e2 = std::exp(-2.0 * para[0]);
     for (uint64_t k = 0; k < nterms * nhyp(); ++k) out[k] *= e2;
     return 0;
   }
   int diaghessgradpara(double *out) override {  // loglik_gauss.cpp:169-172
-    OB_TRY(tmm_host(ones.p, true, out));
+    const double *sq = nullptr;
+    OB_TRY(sqcolsums_host(&sq));
     const double c = -2.0 * std::exp(-2.0 * para[0]);
-    for (uint64_t k = 0; k < nterms; ++k) out[k] *= c;
+    for (uint64_t k = 0; k < nterms; ++k) out[k] = sq[k] * c;
     return 0;
   }
   int hess_dev(double *d_H, bool add) override {  // loglik_std.cpp:170-173
@@ -603,6 +648,7 @@ struct LoglikGda : Loglik {
   // loglik_gda::buildstd (:215-235)
   int buildstd() {
     if (!redostd) return 0;
+    HostTimer ht("gda.buildstd");
     const uint64_t p = nterms, nh = nhyp(), nn = n;
     const double e0 = std::exp(2.0 * para[0]), e1 = std::exp(2.0 * para[1]);
     std::vector<double> varc, lvarge;
@@ -709,6 +755,7 @@ struct LoglikGda : Loglik {
     return 0;
   }
   int diaghessgradhyp(double *out) override {  // :187-200
+    HostTimer ht("gda.diaghessgradhyp");
     OB_TRY(buildstd());
     double *v = r.p;  // r is rebuilt by every update(); free between updates
     const double *sd = obssd.p;
@@ -728,6 +775,11 @@ struct LpdfVec : obhip_lpdf {
   obhip_lpdf *list[2] = {nullptr, nullptr};  // lpdflist (references in the reference)
   uint64_t parasrt[2] = {0, 0}, paraend[2] = {0, 0};
   bool domargadj = true, redohess = true, have_full = false;
+  // diaghessgradhyp of the members is only needed where a hyper-gradient is (gradhyp_margadj):
+  // buildhess() marks it pending, ensure_dhg() forms it on first use -- which lets the likelihood
+  // form its part in the same sweep as its own gradhyp (Loglik::want_dhg).  The reference builds
+  // it eagerly in buildhess (fit.cpp:262-266); the values are the same.
+  bool dhg_pending = false;
   double val_margadj = 0;
   std::vector<double> gradhyp_margadj, gradpara_margadj;
   std::vector<double> diaghessv, diaghessgradhypv, diaghessgradparav;
@@ -817,24 +869,17 @@ struct LpdfVec : obhip_lpdf {
   }
   // lpdfvec::buildhess (fit.cpp:252-302)
   int buildhess() {
-    const uint64_t p = nterms, nh = nhyp();
+    const uint64_t p = nterms;
     if (!redohess && !(fullhess && !have_full)) return 0;
     OB_TRY(diaghess_(diaghessv));
     settotdiaghess(diaghessv);
     if (domargadj) {
-      std::vector<double> a(p * nh), b(p * nh);
-      OB_TRY(list[0]->diaghessgradhyp(a.data()));
-      OB_TRY(list[1]->diaghessgradhyp(b.data()));
-      diaghessgradhypv.resize(p * nh);
-      for (uint64_t e = 0; e < p * nh; ++e) diaghessgradhypv[e] = a[e] + b[e];
+      dhg_pending = true;
       diaghessgradparav.assign(p * npara, 0.0);
       for (int c = 0; c < 2; ++c)
         OB_TRY(list[c]->diaghessgradpara(diaghessgradparav.data() + parasrt[c] * p));
       val_margadj = 0;
       for (uint64_t k = 0; k < p; ++k) val_margadj -= 0.5 * std::log(diaghessv[k]);
-      gradhyp_margadj.assign(nh, 0.0);
-      for (uint64_t h = 0; h < nh; ++h)
-        for (uint64_t k = 0; k < p; ++k) gradhyp_margadj[h] -= 0.5 * diaghessgradhypv[h * p + k] / diaghessv[k];
       gradpara_margadj.assign(npara, 0.0);
       for (uint64_t c = 0; c < npara; ++c)
         for (uint64_t k = 0; k < p; ++k) gradpara_margadj[c] -= 0.5 * diaghessgradparav[c * p + k] / diaghessv[k];
@@ -848,6 +893,24 @@ struct LpdfVec : obhip_lpdf {
       if (domargadj) OB_TRY(margadj_full());
     }
     redohess = false;
+    return 0;
+  }
+  // the deferred part of buildhess: diaghessgradhyp of the members and the diagonal form of
+  // gradhyp_margadj (fit.cpp:262-266, 268)
+  int ensure_dhg() {
+    if (!dhg_pending) return 0;
+    const uint64_t p = nterms, nh = nhyp();
+    std::vector<double> a(p * nh), b(p * nh);
+    OB_TRY(list[0]->diaghessgradhyp(a.data()));
+    OB_TRY(list[1]->diaghessgradhyp(b.data()));
+    diaghessgradhypv.resize(p * nh);
+    for (uint64_t e = 0; e < p * nh; ++e) diaghessgradhypv[e] = a[e] + b[e];
+    if (!have_full) {  // (with the full Hessian margadj_full() has set gradhyp_margadj)
+      gradhyp_margadj.assign(nh, 0.0);
+      for (uint64_t h = 0; h < nh; ++h)
+        for (uint64_t k = 0; k < p; ++k) gradhyp_margadj[h] -= 0.5 * diaghessgradhypv[h * p + k] / diaghessv[k];
+    }
+    dhg_pending = false;
     return 0;
   }
   // -1/2 log det H and -1/2 tr(inv(H) dH) (fit.cpp:270-299); the reference goes through
@@ -876,12 +939,31 @@ struct LpdfVec : obhip_lpdf {
       l->compute_gradhyp = compute_gradhyp;
       l->compute_gradpara = compute_gradpara;
     }
-    for (obhip_lpdf *l : list) OB_TRY(l->update(c));
+    // the likelihood forms its share of diaghessgradhyp together with its gradhyp when this update
+    // is going to need both
+    Loglik *lik = loglik();
+    if (lik) lik->want_dhg = domargadj && compute_gradhyp && (redohess || dhg_pending);
+    for (obhip_lpdf *l : list) {
+      HostTimer ht(compute_gradhyp ? "vec.update member (gradhyp)" : "vec.update member");
+      const int rc = l->update(c);
+      if (rc) {
+        if (lik) lik->want_dhg = false;
+        return rc;
+      }
+    }
+    if (lik) lik->want_dhg = false;
     if (compute_val) val = 0;
     if (compute_grad) grad.assign(p, 0.0);
     if (compute_gradhyp) gradhyp.assign(nh, 0.0);
     if (compute_gradpara) gradpara.assign(npara, 0.0);
-    OB_TRY(buildhess());
+    {
+      HostTimer ht("vec.buildhess");
+      OB_TRY(buildhess());
+    }
+    if (domargadj && compute_gradhyp) {
+      HostTimer ht("vec.ensure_dhg");
+      OB_TRY(ensure_dhg());
+    }
     for (int k = 0; k < 2; ++k) {
       obhip_lpdf *l = list[k];
       if (compute_val) val += l->val;
@@ -914,6 +996,7 @@ struct LpdfVec : obhip_lpdf {
     return 0;
   }
   int diaghessgradhyp(double *out) override {
+    OB_TRY(ensure_dhg());
     if (diaghessgradhypv.size() != nterms * nhyp()) return fail(OBHIP_ERR_STATE, "lpdfvec: not built (domarg off?)");
     std::copy(diaghessgradhypv.begin(), diaghessgradhypv.end(), out);
     return 0;
@@ -952,13 +1035,21 @@ struct LpdfVec : obhip_lpdf {
     compute_gradhyp = compute_gradpara = false;
     const uint64_t p = nterms;
     if (coeff.size() != p) coeff.assign(p, 0.0);
-    DevBuf<double> dth, ddiag;
+    DevBuf<double> dth, ddiag, dsq;
     OB_TRY(dth.upload(coeff.data(), p));
     OB_TRY(ddiag.alloc(p));
+    OB_TRY(dsq.alloc(p));
     // (no value asked for: the update() below evaluates the fit anyway)
     int finite = 1;
-    OB_TRY(fit_cg_dev_impl(lik->ob, lik->t, om, lik->y.p, lik->para[0], pr->para[0], tol, maxepch,
-                           dth.p, &cgiters, ddiag.p, nullptr, lik->comm, &finite));
+    {
+      HostTimer ht("vec.optcg pcg");
+      OB_TRY(fit_cg_dev_impl(lik->ob, lik->t, om, lik->y.p, lik->para[0], pr->para[0], tol, maxepch,
+                             dth.p, &cgiters, ddiag.p, nullptr, lik->comm, &finite, dsq.p));
+      // the preconditioner's sqcolsums serve the likelihood's diaghess / diaghessgradpara
+      lik->sqcs.resize(p);
+      OB_TRY(d2h(lik->sqcs.data(), dsq.p, p * sizeof(double)));
+      lik->sqcs_valid = true;
+    }
     if (!finite) {  // fit.cpp:53-56: val = -inf and no further update(), as obhip_lpdf::optcg
       val = -std::numeric_limits<double>::infinity();
       return 0;

@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <map>
 #include <memory>
 #include <string>
@@ -45,13 +48,50 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// host wall time of a scope, summed per name and printed at exit when OBHIP_HOST_TIMING is set
+// (tuning aid: where an entry point spends its time between the kernels)
+struct HostTimer {
+  const char *name;
+  double t0 = 0;
+  static bool on() {
+    static const bool v = getenv("OBHIP_HOST_TIMING") != nullptr;
+    return v;
+  }
+  static double now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  }
+  struct Table {
+    std::map<std::string, std::pair<uint64_t, double>> t;
+    ~Table() {
+      for (auto &e : t)
+        fprintf(stderr, "[host] %-36s %8llu x %10.3f ms = %10.1f ms\n", e.first.c_str(),
+                (unsigned long long)e.second.first, e.second.second / e.second.first, e.second.second);
+    }
+  };
+  static Table &table() {
+    static Table tb;
+    return tb;
+  }
+  explicit HostTimer(const char *n) : name(n) {
+    if (on()) t0 = now();
+  }
+  ~HostTimer() {
+    if (!on()) return;
+    auto &e = table().t[name];
+    e.first += 1;
+    e.second += now() - t0;
+  }
+};
+
 // ---- device memory pool -----------------------------------------------------------
 // Every C-ABI call allocates its device temporaries (vectors of n or p doubles, an n x nhyp
 // block, ...) and frees them on return; hipMalloc / hipFree cost far more than the kernels of
 // a small call and hipFree synchronises the device.  Freed blocks are therefore kept, keyed
 // by exact size, device and the stream they were last used on -- a block is handed out again
 // only to work queued on that same stream, so stream order protects it -- up to
-// OBHIP_POOL_MB (default 8192) of cached memory; larger blocks and the overflow go back to
+// OBHIP_POOL_MB (default: an eighth of the device's memory, at least 8192) of cached memory; larger blocks and the overflow go back to
 // the driver, and a failed hipMalloc empties the pool and retries.
 int pool_alloc(void **p, size_t bytes);
 // stream: the one the block was allocated for (the tag under which it may be handed out again)
@@ -208,6 +248,20 @@ struct obhip_terms {
     std::vector<uint64_t> hyps, off; // off[j]: first term of hyps[j] in v (off.size() = hyps.size() + 1)
   };
   std::vector<GeGroup> ge_sgroups;
+  std::vector<GeGroup> ge_dgroups;  // the ge_dviews likewise (w^T d(B a)/dhyp as B_delta^T w)
+  // the fused gradient passes (k_tmm_d3, kernels_grad.hip): per launch the terms that have one of a
+  // few dimensions, each with that dimension's own factor moved to the END of its column list and
+  // followed by the delta columns (level of the term) of up to two of the dimension's
+  // hyper-parameters -- tables written by hand into v (no levels), keyed by the level caps
+  struct GeD3 {
+    std::unique_ptr<obhip_terms> v;
+    int nh = 0;                       // delta columns per view-term (1 or 2)
+    std::vector<uint64_t> hyp0, off;  // member j: hyper-parameters hyp0[j] .. hyp0[j] + nh - 1,
+                                      // view-terms [off[j], off[j + 1]) = the terms ge_sidx[hyp0[j]]
+  };
+  std::vector<GeD3> ge_d3;
+  std::vector<int64_t> ge_d3_cap;     // the caps ge_d3 was built for
+  bool ge_d3_ok = false;              // false: some view does not fit the kernel -> older passes
   // device view of the model capped at maxlev, for the fused predictor
   obhip::ModelDev pred_md;
   const obhip_model *pred_model = nullptr;
@@ -368,6 +422,10 @@ obhip_terms *grad_view(obhip_terms &t, const obhip_basis &b, uint64_t h);
 // device-level forms (inputs and n-sized results in HBM) for the likelihood classes
 int grad_mm_dev(obhip_basis &b, obhip_terms &t, bool squared, const double *a_host, const double *d_a,
                 double *d_M, DevBuf<double> &dge);
+int grad_mm_dot_dev(obhip_basis &b, obhip_terms &t, const double *a_host, const double *d_M,
+                    const double *d_w, double *out_host);
+int grad_dual_dev(obhip_basis &b, obhip_terms &t, const double *a_host, const double *d_M, const double *d_w1,
+                  const double *d_w2, double *out_dot, double *out_sq);
 int grad_wdot_dev(const double *d_G, const double *d_w, uint64_t n, uint64_t ncol, double *out_host);
 int grad_tmm_host(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a, double *out_host);
 // kernels_chol.hip
@@ -400,6 +458,7 @@ int comm_nranks(const obhip_comm *c);
 int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *t, const obhip_model *m, const double *d_y,
                     double sigma, double rho, double tol, uint64_t maxit, double *d_theta,
                     uint64_t *iters_out, double *d_diagH, double *val_out, obhip_comm *comm,
-                    int *finite_out);
+                    int *finite_out,
+                    double *d_sqcolsums_out = nullptr);
 
 }  // namespace obhip

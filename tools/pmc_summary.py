@@ -5,7 +5,7 @@ pat = sys.argv[2] if len(sys.argv) > 2 else "gram"
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.Counter()
 for r in rows:
-    if pat in r["Kernel_Name"]:
+    if re.search(pat, r["Kernel_Name"]):
         m = re.search(r"k_\w+(<[^>]*>)?", r["Kernel_Name"])   # "(anonymous namespace)" holds the first "("
         k = m.group(0) if m else r["Kernel_Name"][:60]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
