@@ -1432,6 +1432,9 @@ static void build_sparse_views(obhip_terms &t, const obhip_basis &b) {
 // b's gradient basis; false when some view does not fit the kernel (more than 8 column slots, a
 // tile beyond the prefetch registers): the callers then take the per-hyper-parameter passes.
 static bool build_d3_groups(obhip_terms &t, const obhip_basis &b) {
+  // OBHIP_GRAD_D3=0 (read per call: the tests switch it): the per-hyper-parameter passes
+  const char *sw = getenv("OBHIP_GRAD_D3");
+  if (sw && atoi(sw) == 0) return false;
   if (t.ge_d3_cap == b.md.cap) return t.ge_d3_ok;
   HostTimer ht("build_d3_groups (rebuild)");
   build_sparse_views(t, b);
@@ -1442,8 +1445,6 @@ static bool build_d3_groups(obhip_terms &t, const obhip_basis &b) {
   t.ge_d3.clear();
   t.ge_d3_cap = b.md.cap;
   t.ge_d3_ok = false;
-  static const bool off = getenv("OBHIP_GRAD_D3") && atoi(getenv("OBHIP_GRAD_D3")) == 0;  // A/B runs
-  if (off) return false;
   // two blocks per CU: 2 x Mu x 65 x 8 B <= 160 KB
   constexpr size_t kMuCap = 152;
   static_assert(kMuCap <= (size_t)kTlWaves * kD3Pre, "the tile is prefetched into registers");
