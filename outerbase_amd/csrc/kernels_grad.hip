@@ -757,7 +757,9 @@ k_bt_times_u(const double *__restrict__ Bmat, uint64_t p_pad, const double *__re
 typedef double ge_d4 __attribute__((ext_vector_type(4)));
 constexpr int kGeNU = 4, kGeSteps = 16, kGeInflight = 8;
 
-template <int WE, int W, int NHB>
+// SQF: the unit's product is squared before it enters the MFMA (the squared stores' products are
+// the squares of the plain ones: the double-buffered kernel stages the raw columns by LDS-direct loads)
+template <int WE, int W, int NHB, bool SQF = false>
 struct GePipe {
   static constexpr int NU = kGeNU, TOT = kGeSteps * kGeNU;
   static constexpr int D = (kGeInflight / WE) > 0 ? kGeInflight / WE : 1;
@@ -804,6 +806,7 @@ struct GePipe {
       double v = buf[s];
 #pragma unroll
       for (int j = 1; j < WE; ++j) v *= buf[s + j];
+      if constexpr (SQF) v = v * v;
 #pragma unroll
       for (int hb = 0; hb < NHB; ++hb)
         c.acc[unit][hb] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[(st % 2) * NHB + hb], v,
@@ -834,16 +837,16 @@ struct GeCtx {
   ge_d4 acc[kGeNU][NHB];
 };
 
-template <int W, int NHB>
+template <int W, int NHB, bool SQF = false>
 __device__ __forceinline__ void ge_tile(GeCtx<W, NHB> &c, int we) {
   if (we == W) {
-    GePipe<W, W, NHB>::run(c);
+    GePipe<W, W, NHB, SQF>::run(c);
   } else if (we == W - 1) {
-    GePipe<W - 1, W, NHB>::run(c);
+    GePipe<W - 1, W, NHB, SQF>::run(c);
   } else if (W >= 3 && we == W - 2) {
-    GePipe<(W >= 3 ? W - 2 : 1), W, NHB>::run(c);
+    GePipe<(W >= 3 ? W - 2 : 1), W, NHB, SQF>::run(c);
   } else {
-    GePipe<(W >= 4 ? W - 3 : 1), W, NHB>::run(c);
+    GePipe<(W >= 4 ? W - 3 : 1), W, NHB, SQF>::run(c);
   }
 }
 
@@ -927,6 +930,108 @@ k_tmm_ge0(const double *__restrict__ bm, const double *__restrict__ scale,
   }
 }
 
+// The same with the NEXT tile on its way while this one is worked on: two tile buffers, one block of
+// 16 waves per CU, the value columns fetched by LDS-direct loads (global_load_lds_dword as in k_hm2:
+// no staging registers -- the kernel sits at 104-128 VGPRs -- and no ds_write), the 16 weight
+// columns (one per wave) through two registers.  The columns arrive raw, so the squared stores'
+// products are formed as squares of the plain products (GePipe<SQF>).  k_tmm_ge0 above loads its
+// tile between two barriers: with two blocks per CU one computes while the other loads, but at a
+// few microseconds of compute per tile the matrix pipe still idled half of the time.
+template <int W2, bool SQ>
+__global__ void __launch_bounds__(1024, 4)
+k_tmm_ge0_db(const double *__restrict__ bm, const double *__restrict__ scale,
+             const uint32_t *__restrict__ ucol, int Mu, uint64_t Mtot,
+             const uint32_t *__restrict__ colsw, const uint32_t *__restrict__ sperm,
+             const int *__restrict__ ge0abs, int nhyp, int h0, const double *__restrict__ a, uint64_t n,
+             uint64_t ntiles, uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ part) {
+  extern __shared__ double lds[];
+  constexpr int W = 2 * W2, NHB = 1, HS = 16, NW = 16;
+  const int lane = threadIdx.x & 63, t16 = lane & 15, r4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
+  const uint32_t tile_bytes = (uint32_t)(Mu + HS) * (kTlPitch * 8);
+
+  GeCtx<W, NHB> c;
+  int nzmax = 1;
+#pragma unroll
+  for (int g = 0; g < kGeNU; ++g) {
+    const uint64_t slot = ((uint64_t)blockIdx.y * NW + wave) * 64 + g * 16 + t16;
+    const bool ok = slot < p_pad;
+    const uint64_t k = ok ? sperm[slot] : 0;
+    uint32_t cw[W2];
+#pragma unroll
+    for (int w = 0; w < W2; ++w) {
+      cw[w] = ok ? colsw[k * W2 + w] : 0u;  // column 0 = ones
+      c.ad[g][2 * w] = lds0 + (cw[w] & 0xffffu) * (kTlPitch * 8) + r4 * 8;
+      c.ad[g][2 * w + 1] = lds0 + (cw[w] >> 16) * (kTlPitch * 8) + r4 * 8;
+    }
+    nzmax = max(nzmax, tl_nnz<W2>(cw));
+    c.acc[g][0] = ge_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  c.aw[0] = lds0 + (uint32_t)(Mu + t16) * (kTlPitch * 8) + r4 * 8;
+  const int we = tl_variant<W>(wave_max_i32(nzmax));
+  const bool live = ((uint64_t)blockIdx.y * NW + wave) * 64 < p_pad;
+  // wave h stages weight column h: a s (SQ: a s^2) times ge[h, 0] (SQ: 2 ge[h, 0]) of the row = lane
+  const int wcol = h0 + wave < nhyp ? ge0abs[h0 + wave] : -1;
+
+  // next tile -> the other buffer.  (The weight column's two loads are requested BEFORE the
+  // LDS-direct loads and used at the top of the next tile: the compiler's vmcnt bookkeeping does
+  // not see the inline-asm loads, a use right here would wait for all of them.)
+  double gvn = 0.0, wrn = 0.0;
+  auto prefetch = [&](uint64_t tile, int bsel) {
+    const char *tb = (const char *)(bm + tile * Mtot * kTileRows);
+    const uint64_t row = tile * kTileRows + lane;
+    gvn = wrn = 0.0;
+    if (row < n && wcol >= 0) {
+      const double sc = scale[row];
+      wrn = a[row] * (SQ ? sc * sc : sc);
+      gvn = ((const double *)tb)[(size_t)wcol * kTileRows + lane];
+    }
+    const uint32_t l0 = lds0 + (bsel ? tile_bytes : 0u);
+    for (int u = wave; u < Mu; u += NW) {
+      const uint32_t col = __builtin_amdgcn_readfirstlane(ucol[u]);
+      const uint64_t ga = (uint64_t)(tb + (size_t)col * (kTileRows * 8));
+      const uint64_t gu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ga >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ga);
+      const uint32_t ld = (uint32_t)__builtin_amdgcn_readfirstlane((int)(l0 + (uint32_t)u * (kTlPitch * 8)));
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\t"
+                   "global_load_lds_dword %0, %1 offset:256"
+                   :: "v"((uint32_t)lane * 4u), "s"((const char *)gu), "s"(ld) : "memory");
+    }
+  };
+  if (t0 < t1) prefetch(t0, 0);
+
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    const int bsel = (int)((tile - t0) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed
+    lds[(bsel ? tile_bytes / 8 : 0) + (Mu + wave) * kTlPitch + lane] = wrn * (SQ ? 2.0 * gvn : gvn);
+    __syncthreads();  // tile and weights complete; every wave is done with the other buffer
+    if (tile + 1 < t1) prefetch(tile + 1, bsel ^ 1);
+    if (live) ge_tile<W, NHB, SQ>(c, we);
+    // on to the other buffer
+    const uint32_t delta = bsel ? 0u - tile_bytes : tile_bytes;
+#pragma unroll
+    for (int g = 0; g < kGeNU; ++g)
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        c.ad[g][j] += delta;
+        asm volatile("" : "+v"(c.ad[g][j]));
+      }
+    c.aw[0] += delta;
+    asm volatile("" : "+v"(c.aw[0]));
+  }
+#pragma unroll
+  for (int g = 0; g < kGeNU; ++g) {
+    const uint64_t slot = ((uint64_t)blockIdx.y * NW + wave) * 64 + g * 16 + t16;
+    if (slot >= p_pad) continue;
+    const uint64_t k = sperm[slot];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[((uint64_t)blockIdx.x * HS + r4 + 4 * v) * p_pad + k] = c.acc[g][0][v];
+  }
+}
+
 // D[h0 + h][k] = sum of the row-split partials laid out [split][hs][p_pad]
 __global__ void k_ge0_reduce(const double *__restrict__ part, int nsplit, int hs, uint64_t p_pad,
                              int p, int nh, double *__restrict__ out /* [nh][p] */) {
@@ -975,9 +1080,24 @@ int run_tmm_ge0_sq(const obhip_basis &src, obhip_terms &t, const int *d_c0, int 
   OB_HIP(hipGetLastError());
   return 0;
 }
+template <int W2, bool SQ>
+int run_tmm_ge0_db(const obhip_basis &src, obhip_terms &t, const int *d_c0, int nhyp, int h0,
+                   const double *d_a, dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
+  const size_t lds = 2 * (t.Mu + 16) * kTlPitch * sizeof(double);
+  OB_TRY(ensure_dyn_lds((const void *)k_tmm_ge0_db<W2, SQ>, lds));
+  hipLaunchKernelGGL((k_tmm_ge0_db<W2, SQ>), grid, dim3(1024), lds, cur_stream(), src.bm.p, src.scale.p,
+                     t.ucol.p, (int)t.Mu, src.md.Mc, (const uint32_t *)t.cols.p, t.sperm.p, d_c0, nhyp, h0,
+                     d_a, src.n, ntiles, tps, t.p_pad, part);
+  OB_HIP(hipGetLastError());
+  return 0;
+}
 template <int W2, int NHB>
 int run_tmm_ge0(bool sq, int nw, const obhip_basis &src, obhip_terms &t, const int *d_c0, int nhyp, int h0,
                 const double *d_a, dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
+  if (nw == 32) {  // (16 waves, two tile buffers)
+    if (sq) return run_tmm_ge0_db<W2, true>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+    return run_tmm_ge0_db<W2, false>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+  }
   if (nw == 16) {
     if (sq) return run_tmm_ge0_sq<W2, NHB, true, 16>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
     return run_tmm_ge0_sq<W2, NHB, false, 16>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
@@ -1006,10 +1126,17 @@ int launch_tmm_ge0(obhip_basis &b, obhip_terms &t, bool squared, const double *d
   const uint64_t ntiles = b.n_pad / kTileRows;
   // a tile of more than half the LDS leaves one block per CU: 16 waves in it instead of 8
   // (OBHIP_GE0_WAVES=8|16 forces either: A/B runs)
+  // ... and where TWO tiles fit the LDS, 16 waves with the next tile prefetched into the second
+  // buffer (k_tmm_ge0_db; nw = 32 stands for it below)
   static const int force_nw = getenv("OBHIP_GE0_WAVES") ? atoi(getenv("OBHIP_GE0_WAVES")) : 0;
-  const bool one_per_cu = (t.Mu + 16) * kTlPitch * sizeof(double) > 80 * 1024;
-  const int nw = force_nw == 8 || force_nw == 16 ? force_nw : (one_per_cu ? 16 : 8);
-  const uint64_t tpb = (uint64_t)nw * 64;
+  const size_t tile_lds = (t.Mu + 16) * kTlPitch * sizeof(double);
+  const bool two_tiles = 2 * tile_lds <= 156 * 1024;
+  bool one_per_cu = tile_lds > 80 * 1024;
+  int nw = one_per_cu ? 16 : 8;
+  if (two_tiles) nw = 32;
+  if (force_nw == 8 || force_nw == 16 || (force_nw == 32 && two_tiles)) nw = force_nw;
+  if (nw == 32) one_per_cu = true;
+  const uint64_t tpb = (uint64_t)(nw == 32 ? 16 : nw) * 64;
   const uint64_t pblocks = (t.p_pad + tpb - 1) / tpb;
   const int ncu = device_cus(b.device);
   uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)ncu * (one_per_cu ? 1 : 2) / pblocks);

@@ -1268,17 +1268,19 @@ int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B, con
 }
 
 // d_out (p) = B^T a and d_out2 (p) = (B^2)^T a2 (a2 null: ones -> sqcolsums) in ONE pass of
-// k_tmm_tl<DUAL>; kNotFused when the terms do not fit that instantiation (more than 4 factors, a
-// tile beyond the prefetch registers): the caller then makes the two passes.
+// k_tmm_tl<DUAL>; kNotFused when the terms do not fit that instantiation (more than 6 factors): the caller then makes the two passes.
 int launch_tmm_dual(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, const double *d_a2,
                     double *d_out2) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   static const bool off = getenv("OBHIP_TMM_DUAL") && atoi(getenv("OBHIP_TMM_DUAL")) == 0;
   const int w2 = (int)(t.W / 2);
-  if (off || beyond_lds(t) || !tmm_tl_supports(t) || w2 > 2 || t.Mu > (uint64_t)kTlWaves * kTlPre) return kNotFused;
+  if (off || beyond_lds(t) || !tmm_tl_supports(t) || w2 > 3) return kNotFused;
+  const bool pf = t.Mu <= (uint64_t)kTlWaves * kTlPre;  // (else the tile is loaded between the barriers)
   const uint64_t ntiles = b.n_pad / kTileRows, p_pad = t.p_pad;
+  // six-slot terms (obfit's eight-dimensional sets): 4 terms per lane at 123 VGPRs, 8 would spill
+  const int npmax = w2 <= 2 ? 4 : 2;
   int npair = 1;
-  while (npair < 4 && (uint64_t)kTlWaves * npair * kTlGP * 64 < p_pad) npair *= 2;
+  while (npair < npmax && (uint64_t)kTlWaves * npair * kTlGP * 64 < p_pad) npair *= 2;
   const uint64_t tpb = (uint64_t)kTlWaves * npair * kTlGP * 64;
   const uint64_t pblocks = (p_pad + tpb - 1) / tpb;
   uint64_t nsplit = std::max<uint64_t>(1, (uint64_t)device_cus(b.device) * 2 / pblocks);
@@ -1292,18 +1294,28 @@ int launch_tmm_dual(const obhip_basis &b, obhip_terms &t, const double *d_a, dou
   const size_t lds = t.Mu * kTlPitch * sizeof(double);
   {
     ProfScope ps("tmm_dual");
-#define OB_TD(W2_, NP_)                                                                                      \
+#define OB_TD2(W2_, NP_, PF_)                                                                               \
   do {                                                                                                       \
-    OB_TRY(set_lds(k_tmm_tl<W2_, false, NP_, true, true>, lds));                                             \
-    hipLaunchKernelGGL((k_tmm_tl<W2_, false, NP_, true, true>), grid, dim3(kTlThreads), lds, cur_stream(),   \
+    OB_TRY(set_lds(k_tmm_tl<W2_, false, NP_, PF_, true>, lds));                                              \
+    hipLaunchKernelGGL((k_tmm_tl<W2_, false, NP_, PF_, true>), grid, dim3(kTlThreads), lds, cur_stream(),    \
                        b.bm.p, b.scale.p, t.ucol.p, (int)t.Mu, b.md.Mc, (const uint32_t *)t.cols.p,          \
                        t.sperm.p, d_a, b.n, ntiles, tps, p_pad, part, d_a2, part2);                          \
   } while (0)
+#define OB_TD(W2_, NP_)                                                                                      \
+  do {                                                                                                       \
+    if (pf)                                                                                                  \
+      OB_TD2(W2_, NP_, true);                                                                                \
+    else                                                                                                     \
+      OB_TD2(W2_, NP_, false);                                                                               \
+  } while (0)
     if (w2 == 1) {
       if (npair == 4) OB_TD(1, 4); else if (npair == 2) OB_TD(1, 2); else OB_TD(1, 1);
-    } else {
+    } else if (w2 == 2) {
       if (npair == 4) OB_TD(2, 4); else if (npair == 2) OB_TD(2, 2); else OB_TD(2, 1);
+    } else {
+      if (npair == 2) OB_TD(3, 2); else OB_TD(3, 1);
     }
+#undef OB_TD2
 #undef OB_TD
     OB_HIP(hipGetLastError());
   }
