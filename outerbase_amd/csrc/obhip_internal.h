@@ -424,6 +424,11 @@ int grad_mm_dev(obhip_basis &b, obhip_terms &t, bool squared, const double *a_ho
                 double *d_M, DevBuf<double> &dge);
 int grad_mm_dot_dev(obhip_basis &b, obhip_terms &t, const double *a_host, const double *d_M,
                     const double *d_w, double *out_host);
+constexpr int kD3Pre = 20;  // k_tmm_d3: prefetch registers per thread => at most 8 * 20 columns per group
+// one group of obhip_terms::ge_d3 (kernels_grad_d3.hip): d_out (device, [2 nh][v.p]) = u1 of the
+// group's first hyper-parameter, of its second, u2 likewise; mode bit 0: u1, bit 1: u2
+int launch_tmm_d3(obhip_basis &b, const obhip_terms::GeD3 &g, int mode, const double *d_w1, const double *d_w2,
+                  double *d_out);
 int grad_dual_dev(obhip_basis &b, obhip_terms &t, const double *a_host, const double *d_M, const double *d_w1,
                   const double *d_w2, double *out_dot, double *out_sq);
 int grad_wdot_dev(const double *d_G, const double *d_w, uint64_t n, uint64_t ncol, double *out_host);
