@@ -337,8 +337,8 @@ size_t hm2_lds_bytes(const obhip_terms &t, bool ro, int variant) {
   size_t slots = 0;
   if (variant == 2 || variant == 3)
     slots = ro ? 4608 : 0;  // (12 waves x 6 units, 8 x 8: the experiments at 4-factor terms)
-  else if (nu == 4 && (ro || w2 == 3 || variant == 5))
-    slots = 4096;
+  else if (nu == 4 && (ro || variant == 5 || (w2 == 3 && variant == 7)))
+    slots = 4096;  // (the instantiations that keep the coefficients in LDS: launch_hm2)
   return ((size_t)2 * t.Mu * kTlPitch + 2 * 128 + 2 * kHm2RedSlots + slots) * sizeof(double);
 }
 
@@ -372,9 +372,13 @@ int launch_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const do
     OB_HM2(2, 4, 16, 8, true);
   }
   if (w2 == 3) {  // terms of 5 and 6 factors (obfit's eight-dimensional examples)
+    // (n = 1e6, p = 4096, d = 8, tools/hm_bench.py: sums outside the pipeline, 8 reads in flight 1.797 ms,
+    // 12 in flight 1.780, sums inside -- 128 VGPRs, two of them spilled outside the loops -- 1.723)
+    if (variant == 5) OB_HM2(3, 4, 16, 12, false);
+    if (variant == 7) OB_HM2(3, 4, 16, 8, false);
     if (pp <= 16 * 1 * 64) OB_HM2(3, 1, 16, 12, true);
     if (pp <= 16 * 2 * 64) OB_HM2(3, 2, 16, 12, true);
-    OB_HM2(3, 4, 16, 8, false);
+    OB_HM2(3, 4, 16, 8, true);
   }
   if (pp <= 16 * 1 * 64) OB_HM2(1, 1, 16, 12, true);
   if (pp <= 16 * 2 * 64) OB_HM2(1, 2, 16, 12, true);
