@@ -23,6 +23,8 @@ Before the warm-up a job with more than one rank verifies its transport
 `parity_check` = rank 0's predictions against the oracle's basis, Newton stationarity with the
 matrix-free kernels summed through the communicator, and `fit_vs_oracle` -- Gram + Cholesky +
 predict of the device against the oracle's own fit on the first 20 000 rows.
+`obfit_eval` (one rank): one second-stage function evaluation of obfit on the same rows and
+terms -- device PCG fit plus all hyper-parameter gradients -- with its phases.
 `python bench.py --gpus N` launches its own N ranks (one process per GPU,
 torch.distributed.run) when it is not already running under a launcher; `--sim-ranks N` times
 on ONE GPU the step a rank of an N-GPU job runs.  Prints ONE JSON line on rank 0.
@@ -66,6 +68,8 @@ def parse():
                     help="rank 0 writes theta and its first 1000 de-standardised predictions here (.npz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-backend", action="store_true")
+    ap.add_argument("--no-obfit-eval", action="store_true",
+                    help="skip the timing of one obfit function evaluation (PCG fit + hyper-gradients)")
     ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the other BASELINE.json configurations (configs[1], configs[4]'s shard)")
@@ -464,6 +468,69 @@ def secondary_rooflines(hp, prof):
     return out
 
 
+def obfit_evaluation(kinds, knots, p, n, torch, _lib, reps=3):
+    """One second-stage function evaluation of obfit (R/fitting.R:123-136 through BFGS_lpdf ->
+    .lpdfwrapper, R/optimization.R: updatehyp, updateom, updatepara, lpdf$optcg, then value and
+    gradients) on the bench's rows and terms: lpdfvec(loglik_gauss, logpr_gauss) with the marginal
+    adjustment on -- the device PCG fit followed by ONE update with the hyper-parameter and
+    parameter gradients.  Untimed region of the bench; hipEvent scopes of the library for the
+    phases.  The model layer takes host arrays at creation, so the seeded rows go through the
+    host once (not timed)."""
+    import numpy as np
+    import outerbase_amd as ob
+    from outerbase_amd.driver import bench_knots, KIND_ID
+    d = len(kinds)
+    kid = (C.c_int * d)(*[KIND_ID[k] for k in kinds])
+    x = torch.empty((d, n), dtype=torch.float64, device="cuda")
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    _lib.call("obhip_synth_xy_dev", 42, 0, n, d, C.cast(kid, C.c_void_p), x.data_ptr(), y.data_ptr())
+    torch.cuda.synchronize()
+    xh = np.ascontiguousarray(x.cpu().numpy().T)
+    yh = y.cpu().numpy()
+    del x, y
+    yh = (yh - yh.mean()) / yh.std(ddof=1)
+    om = ob.outermod()
+    ob.setcovfs(om, kinds)
+    ob.setknot(om, bench_knots(kinds, knots))
+    terms = om.selectterms(p)
+    lik = ob.loglik_gauss(om, terms, yh, xh)
+    pr = ob.logpr_gauss(om, terms)
+    vec = ob.lpdfvec(lik, pr)
+    hyp = ob.gethyp(om)
+    para = np.asarray(ob.getpara(vec), dtype=np.float64)
+
+    def evaluate(i):
+        om.updatehyp(hyp + 1e-3 * (i + 1))
+        vec.updateom()
+        vec.updatepara(para)
+        vec.optcg(1e-3, 100)             # BFGS_lpdf's tolerance and step cap (R/optimization.R:160-175)
+    evaluate(-1)                         # first use: views, tables, instantiations
+    torch.cuda.synchronize()
+    _lib.call("obhip_profile_reset")
+    _lib.call("obhip_profile_enable", 1)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        evaluate(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    phases = {}
+    for name in ("hessmult", "tmm_d3", "sqtmm_gradhyp_dense", "build_basis", "build_basis_grad", "mm", "tmm",
+                 "sqtmm", "tmm_dual"):
+        cnt, tot = C.c_uint64(0), C.c_double(0)
+        _lib.call("obhip_profile_get", name.encode(), C.byref(cnt), C.byref(tot))
+        if cnt.value:
+            phases[name] = {"launches_per_evaluation": cnt.value / reps, "ms_per_evaluation": round(tot.value / reps, 3)}
+    _lib.call("obhip_profile_enable", 0)
+    out = {"workload": "one second-stage obfit function evaluation on the headline rows and terms: updatehyp, "
+                       "updateom, updatepara, lpdf$optcg (device PCG, tol 1e-3, <= 100 steps), then value, "
+                       "%d hyper-parameter and 2 parameter gradients with the marginal adjustment "
+                       "(lpdfvec of loglik_gauss and logpr_gauss)" % len(hyp),
+           "ms_per_evaluation": ms, "cg_iterations": int(vec.cgiters) if hasattr(vec, "cgiters") else None,
+           "phases": phases, "gradhyp_norm": float(np.linalg.norm(np.asarray(vec.gradhyp)))}
+    del vec, lik, pr
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -636,6 +703,14 @@ def main():
                      "125 000 rows per GPU (n=1e6 at 8 GPUs)",
             mixed, 40, 16384, 125_000, rank, vworld, transport, 3, sync, torch, dist, _lib, world))
 
+    # obfit's function evaluation on the same problem (north_star's entry point runs these by the
+    # hundred): one process, after everything that is timed
+    obfit_eval = None
+    if headline and world == 1 and not transport and not args.no_obfit_eval:
+        torch.cuda.empty_cache()
+        _lib.call("obhip_trim_pool")
+        obfit_eval = obfit_evaluation(kinds, args.knots, args.p, n_total, torch, _lib)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -686,6 +761,7 @@ def main():
         "alt_backend": alt,
         "config3": config3,
         "configs": others,
+        "obfit_eval": obfit_eval,
     }
     if transport:
         out["sim_ranks"] = vworld

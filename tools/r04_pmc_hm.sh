@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r04
 mkdir -p $OUT
-LEAN="--no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity"
+LEAN="--no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity --no-obfit-eval"
 : > $OUT/pmc_products.txt
 for v1 in 1 0; do
   for set in "LdsUtil VALUBusy" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do

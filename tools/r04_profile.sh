@@ -51,7 +51,7 @@ timeout -k 10 900 python3 bench.py > $OUT/bench_line_$TAG.json 2> $OUT/bench_$TA
 echo "bench ok"
 # the per-rank step of an N-GPU job on this one GPU: N virtual ranks (obhip_comm_init_sim: the real
 # exchange-buffer layout, pack, unpack, replicated solve; the sum itself is one device pass)
-LEAN="--no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity"
+LEAN="--no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity --no-obfit-eval"
 rm -f $OUT/bench_lines_shard_sizes_$TAG.jsonl
 for spec in "125000 8" "250000 4" "500000 2"; do
   set -- $spec
