@@ -185,6 +185,11 @@ def test_bench_self_launch_two_ranks(tmp_path):
     r1 = subprocess.run(base + ["--gpus", "1", "--no-alt-backend", "--no-fit-parity", "--dump", d1], env=env,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r1.returncode == 0, r1.stderr.decode(errors="replace")[-3000:]
+    # the one-rank line also times an obfit function evaluation (PCG fit + hyper-gradients)
+    line1 = [json.loads(l) for l in r1.stdout.decode().splitlines() if l.startswith("{")][-1]
+    oe = line1["obfit_eval"]
+    assert oe["ms_per_evaluation"] > 0 and np.isfinite(oe["gradhyp_norm"]) and oe["gradhyp_norm"] > 0
+    assert oe["phases"]["tmm_d3"]["launches_per_evaluation"] >= 1        # the fused gradient pass ran
     two, one = np.load(d2), np.load(d1)
     assert int(two["world"]) == 2 and int(one["world"]) == 1 and int(two["n_total"]) == 200000
     assert np.max(np.abs(two["meansd"] - one["meansd"])) < 1e-12 * np.max(np.abs(one["meansd"]))
