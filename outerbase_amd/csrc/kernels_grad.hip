@@ -1203,7 +1203,12 @@ int launch_bt_times_ge0(obhip_basis &b, obhip_terms &t, bool squared, const doub
 static void build_sparse_views(obhip_terms &t, const obhip_basis &b) {
   const obhip_model &m = *b.model;
   const uint64_t nh = m.nhyp(), d = t.d, de = d + 2 * nh;
-  if (t.ge_sviews.size() == nh && t.ge_dviews.size() == nh) return;
+  // (keyed by the dimension of every hyper-parameter: the same terms may meet a basis of another
+  // model with as many hyper-parameters laid out differently)
+  std::vector<uint64_t> sig(m.hypmatch.begin(), m.hypmatch.end());
+  if (t.ge_sviews.size() == nh && t.ge_dviews.size() == nh && t.ge_views_sig == sig) return;
+  t.ge_views_sig = sig;
+  t.ge_d3_cap.clear();
   t.ge_sviews.clear();
   t.ge_sviews.resize(nh);
   t.ge_dviews.clear();
@@ -1304,15 +1309,23 @@ static bool build_d3_groups(obhip_terms &t, const obhip_basis &b) {
   // OBHIP_GRAD_D3=0 (read per call: the tests switch it): the per-hyper-parameter passes
   const char *sw = getenv("OBHIP_GRAD_D3");
   if (sw && atoi(sw) == 0) return false;
-  if (t.ge_d3_cap == b.md.cap) return t.ge_d3_ok;
-  HostTimer ht("build_d3_groups (rebuild)");
-  build_sparse_views(t, b);
+  // the tables hold column numbers of the gradient basis: keyed by everything those depend on
+  // (level caps, first column of every dimension, first delta column of every hyper-parameter)
   const obhip_model &m = *b.model;
   const obhip_gradbasis &g = *b.grad;
   const std::vector<DimDesc> &dims = b.md.dims_h;
   const uint64_t d = t.d;
+  std::vector<int64_t> key = b.md.cap;
+  for (uint64_t l = 0; l < d; ++l) key.push_back(dims[l].ccol0);
+  for (const GradHyp &gh : g.hyps_h) {
+    key.push_back(gh.dim);
+    key.push_back(gh.dcol);
+  }
+  if (t.ge_d3_cap == key) return t.ge_d3_ok;
+  HostTimer ht("build_d3_groups (rebuild)");
+  build_sparse_views(t, b);
   t.ge_d3.clear();
-  t.ge_d3_cap = b.md.cap;
+  t.ge_d3_cap = key;
   t.ge_d3_ok = false;
   // two blocks per CU: 2 x Mu x 65 x 8 B <= 160 KB
   constexpr size_t kMuCap = 152;
@@ -1432,9 +1445,10 @@ obhip_terms *grad_view_delta(obhip_terms &t, const obhip_basis &b, uint64_t h,
 obhip_terms *grad_view(obhip_terms &t, const obhip_basis &b, uint64_t h) {
   const obhip_model &m = *b.model;
   const uint64_t nh = m.nhyp(), d = t.d, de = d + 2 * nh;
-  if (t.ge_views.size() != nh) {
+  if (t.ge_views.size() != nh || t.ge_full_sig != m.hypmatch) {
     t.ge_views.clear();
     t.ge_views.resize(nh);
+    t.ge_full_sig = m.hypmatch;
   }
   if (!t.ge_views[h]) {
     auto v = std::make_unique<obhip_terms>();

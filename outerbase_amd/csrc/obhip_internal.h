@@ -240,6 +240,8 @@ struct obhip_terms {
   // their indices (transposed gradient products: the other terms come from one dense pass)
   std::vector<std::unique_ptr<obhip_terms>> ge_sviews;
   std::vector<std::vector<uint32_t>> ge_sidx;
+  std::vector<uint64_t> ge_views_sig;  // hypmatch of the model the views were built for
+  std::vector<uint64_t> ge_full_sig;   // the same for ge_views
   // restricted likewise, the dimension's factor replaced by the delta column (products B a)
   std::vector<std::unique_ptr<obhip_terms>> ge_dviews;
   // all ge_sviews concatenated (one B^T a pass for every hyper-parameter), offsets per h
@@ -260,7 +262,7 @@ struct obhip_terms {
                                       // view-terms [off[j], off[j + 1]) = the terms ge_sidx[hyp0[j]]
   };
   std::vector<GeD3> ge_d3;
-  std::vector<int64_t> ge_d3_cap;     // the caps ge_d3 was built for
+  std::vector<int64_t> ge_d3_cap;     // key of the column layout ge_d3 was built for (build_d3_groups)
   bool ge_d3_ok = false;              // false: some view does not fit the kernel -> older passes
   // device view of the model capped at maxlev, for the fused predictor
   obhip::ModelDev pred_md;

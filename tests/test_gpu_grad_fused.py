@@ -172,3 +172,28 @@ def test_views_too_wide_for_the_fused_kernel_take_the_older_passes():
     bd = ob.outerbase(om_d, x)
     assert relerr(bd.tmatmul_gradhyp(terms, v), O.ob_tmm_gradhyp(bo, terms, v)[1]) < 1e-9
     assert relerr(bd.sqcolsums_gradhyp(terms), O.ob_sqcolsums_gradhyp(bo, terms)) < 1e-9
+
+
+def test_one_terms_handle_on_bases_of_two_models():
+    """The view tables cached in a terms handle hold column numbers of a gradient basis; the same
+    handle may meet the basis of another model with as many hyper-parameters laid out differently
+    (here 2 + 1 + 1 against 1 + 2 + 1): the caches are keyed by that layout."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    rng = np.random.default_rng(4)
+    n, p = 300, 150
+    terms = random_terms(rng, p, 3, 4, 3)
+    v, a = rng.standard_normal(n), rng.standard_normal(p)
+    handle = None
+    for kinds in (["mat25pow", "mat25", "mat25"], ["mat25", "mat25pow", "mat25"], ["mat25pow", "mat25", "mat25"]):
+        om_o, om_d = make_pair(kinds, knots_for(kinds, 14))
+        assert len(om_o.hypmatch) == 4
+        if handle is None:
+            handle = ob.obmod._Terms(om_d, terms)
+        x = sample_x(rng, n, kinds)
+        bo = O.OuterBase(om_o, x, dograd=True)
+        bd = ob.outerbase(om_d, x)
+        assert relerr(bd.tmatmul_gradhyp(handle, v), O.ob_tmm_gradhyp(bo, terms, v)[1]) < 1e-7, kinds     # (a stale table gives errors of order one)
+        assert relerr(bd.sqcolsums_gradhyp(handle), O.ob_sqcolsums_gradhyp(bo, terms)) < 1e-7, kinds     # (a stale table gives errors of order one)
+        assert relerr(bd.matmul_gradhyp_dot(handle, a, v), O.ob_mm_gradhyp(bo, terms, a)[1].T @ v) < 1e-7, kinds     # (a stale table gives errors of order one)
+        assert relerr(bd.matmul_gradhyp(handle, a), O.ob_mm_gradhyp(bo, terms, a)[1]) < 1e-7, kinds     # (a stale table gives errors of order one)
