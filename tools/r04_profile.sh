@@ -36,7 +36,7 @@ if [ "$1" = "--check" ]; then
 fi
 TAG=${1:-a}
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$TAG -o p -- \
-  python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity \
+  python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity --no-obfit-eval \
   > $OUT/bench_line_profiled_$TAG.json 2> $OUT/stats_$TAG.err ) || { tail -5 $OUT/stats_$TAG.err; exit 1; }
 rm -f $OUT/stats_$TAG/*kernel_trace.csv
 echo "stats ok"

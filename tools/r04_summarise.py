@@ -113,16 +113,16 @@ def main():
     for sub, out, cmdline in (
             ("stats_%s" % tag, "r04_kernel_stats_bench",
              "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 "
-             "--no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity"),
+             "--no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity --no-obfit-eval"),
             ("stats125_%s" % tag, "r04_kernel_stats_shard_125000_rows_8_virtual_ranks",
              "rocprofv3 --kernel-trace --stats -- python3 bench.py --rows 125000 --sim-ranks 8 --steps 5 "
-             "--warmup 1 --no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity"),
+             "--warmup 1 --no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity --no-obfit-eval"),
             ("statsc1_%s" % tag, "r04_kernel_stats_configs1",
              "rocprofv3 --kernel-trace --stats -- python3 bench.py --dims 10 --p 1024 --rows 100000 --steps 20 "
-             "--warmup 2 --no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity"),
+             "--warmup 2 --no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity --no-obfit-eval"),
             ("statscg_%s" % tag, "r04_kernel_stats_bench_cg",
              "rocprofv3 --kernel-trace --stats -- python3 bench.py --backend cg --steps 3 --warmup 1 "
-             "--no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity")):
+             "--no-cpu-baseline --no-alt-backend --no-config3 --no-configs --no-fit-parity --no-obfit-eval")):
         st = os.path.join(SRC, sub)
         for f in os.listdir(st) if os.path.isdir(st) else []:
             if f.endswith("kernel_stats.csv"):
