@@ -453,10 +453,11 @@ struct Loglik : obhip_lpdf {
   // grad = B^T r and, when asked for, gradhyp = yhat_gradhyp^T r -- the reference forms the
   // n x nhyp matrix yhat_gradhyp = matmul_gradhyp(terms, coeff) first (loglik_gauss.cpp:120-127);
   // it is only ever contracted with r, which grad_mm_dot_dev does without forming it
-  int backward() {
+  // have_btr: dpv already holds this rank's B^T r (the fused pass of LoglikGauss::update)
+  int backward(bool have_btr = false) {
     const uint64_t p = nterms;
     OB_TRY(dpv.alloc(p));
-    OB_TRY(launch_tmm(*ob, *t, r.p, dpv.p, false));
+    if (!have_btr) OB_TRY(launch_tmm(*ob, *t, r.p, dpv.p, false));
     grad.resize(p);
     if (comm) OB_TRY(comm_allreduce(comm, dpv.p, p));
     OB_TRY(d2h(grad.data(), dpv.p, p * sizeof(double)));
@@ -529,16 +530,34 @@ struct LoglikGauss : Loglik {
     return 0;
   }
   int update(const double *c) override {  // loglik_gauss.cpp:110-130, loglik_std.cpp:100-120
-    OB_TRY(forward(c));
     const double e2 = std::exp(-2.0 * para[0]);
-    OB_TRY(launch_resid(yhat.p, y.p, n, e2, r.p, tmp.p));  // r = -e2 (yhat - y), tmp = yhat - y
-    double ss[2];
-    OB_TRY(launch_sum_sumsq(tmp.p, n, red.p, red.p + 64));
-    OB_TRY(d2h(ss, red.p, 2 * sizeof(double)));
+    double ss[2] = {0.0, 0.0};  // (sum, sum of squares) of yhat - y; only the second is used
+    // With the gradient asked for: B c, B^T r and the residual sum from ONE pass over the basis
+    // (the fused kernel of the PCG's update(), kernels_hm.hip) where the terms fit it
+    bool have_btr = false;
+    static const bool no_fused = getenv("OBHIP_UPDATE_FUSED") && atoi(getenv("OBHIP_UPDATE_FUSED")) == 0;
+    if (compute_grad && !no_fused) {
+      coeff.assign(c, c + nterms);
+      OB_TRY(dcoeff.upload(c, nterms));
+      OB_TRY(dpv.alloc(nterms));
+      const int fused = launch_hessmult_fused(*ob, *t, dcoeff.p, y.p, -e2, e2, dpv.p, yhat.p, red.p + 1);
+      if (fused != kNotFused) {
+        OB_TRY(fused);
+        have_btr = true;
+        OB_TRY(launch_resid(yhat.p, y.p, n, e2, r.p, tmp.p));  // r = -e2 (yhat - y) for gradhyp
+        OB_TRY(d2h(&ss[1], red.p + 1, sizeof(double)));
+      }
+    }
+    if (!have_btr) {
+      OB_TRY(forward(c));
+      OB_TRY(launch_resid(yhat.p, y.p, n, e2, r.p, tmp.p));  // r = -e2 (yhat - y), tmp = yhat - y
+      OB_TRY(launch_sum_sumsq(tmp.p, n, red.p, red.p + 64));
+      OB_TRY(d2h(ss, red.p, 2 * sizeof(double)));
+    }
     OB_TRY(sum_ranks(ss, 2));
     if (compute_val) val = -0.5 * e2 * ss[1] - n_total * para[0];
     if (compute_grad) {
-      OB_TRY(backward());
+      OB_TRY(backward(have_btr));
       if (compute_gradpara) gradpara = {e2 * ss[1] - n_total};
     }
     return 0;
