@@ -1350,11 +1350,15 @@ static bool build_d3_groups(obhip_terms &t, const obhip_basis &b) {
         for (uint64_t q = 0; q < d; ++q) {
           const uint32_t lv = t.lev[(uint64_t)k * d + q];
           if (lv == 0) continue;
-          M.cols.insert((uint32_t)(dims[q].ccol0 + lv - 1));
-          if (q == l)
-            for (int j = 0; j < M.nh; ++j) M.cols.insert((uint32_t)(g.hyps_h[h0 + j].dcol + lv - 1));
-          else
+          // (bits 28-29: how the column is staged -- 0 as it is, 1 times the row's basescale (delta
+          // columns), 2 times basescale x second weight (the dimension's OWN factor): k_tmm_d3)
+          if (q == l) {
+            M.cols.insert((uint32_t)(dims[q].ccol0 + lv - 1) | kD3Own);
+            for (int j = 0; j < M.nh; ++j) M.cols.insert((uint32_t)(g.hyps_h[h0 + j].dcol + lv - 1) | kD3Delta);
+          } else {
+            M.cols.insert((uint32_t)(dims[q].ccol0 + lv - 1));
             ++w;
+          }
         }
         M.maxw = std::max(M.maxw, w);
       }
@@ -1409,8 +1413,9 @@ static bool build_d3_groups(obhip_terms &t, const obhip_basis &b) {
           if (a != M.l && lv > 0) hc[vt * W + w++] = pos[(uint32_t)(dims[a].ccol0 + lv - 1)];
         }
         const uint32_t lv = t.lev[k * d + M.l];
-        hc[vt * W + w++] = pos[(uint32_t)(dims[M.l].ccol0 + lv - 1)];
-        for (int a = 0; a < M.nh; ++a) hc[vt * W + w++] = pos[(uint32_t)(g.hyps_h[M.h0 + a].dcol + lv - 1)];
+        hc[vt * W + w++] = pos[(uint32_t)(dims[M.l].ccol0 + lv - 1) | kD3Own];
+        for (int a = 0; a < M.nh; ++a)
+          hc[vt * W + w++] = pos[(uint32_t)(g.hyps_h[M.h0 + a].dcol + lv - 1) | kD3Delta];
       }
     }
     for (uint64_t k = 0; k < v->p_pad; ++k) order[k] = (uint32_t)k;

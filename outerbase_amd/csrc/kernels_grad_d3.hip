@@ -38,25 +38,29 @@ __global__ void k_d3_reduce(const double *__restrict__ part, int nsplit, int nc,
 // re-reading the other factors: 4 |A| column reads per (term with |A| factors, dimension of two
 // hyper-parameters, row).  Here a view-term reads its |A| - 1 other factors, b and the delta
 // columns of both hyper-parameters ONCE -- |A| + 2 reads -- and feeds four lane accumulators.
+// The row's basescale s and second weight w2 are folded into the tile while it is staged (delta
+// columns times s, the dimension's own factor times s w2; the group's tables give those their own
+// LDS columns), so that the inner loop multiplies by no weight but w1.
 // Skeleton (tile staging, lane = term, hand-issued reads) as k_tmm_tl; the pipeline hands the
 // last 1 + NH factors over singly (TlPipe<..., TAIL>).  MODE bit 0: u1, bit 1: u2.
 template <int W, int NU, int NH, int MODE>
 struct D3Ctx {
   uint32_t ad[NU][W];
   double acc1[NU][NH], acc2[NU][NH];
-  double vs, vs2;  // weights of row = lane
-  double vr, vr2;  // weights of the current row, wave-uniform
+  double vs;  // first weight of row = lane
+  double vr;  // of the current row, wave-uniform
   int rc;
   template <int RR>
   __device__ __forceinline__ void row() {
     if constexpr ((MODE & 1) != 0) vr = readlane_f64(vs, rc + RR);
-    if constexpr ((MODE & 2) != 0) vr2 = readlane_f64(vs2, rc + RR);
   }
-  // buf[S] = the dimension's own factor, buf[S + 1 + h] = the delta column of hyper-parameter h
+  // buf[S] = the dimension's own factor (staged times s w2), buf[S + 1 + h] = the delta column of
+  // hyper-parameter h (staged times s): the row's basescale and second weight cost no instruction
+  // here, the first weight is the multiplier of the accumulation into u1
   template <int RR, int UNIT, int S, bool LEAD>
   __device__ __forceinline__ void use_tail(double o, double (&buf)[12]) {
     double t2 = 0.0;
-    if constexpr ((MODE & 2) != 0) t2 = (LEAD ? o * buf[S] : buf[S]) * vr2;
+    if constexpr ((MODE & 2) != 0) t2 = LEAD ? o * buf[S] : buf[S];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const double g = LEAD ? o * buf[S + 1 + h] : buf[S + 1 + h];
@@ -117,23 +121,28 @@ k_tmm_d3(const double *__restrict__ bm, const double *__restrict__ scale,
   live = wave_max_i32(live ? 1 : 0) != 0;
 
   // this wave stages columns u = wave + 8 q of every tile: their tile offsets, wave-uniform
-  int lu[PF ? PRE : 1];
+  // (lu: tile offset of the column with its staging class in bits 28-29 of the column entry)
+  int lu[PF ? PRE : 1], cl[PF ? PRE : 1];
   double pre[PF ? PRE : 1];
   if (PF) {
 #pragma unroll
     for (int q = 0; q < PRE; ++q) {
       const int u = wave + NW * q;
-      lu[q] = u < Mu ? __builtin_amdgcn_readfirstlane((int)ucol[u] * kTileRows) : 0;
+      const uint32_t e = u < Mu ? (uint32_t)__builtin_amdgcn_readfirstlane((int)ucol[u]) : 0u;
+      lu[q] = (int)(e & kD3ColMask) * kTileRows;
+      cl[q] = (int)(e >> 28);
     }
   }
-  double vsn = 0.0, vs2n = 0.0;
+  // vsn: first weight of row = lane; scn, scw2n: the multipliers of the delta columns and of the
+  // dimension's own factor (0 beyond the last row: padded rows contribute nothing)
+  double vsn = 0.0, scn = 0.0, scw2n = 0.0;
   auto weights = [&](uint64_t tile) {
     const uint64_t row = tile * kTileRows + lane;
-    vsn = vs2n = 0.0;
+    vsn = scn = scw2n = 0.0;
     if (row < n) {
-      const double sc = scale[row];
-      if ((MODE & 1) != 0) vsn = w1[row] * sc;
-      if ((MODE & 2) != 0) vs2n = (w2 ? w2[row] : 1.0) * sc * sc;
+      scn = scale[row];
+      if ((MODE & 1) != 0) vsn = w1[row];
+      if ((MODE & 2) != 0) scw2n = (w2 ? w2[row] : 1.0) * scn;
     }
   };
   auto fetch = [&](uint64_t tile) {
@@ -153,15 +162,19 @@ k_tmm_d3(const double *__restrict__ bm, const double *__restrict__ scale,
 #pragma unroll
       for (int q = 0; q < PRE; ++q) {
         const int u = wave + NW * q;
-        if (u < Mu) lds[u * kTlPitch + lane] = pre[q];
+        const double mlt = cl[q] == 0 ? 1.0 : (cl[q] == 1 ? scn : scw2n);
+        if (u < Mu) lds[u * kTlPitch + lane] = pre[q] * mlt;
       }
     } else {  // (the other block of the CU computes meanwhile)
       const double *src = bm + tile * Mc * kTileRows + lane;
-      for (int u = wave; u < Mu; u += NW) lds[u * kTlPitch + lane] = src[(size_t)ucol[u] * kTileRows];
       weights(tile);
+      for (int u = wave; u < Mu; u += NW) {
+        const uint32_t e = ucol[u];
+        const double mlt = (e >> 28) == 0 ? 1.0 : ((e >> 28) == 1 ? scn : scw2n);
+        lds[u * kTlPitch + lane] = src[(size_t)(e & kD3ColMask) * kTileRows] * mlt;
+      }
     }
     c.vs = vsn;
-    c.vs2 = vs2n;
     __syncthreads();
     if (PF && tile + 1 < t1) fetch(tile + 1);
     if (!live) continue;  // (whole waves beyond p_pad in the last block along p)

@@ -426,6 +426,8 @@ int grad_mm_dev(obhip_basis &b, obhip_terms &t, bool squared, const double *a_ho
                 double *d_M, DevBuf<double> &dge);
 int grad_mm_dot_dev(obhip_basis &b, obhip_terms &t, const double *a_host, const double *d_M,
                     const double *d_w, double *out_host);
+// staging class of a column of a k_tmm_d3 tile, in bits 28-29 of its entry in the group's ucol list
+constexpr uint32_t kD3Delta = 1u << 28, kD3Own = 2u << 28, kD3ColMask = (1u << 28) - 1;
 constexpr int kD3Pre = 20;  // k_tmm_d3: prefetch registers per thread => at most 8 * 20 columns per group
 // one group of obhip_terms::ge_d3 (kernels_grad_d3.hip): d_out (device, [2 nh][v.p]) = u1 of the
 // group's first hyper-parameter, of its second, u2 likewise; mode bit 0: u1, bit 1: u2
