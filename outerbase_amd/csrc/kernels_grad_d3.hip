@@ -241,12 +241,12 @@ int launch_tmm_d3(obhip_basis &b, const obhip_terms::GeD3 &g, int mode, const do
   const obhip_basis &src = *b.grad->gb;
   const obhip_terms &v = *g.v;
   const uint64_t ntiles = b.n_pad / kTileRows;
-  // 8 waves x 2 view-terms per lane, the tile prefetched into registers while the previous one is
-  // worked on.  OBHIP_D3_VARIANT=1 (A/B runs): 4 per lane, the tile loaded between the barriers
-  // (with the prefetch registers it spills 77) -- 1.26 against 1.32 ms per launch at d = 8.  Also
-  // measured: 2 per lane without prefetch 1.27, 16 waves x 1 per lane 1.42 (twice the row-weight
-  // v_readlanes per view-term: the kernel is bound by its VALU work, VALUBusy 60 %, LdsUtil 55 %).
-  static const int variant = getenv("OBHIP_D3_VARIANT") ? atoi(getenv("OBHIP_D3_VARIANT")) : 0;
+  // 8 waves x 4 view-terms per lane, the tile loaded between the barriers (the other block of the CU
+  // computes meanwhile; with prefetch registers this shape spills 77).  OBHIP_D3_VARIANT=0 (A/B runs):
+  // 2 per lane, the tile prefetched into registers -- 1.21 against 1.11 ms per launch at d = 8, 1.96
+  // against 1.91 at C3 (half the row-weight v_readlanes per view-term).  Also measured: 2 per lane
+  // without prefetch 1.27, 16 waves x 1 per lane 1.42 (before the weights went into the staged columns).
+  static const int variant = getenv("OBHIP_D3_VARIANT") ? atoi(getenv("OBHIP_D3_VARIANT")) : 1;
   const int nw = 8;
   const int nu = variant == 1 && v.p_pad > 1024 ? 4 : 2;
   const uint64_t tpb = (uint64_t)nw * nu * 64;
