@@ -483,6 +483,11 @@ int ensure_gradbasis(obhip_basis &b) {
     gecol += (uint64_t)b.md.dims_h[m.hypmatch[h]].ncol - 1;
   }
   OB_TRY(g->hyps.upload(g->hyps_h.data(), nh));
+  {
+    std::vector<int> c0(nh);
+    for (uint64_t h = 0; h < nh; ++h) c0[h] = g->hyps_h[h].gecol;
+    if (nh) OB_TRY(g->ge0col.upload(c0.data(), nh));
+  }
   OB_TRY(g->rotg.upload(hrotg.data(), hrotg.size()));
   OB_TRY(g->kd.upload(hkd.data(), hkd.size()));
   DevBuf<int> dhypst;
@@ -1108,10 +1113,8 @@ int launch_tmm_ge0(obhip_basis &b, obhip_terms &t, bool squared, const double *d
   obhip_gradbasis &g = *b.grad;
   const obhip_basis &src = *g.gb;
   const int nhyp = (int)b.model->nhyp();
-  std::vector<int> c0(nhyp);
-  for (int h = 0; h < nhyp; ++h) c0[h] = g.hyps_h[h].gecol;  // absolute column in the combined array
-  DevBuf<int> dc0;
-  OB_TRY(dc0.upload(c0.data(), c0.size()));
+  const DevBuf<int> &dc0 = g.ge0col;  // absolute columns in the combined array (resident: no upload,
+                                      // and no synchronisation at the end of this function)
   const uint64_t ntiles = b.n_pad / kTileRows;
   // a tile of more than half the LDS leaves one block per CU: 16 waves in it instead of 8
   // (OBHIP_GE0_WAVES=8|16 forces either: A/B runs)
@@ -1152,7 +1155,6 @@ int launch_tmm_ge0(obhip_basis &b, obhip_terms &t, bool squared, const double *d
                        d_out + (uint64_t)h0 * t.p);
     OB_HIP(hipGetLastError());
   }
-  OB_HIP(hipStreamSynchronize(cur_stream()));  // dc0 is a local
   return 0;
 }
 
@@ -1927,49 +1929,50 @@ int grad_dual_dev(obhip_basis &b, obhip_terms &t, const double *a_host, const do
   const obhip_basis &src = *g.gb;
   const uint64_t nh = b.model->nhyp(), n = b.n, p = t.p;
   if (nh == 0) return 0;
-  DevBuf<double> ones, dout, dall;
+  DevBuf<double> ones, dpart, dres;
   if (!d_w2) {
     OB_TRY(ones.alloc(n));
     OB_TRY(launch_fill(ones.p, n, 1.0));
     d_w2 = ones.p;
   }
-  {  // level-0 columns: sum_i w1_i ge[h, 0]_i M_i
-    constexpr int nblk = 256;
-    std::vector<int> c0(nh);
-    for (uint64_t h = 0; h < nh; ++h) c0[h] = g.hyps_h[h].gecol;
-    DevBuf<int> dc0;
-    DevBuf<double> dpart, dres;
-    OB_TRY(dc0.upload(c0.data(), c0.size()));
-    OB_TRY(dpart.alloc(nh * nblk));
-    OB_TRY(dres.alloc(nh));
-    hipLaunchKernelGGL(k_wdot_ge0, dim3(nblk, (unsigned)nh), dim3(256), 0, cur_stream(), src.bm.p, src.md.Mc,
-                       dc0.p, d_M, d_w1, n, dpart.p);
-    hipLaunchKernelGGL(k_wdot2, dim3((unsigned)nh), dim3(64), 0, cur_stream(), dpart.p, nblk, dres.p);
-    OB_HIP(hipGetLastError());
-    OB_TRY(d2h(out_dot, dres.p, nh * sizeof(double)));
-  }
-  OB_TRY(dout.alloc(p * nh));
-  OB_TRY(launch_tmm_ge0(b, t, true, d_w2, dout.p));
-  OB_TRY(d2h(out_sq, dout.p, p * nh * sizeof(double)));
-  std::vector<double> tmp;
+  // The whole sweep is enqueued before the host reads anything: [nh level-0 dot products |
+  // p x nh dense part | per group its 2 nh x view-terms block], ONE copy at the end (every blocking
+  // copy in between would drain the queue: ten of them per evaluation in the first version).
+  uint64_t total = nh + p * nh;
+  std::vector<uint64_t> goff;
   for (const obhip_terms::GeD3 &grp : t.ge_d3) {
+    goff.push_back(total);
+    total += 2 * (uint64_t)grp.nh * grp.v->p;
+  }
+  constexpr int nblk = 256;
+  OB_TRY(dpart.alloc(nh * nblk));
+  OB_TRY(dres.alloc(total));
+  hipLaunchKernelGGL(k_wdot_ge0, dim3(nblk, (unsigned)nh), dim3(256), 0, cur_stream(), src.bm.p, src.md.Mc,
+                     g.ge0col.p, d_M, d_w1, n, dpart.p);
+  hipLaunchKernelGGL(k_wdot2, dim3((unsigned)nh), dim3(64), 0, cur_stream(), dpart.p, nblk, dres.p);
+  OB_HIP(hipGetLastError());
+  OB_TRY(launch_tmm_ge0(b, t, true, d_w2, dres.p + nh));
+  for (size_t gi = 0; gi < t.ge_d3.size(); ++gi) OB_TRY(launch_tmm_d3(b, t.ge_d3[gi], 3, d_w1, d_w2, dres.p + goff[gi]));
+  std::vector<double> host(total);
+  OB_TRY(d2h(host.data(), dres.p, total * sizeof(double)));
+  std::copy(host.begin(), host.begin() + nh, out_dot);
+  std::copy(host.begin() + nh, host.begin() + nh + p * nh, out_sq);
+  for (size_t gi = 0; gi < t.ge_d3.size(); ++gi) {
+    const obhip_terms::GeD3 &grp = t.ge_d3[gi];
     const uint64_t vp = grp.v->p;
-    OB_TRY(dall.alloc(std::max<uint64_t>(2 * grp.nh * vp, dall.n)));
-    OB_TRY(launch_tmm_d3(b, grp, 3, d_w1, d_w2, dall.p));
-    tmp.resize(2 * grp.nh * vp);
-    OB_TRY(d2h(tmp.data(), dall.p, tmp.size() * sizeof(double)));
+    const double *tmp = host.data() + goff[gi];
     for (size_t j = 0; j < grp.hyp0.size(); ++j)
       for (int hh = 0; hh < grp.nh; ++hh) {
         const uint64_t h = grp.hyp0[j] + hh;
         const std::vector<uint32_t> &ix = t.ge_sidx[h];
-        const double *u1 = tmp.data() + hh * vp + grp.off[j];
-        const double *u2 = tmp.data() + (grp.nh + hh) * vp + grp.off[j];
-        long double s = 0;
+        const double *u1 = tmp + hh * vp + grp.off[j];
+        const double *u2 = tmp + (grp.nh + hh) * vp + grp.off[j];
+        long double s2 = 0;
         for (size_t q = 0; q < ix.size(); ++q) {
-          s += (long double)a_host[ix[q]] * u1[q];
+          s2 += (long double)a_host[ix[q]] * u1[q];
           out_sq[h * p + ix[q]] += 2.0 * u2[q];
         }
-        out_dot[h] += (double)s;
+        out_dot[h] += (double)s2;
       }
   }
   return 0;

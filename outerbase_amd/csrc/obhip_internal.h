@@ -297,6 +297,7 @@ struct obhip_gradbasis {
   uint64_t id = 0;  // unique per build: tables derived from the column layout are keyed by it
   std::vector<obhip::GradHyp> hyps_h;
   obhip::DevBuf<obhip::GradHyp> hyps;
+  obhip::DevBuf<int> ge0col;   // gecol of every hyper-parameter (the level-0 gradient columns), device
   obhip::DevBuf<double> rotg;  // per hyper-parameter [m][ncolp]
   obhip::DevBuf<double> kd;    // per knot: log(knot) * t(knot) (mat25pow), else 0
   std::unique_ptr<obhip_basis> gb;    // combined array + extended dimension table
