@@ -34,7 +34,9 @@
 //   fallback: k_tmm on the full views, one pass per hyper-parameter
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <atomic>
 #include <set>
+#include <thread>
 
 #include "obhip_internal.h"
 #include "device_common.h"
@@ -448,6 +450,7 @@ int ensure_gradbasis(obhip_basis &b) {
   if (b.md.model_version != m.version)
     return fail(OBHIP_ERR_STATE, "the model changed after this basis was built: call build() first");
   if (b.grad && b.grad->model_version == m.version) return 0;
+  HostTimer ht_all("ensure_gradbasis (rebuild)");
   auto g = std::make_unique<obhip_gradbasis>();
   const uint64_t d = m.d, nh = m.nhyp();
   // tables: per hyper-parameter the rotmat_gradhyp block capped like ModelDev::rot
@@ -495,13 +498,16 @@ int ensure_gradbasis(obhip_basis &b) {
   // interval tables of the mat25 / mat25pow dimensions (OBHIP_GRAD_KNOTLOOP=1: none, the
   // round-3 kernel -- A/B runs)
   const bool knotloop = getenv("OBHIP_GRAD_KNOTLOOP") && atoi(getenv("OBHIP_GRAD_KNOTLOOP")) != 0;
+  HostTimer ht_tab("ensure_gradbasis: host tables + uploads");
   std::vector<GradTab> hgt(d);
   std::vector<int> rest;  // dimensions without a table: the knot loop
   std::vector<double> htab;
+  std::vector<uint64_t> tabbed;  // dimensions with a table
+  uint64_t htab_size = 0;
   bool any_tab = false;
   for (uint64_t l = 0; l < d; ++l) {
     const DimDesc &D = b.md.dims_h[l];
-    const uint64_t ml = m.m_of(l), o = m.knotptst[l];
+    const uint64_t ml = m.m_of(l);
     const bool pw = m.kinds[l] == OBHIP_COV_MAT25POW;
     const int nc = pw ? 28 : 14;
     const uint64_t mu = (ml + 1) / 2 * 2;
@@ -515,6 +521,24 @@ int ensure_gradbasis(obhip_basis &b) {
     const uint64_t nchunks = ((uint64_t)D.ncol + nck - 1) / nck;
     const uint64_t size = mu + nchunks * nck * per_level;
     rest.pop_back();
+    if (htab_size % 2) ++htab_size;
+    hgt[l].off = (int)htab_size;
+    hgt[l].nck = (int)nck;
+    hgt[l].nchunks = (int)nchunks;
+    hgt[l].chunk = (int)(nck * per_level);
+    htab_size += size;
+    tabbed.push_back(l);
+    any_tab = true;
+  }
+  // the tables of the dimensions are independent (two extended-precision recurrences over the knots
+  // per level each): filled on host threads, like the eigen-problems of obhip_model::build -- an
+  // obfit function evaluation rebuilds them
+  htab.assign(htab_size, 0.0);
+  auto fill_dim = [&](uint64_t l) {
+    const DimDesc &D = b.md.dims_h[l];
+    const uint64_t ml = m.m_of(l), o = m.knotptst[l];
+    const bool pw = m.kinds[l] == OBHIP_COV_MAT25POW;
+    const uint64_t mu = (ml + 1) / 2 * 2;
     std::vector<int> ord(ml);
     std::vector<double> u(ml), us(ml);
     for (uint64_t j = 0; j < ml; ++j) {
@@ -523,20 +547,28 @@ int ensure_gradbasis(obhip_basis &b) {
     }
     std::stable_sort(ord.begin(), ord.end(), [&](int a2, int b2) { return u[a2] < u[b2]; });
     for (uint64_t j = 0; j < ml; ++j) us[j] = u[ord[j]];
-    if (htab.size() % 2) htab.push_back(0.0);
-    hgt[l].off = (int)htab.size();
-    hgt[l].nck = (int)nck;
-    hgt[l].nchunks = (int)nchunks;
-    hgt[l].chunk = (int)(nck * per_level);
-    htab.resize(htab.size() + size, 0.0);
     double *T = &htab[hgt[l].off];
     for (uint64_t j = 0; j < ml; ++j) T[j] = us[j];
     for (uint64_t j = ml; j < mu; ++j) T[j] = us[ml - 1];
     const uint64_t h0 = m.hypst[l];
-    build_grad_tab((int)ml, D.ncol, (int)nck, pw, D.p0, us, ord, &m.rotmat[o * m.mmax],
+    build_grad_tab((int)ml, D.ncol, hgt[l].nck, pw, D.p0, us, ord, &m.rotmat[o * m.mmax],
                    &m.rotmat_gradhyp[m.gest[h0] * m.mmax], pw ? &m.rotmat_gradhyp[m.gest[h0 + 1] * m.mmax] : nullptr,
                    m.mmax, &hkd[o], T + mu);
-    any_tab = true;
+  };
+  {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint64_t nthr = std::min<uint64_t>({(uint64_t)tabbed.size(), (uint64_t)hw, 16});
+    if (nthr <= 1) {
+      for (uint64_t l : tabbed) fill_dim(l);
+    } else {
+      std::atomic<uint64_t> next{0};
+      std::vector<std::thread> pool;
+      for (uint64_t q = 0; q < nthr; ++q)
+        pool.emplace_back([&] {
+          for (uint64_t e = next++; e < tabbed.size(); e = next++) fill_dim(tabbed[e]);
+        });
+      for (std::thread &th : pool) th.join();
+    }
   }
   DevBuf<GradTab> dgt;
   DevBuf<double> dtab;

@@ -428,6 +428,7 @@ struct Loglik : obhip_lpdf {
   double yvar_total = 0;
   int updateom() override {
     dhg_valid = sqcs_valid = false;
+    HostTimer ht("loglik.updateom (basis rebuild)");
     return obhip_basis_rebuild(ob);
   }
   int updateterms(const uint64_t *tt, uint64_t p) override {
