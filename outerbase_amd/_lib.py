@@ -21,6 +21,10 @@ except Exception:  # pragma: no cover - host-only use (model, term selection)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "obhip.h")
 LIB_PATH = os.path.join(_HERE, "libobhip.so")
+# tests/fault_inject_worker.py (a child process of one test) loads the test build instead: the
+# same sources with the exchange's fault injector compiled in (csrc/Makefile, OBHIP_TESTING)
+if os.environ.get("OBHIP_TEST_LIBRARY") == "testing":
+    LIB_PATH = os.path.join(_HERE, "libobhip_testing.so")
 
 # obhip_host_allreduce_fn: sum count doubles of a HOST buffer in place over all ranks
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)

@@ -137,6 +137,10 @@ bool pair_fits(const obhip_comm *c, uint64_t count) {
   return count >= 4096 * nr && count % (2 * nr) == 0;
 }
 
+#ifdef OBHIP_TESTING
+bool g_fault_inject_pair = false;
+#endif
+
 int rccl_pair(obhip_comm *c, double *d_buf, uint64_t count, hipStream_t st) {
   Rccl *r = c->r;
   const uint64_t blk = count / (uint64_t)c->nranks;
@@ -145,12 +149,15 @@ int rccl_pair(obhip_comm *c, double *d_buf, uint64_t count, hipStream_t st) {
   if (rc) return rccl_fail(r, rc, "ncclReduceScatter");
   rc = r->all_gather(mine, d_buf, blk, kNcclDouble, c->nccl, st);
   if (rc) return rccl_fail(r, rc, "ncclAllGather");
-  // fault injection for the tests of the self-test's in-process switch: one wrong element
-  if (const char *e = getenv("OBHIP_FAULT_INJECT_PAIR"))
-    if (atoi(e) != 0) {
-      double *q = d_buf + count / 2;
-      OB_TRY(vmap(1, [=] __device__(uint64_t) { *q += 1.0; }));
-    }
+#ifdef OBHIP_TESTING
+  // fault injection for the tests of the self-test's in-process switch: one wrong element.
+  // Compiled into libobhip_testing.so only (csrc/Makefile); the shipping library has neither
+  // this branch nor the entry point that arms it.
+  if (g_fault_inject_pair) {
+    double *q = d_buf + count / 2;
+    OB_TRY(vmap(1, [=] __device__(uint64_t) { *q += 1.0; }));
+  }
+#endif
   return 0;
 }
 
@@ -541,3 +548,9 @@ extern "C" int obhip_quantiles_dev(obhip_comm *comm, const double *d_x, uint64_t
     }
   return 0;
 }
+
+#ifdef OBHIP_TESTING
+// test build only (libobhip_testing.so): arm / disarm the wrong element behind the
+// reduce-scatter + all-gather pair (tests/fault_inject_worker.py)
+extern "C" void obhip_testing_fault_inject_pair(int on) { g_fault_inject_pair = on != 0; }
+#endif

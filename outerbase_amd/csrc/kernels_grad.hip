@@ -1033,9 +1033,14 @@ k_tmm_ge0_db(const double *__restrict__ bm, const double *__restrict__ scale,
       const uint64_t gu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ga >> 32)) << 32) |
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ga);
       const uint32_t ld = (uint32_t)__builtin_amdgcn_readfirstlane((int)(l0 + (uint32_t)u * (kTlPitch * 8)));
+// m0 is written here: on the clobber list so that the compiler never assumes a value of its own
+// survives the statement (round-4 advice; m0 is a reserved register, hence the diagnostic)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\t"
                    "global_load_lds_dword %0, %1 offset:256"
-                   :: "v"((uint32_t)lane * 4u), "s"((const char *)gu), "s"(ld) : "memory");
+                   :: "v"((uint32_t)lane * 4u), "s"((const char *)gu), "s"(ld) : "memory", "m0");
+#pragma clang diagnostic pop
     }
   };
   if (t0 < t1) prefetch(t0, 0);

@@ -41,6 +41,7 @@
 #include <mutex>
 #include <tuple>
 
+#include <memory>
 #include "obhip_internal.h"
 #include "device_common.h"
 
@@ -100,8 +101,13 @@ k_materialize_rows(const double *__restrict__ bm, const double *__restrict__ sca
 // one wave instruction: 1 KB from gbase + 16 lane -> LDS at lds_addr + 16 lane
 __device__ __forceinline__ void lds_dma_1k(const char *gbase /* uniform */, uint32_t voff,
                                            uint32_t lds_addr /* uniform */) {
+// m0 is written here: on the clobber list so that the compiler never assumes a value of its own
+// survives the statement (round-4 advice; m0 is a reserved register, hence the diagnostic)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-               :: "v"(voff), "s"(gbase), "s"(lds_addr) : "memory");
+               :: "v"(voff), "s"(gbase), "s"(lds_addr) : "memory", "m0");
+#pragma clang diagnostic pop
 }
 
 template <int OFF>
@@ -751,16 +757,21 @@ int launch_atb(int mode, const double *A, uint64_t ldA, uint64_t M, const double
   // var() call: built and uploaded once per device and shape and kept (no per-call upload, no
   // stream synchronisation for a local buffer) -- the kAtbCache most recently used shapes, so
   // that a long-lived process predicting on ever-changing batch sizes does not grow without
-  // bound (a table is mt * nt * 8 bytes: megabytes at 1e6 rows).  Evicting one waits for the
-  // device, because a launch on any stream may still be reading it; that happens once per
+  // bound (a table is mt * nt * 8 bytes: megabytes at 1e6 rows).  Entries are shared_ptrs: a
+  // caller keeps its table alive from the look-up until its launch has been enqueued, whatever
+  // another thread evicts meanwhile (round-4 advice: handles of different threads may launch
+  // concurrently).  The evicting thread waits for the device THE ENTRY BELONGS TO (a launch on
+  // any of its streams may still be reading the table) outside the lock; that happens once per
   // kAtbCache new shapes at most.
   constexpr size_t kAtbCache = 8;
+  using Tab = std::shared_ptr<DevBuf<uint64_t>>;
   static std::mutex mu;
-  static std::map<std::tuple<int, uint64_t, uint64_t>, DevBuf<uint64_t> *> cache;
+  static std::map<std::tuple<int, uint64_t, uint64_t>, Tab> cache;
   static std::vector<std::tuple<int, uint64_t, uint64_t>> lru;  // least recently used first
   int dev = 0;
   (void)hipGetDevice(&dev);
-  DevBuf<uint64_t> *dtabp = nullptr;
+  Tab dtabp, victim;
+  int victim_dev = dev;
   {
     std::lock_guard<std::mutex> lk(mu);
     const auto key = std::make_tuple(dev, mt, nt);
@@ -769,13 +780,13 @@ int launch_atb(int mode, const double *A, uint64_t ldA, uint64_t M, const double
     if (lru.size() > kAtbCache) {
       auto it = cache.find(lru.front());
       if (it != cache.end()) {
-        (void)hipDeviceSynchronize();
-        delete it->second;
+        victim = std::move(it->second);
+        victim_dev = std::get<0>(lru.front());
         cache.erase(it);
       }
       lru.erase(lru.begin());
     }
-    DevBuf<uint64_t> *&slot = cache[key];
+    Tab &slot = cache[key];
     if (!slot) {
       // units of up to 8 x 8 tiles, column-tile squares of equal k range together, dealt to the
       // XCD with the fewest blocks so far
@@ -793,15 +804,21 @@ int launch_atb(int mode, const double *A, uint64_t ldA, uint64_t M, const double
       std::vector<uint64_t> tab(len * kXcd, kAtbNoTask);
       for (int k = 0; k < kXcd; ++k)
         for (size_t m = 0; m < seq[k].size(); ++m) tab[m * kXcd + k] = seq[k][m];
-      slot = new DevBuf<uint64_t>();  // freed on eviction only (after a device synchronise)
+      slot = std::make_shared<DevBuf<uint64_t>>();  // freed by its last holder, after eviction
       const int rc = slot->upload(tab.data(), tab.size());
       if (rc) {
-        delete slot;
-        slot = nullptr;
+        cache.erase(key);
+        lru.pop_back();
         return rc;
       }
     }
     dtabp = slot;
+  }
+  if (victim) {  // (its own device's work first: the table may be in use by a launch in flight)
+    if (victim_dev != dev) (void)hipSetDevice(victim_dev);
+    (void)hipDeviceSynchronize();
+    victim.reset();
+    if (victim_dev != dev) (void)hipSetDevice(dev);
   }
   DevBuf<uint64_t> &dtab = *dtabp;
   const size_t ntasks = dtab.n;

@@ -76,9 +76,14 @@ struct Hm2Ctx {
 // (lane l: dword at g + 4 l -> LDS l + 4 l, then the same 256 bytes on)
 __device__ __forceinline__ void hm2_dma_col(const char *g /* uniform */, uint32_t voff /* 4 lane */,
                                             uint32_t l /* uniform */) {
+// m0 is written here: on the clobber list so that the compiler never assumes a value of its own
+// survives the statement (round-4 advice; m0 is a reserved register, hence the diagnostic)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\t"
                "global_load_lds_dword %0, %1 offset:256"
-               :: "v"(voff), "s"(g), "s"(l) : "memory");
+               :: "v"(voff), "s"(g), "s"(l) : "memory", "m0");
+#pragma clang diagnostic pop
 }
 
 // one sub-chunk of 4 rows (tile rows rc .. rc + 3; the addresses in c.ad point ROW0 rows before).
@@ -337,8 +342,10 @@ size_t hm2_lds_bytes(const obhip_terms &t, bool ro, int variant) {
   size_t slots = 0;
   if (variant == 2 || variant == 3)
     slots = ro ? 4608 : 0;  // (12 waves x 6 units, 8 x 8: the experiments at 4-factor terms)
-  else if (nu == 4 && (ro || variant == 5 || (w2 == 3 && variant == 7)))
-    slots = 4096;  // (the instantiations that keep the coefficients in LDS: launch_hm2)
+  else if ((w2 >= 2 && variant == 5) || (w2 == 3 && variant == 7) || (nu == 4 && ro))
+    slots = 4096;  // the instantiations that keep the coefficients in LDS (launch_hm2): variants 5
+                   // and 7 are 16 waves x 4 units whatever p_pad is (round-4 advice), the update()
+                   // form at 4 units per lane
   return ((size_t)2 * t.Mu * kTlPitch + 2 * 128 + 2 * kHm2RedSlots + slots) * sizeof(double);
 }
 

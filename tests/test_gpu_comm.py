@@ -263,32 +263,23 @@ def test_comm_selftest_single_rank(transport):
         lib.obhip_comm_destroy(comm)
 
 
-def test_comm_selftest_switches_a_wrong_pair_off_in_process(monkeypatch):
-    """The reduce-scatter / all-gather pair returning one wrong element (fault injection,
-    OBHIP_FAULT_INJECT_PAIR) while ncclAllReduce is right: the self-test reports the mismatch,
-    switches this communicator to ncclAllReduce for every size without a relaunch, and the next
-    exchange of the same buffer is exact."""
-    import torch
-    from outerbase_amd._lib import call, lib
-    comm = _comm_rccl_single()
-    try:
-        count = 1 << 20
-        monkeypatch.setenv("OBHIP_FAULT_INJECT_PAIR", "1")
-        v = torch.arange(count, dtype=torch.float64, device="cuda")
-        w = v.clone()
-        call("obhip_comm_allreduce_dev", comm, w.data_ptr(), count)
-        torch.cuda.synchronize()
-        assert not torch.equal(v, w)                                  # the fault is real
-        rc, res = _selftest(comm, count)
-        assert rc == 0, lib.obhip_last_error()
-        assert res == [2, 1, 0, 1]                                    # all-reduce in use, pair: 1 bad
-        assert _path(comm, count) == (2, 2)
-        w = v.clone()
-        call("obhip_comm_allreduce_dev", comm, w.data_ptr(), count)
-        torch.cuda.synchronize()
-        assert torch.equal(v, w)
-    finally:
-        lib.obhip_comm_destroy(comm)
+def test_comm_selftest_switches_a_wrong_pair_off_in_process():
+    """The reduce-scatter / all-gather pair returning one wrong element while ncclAllReduce is
+    right: the self-test reports the mismatch, switches this communicator to ncclAllReduce for
+    every size without a relaunch, and the next exchange of the same buffer is exact.  The fault
+    injector exists in the TEST build of the library only (libobhip_testing.so: comm.cpp compiled
+    with -DOBHIP_TESTING, armed through obhip_testing_fault_inject_pair), so the case runs in a
+    child process that loads that build (tests/fault_inject_worker.py); the shipping library has
+    no such switch (test_host_logic.py::test_shipping_library_has_no_fault_injector)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, OBHIP_TEST_LIBRARY="testing")
+    r = subprocess.run([sys.executable, os.path.join(here, "fault_inject_worker.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "fault injection ok" in r.stdout
 
 
 def test_comm_selftest_fails_loudly_when_the_transport_sums_wrongly():

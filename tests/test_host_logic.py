@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import ob_oracle as O
-from conftest import KNOTS_REF, make_pair
+from conftest import KNOTS_REF, ROOT, make_pair
 
 
 def test_library_exports_every_declared_symbol():
@@ -371,3 +371,40 @@ def test_glue_passes_the_compilers_front_end():
     r = subprocess.run(cmd[:-1] + ["-x", "c++", "-"], input=broken.encode(), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT)
     assert r.returncode != 0 and b"obhip_basis_rebuild" in r.stdout
+
+
+def test_every_environment_switch_is_documented():
+    """Every OBHIP_* variable the library reads is a row of INTEGRATION.md's table, and the table
+    lists nothing the library does not read (round-4 verdict: 30 switches, two documented
+    nowhere)."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "outerbase_amd", "csrc")
+    read = set()
+    for f in glob.glob(os.path.join(csrc, "*")):
+        if f.endswith((".cpp", ".hip", ".h")):
+            read |= set(re.findall(r'getenv\("(OBHIP_[A-Z0-9_]+)"\)', open(f).read()))
+    assert len(read) >= 25
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    i = doc.index("Environment variables the library reads")
+    j = doc.index("## Behavioural differences")
+    rows = [ln for ln in doc[i:j].splitlines() if ln.startswith("| `OBHIP_")]
+    listed = set()
+    for ln in rows:
+        listed |= set(re.findall(r"`(OBHIP_[A-Z0-9_]+)", ln))
+    assert read - listed == set(), "undocumented switches: %s" % sorted(read - listed)
+    assert listed - read == set(), "documented but never read: %s" % sorted(listed - read)
+
+
+def test_shipping_library_has_no_fault_injector():
+    """The exchange's fault injector (tests of obhip_comm_selftest_dev's in-process switch) lives in
+    the test build only: libobhip.so neither exports obhip_testing_* nor consults the environment
+    for it; libobhip_testing.so exports the arming entry point."""
+    from outerbase_amd import _lib
+    assert not hasattr(_lib.lib, "obhip_testing_fault_inject_pair")
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"FAULT_INJECT" not in blob and b"obhip_testing" not in blob
+    tst = open(os.path.join(os.path.dirname(_lib.LIB_PATH), "libobhip_testing.so"), "rb").read()
+    assert b"obhip_testing_fault_inject_pair" in tst
+    src = open(os.path.join(ROOT, "outerbase_amd", "csrc", "comm.cpp")).read()
+    assert src.count("#ifdef OBHIP_TESTING") == 3 and "FAULT_INJECT" not in src
