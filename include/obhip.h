@@ -67,10 +67,10 @@ typedef struct obhip_comm obhip_comm;   /* the ranks of a row-sharded job (no re
                                            modandbase.cpp:464) */
 
 /* ---- library ----------------------------------------------------------- */
-/* 4.  (2 -> 3: obhip_standardise_dev, obhip_destandardise_dev, obhip_fit_newton_count,
+/* 5.  (2 -> 3: obhip_standardise_dev, obhip_destandardise_dev, obhip_fit_newton_count,
  * obhip_fit_newton_sharded_dev, obhip_source_hash added; 3 -> 4: obhip_comm_selftest_dev,
  * obhip_comm_exchange_path, obhip_comm_init_sim added, obhip_standardise_dev accepts an empty
- * shard when it has a communicator; nothing removed.) */
+ * shard when it has a communicator; 4 -> 5: obhip_terms_share_tables added; nothing removed.) */
 int obhip_abi_version(void);
 const char *obhip_last_error(void);
 /* 16 hex digits of the SHA-256 over the library's sources at build time: which = 0 all of
@@ -180,6 +180,31 @@ int obhip_terms_info(const obhip_terms *t, uint64_t *p, uint64_t *d,
                      uint64_t *nnz_total, uint64_t *max_nnz);
 /* highest level used per dimension (d entries) */
 int obhip_terms_maxlevels(const obhip_terms *t, int64_t *levels);
+/* How the term-per-lane kernels share sub-products among these terms (host only, no device
+ * needed).  The reference multiplies every term out on its own (prodmm_ / tprodmm_,
+ * linalg.cpp:57-131,286-355); selectterms' output is downward-closed (modandbase.cpp:419-436), so
+ * its terms come in families that differ in one factor, and the library groups the p_pad = p
+ * rounded up to 256 terms (the padding terms have no factors) into *stars*: four terms whose P
+ * shared factors are read and multiplied once (csrc/share.cpp).  Terms that find no family with
+ * four free members are *left over* (any term set is accepted; one that is not downward-closed
+ * just leaves more over): they are listed, and also packed four at a time into plain stars
+ * (nothing shared) behind the family stars.  Stars come in star-waves of 64, filled up with empty
+ * stars.  info (10 entries):
+ *   [0] p_pad, [1] left-over terms, [2] column reads per row of the family star-waves (sum of
+ *   P + 4), [3] of the scheme without sharing (4 terms per lane, terms by falling number of
+ *   factors: rounds 1-4), [4] W, the column slots per term, [5] LDS cycles of all star-waves' reads
+ *   with their bank conflicts (2 per read at best; column u of the [column][65] tile lies in bank
+ *   pair u mod 32), [6] the same before the search over the stars' half-waves and term orders that
+ *   minimises them, [7] family star-waves, [8] plain star-waves, [9] reads per row of the latter.
+ * With S = 64 ([7] + [8]) stars in all -- S <= p_pad / 4 + 128 -- the optional outputs are:
+ * term (4 S entries): the four term indices of star 0, of star 1, ... (0xffffffff: none);
+ * shape ([7] + [8] entries): per star-wave P | S << 8 (family star-waves first: S = 1);
+ * factor (S * 4 W entries): per star its column slots in read order -- [P shared][own of term 0]
+ * [own of term 1] ... -- as 1 + (levels of the dimensions before l) + (level - 1) for level >= 1
+ * of dimension l (levels counted up to obhip_terms_maxlevels), 0 = unused;
+ * left ([1] entries): the left-over terms. */
+int obhip_terms_share_tables(const obhip_terms *t, uint64_t *info, uint32_t *term, uint32_t *shape,
+                             uint16_t *factor, uint32_t *left);
 
 /* ---- outerbase --------------------------------------------------------- */
 /* new(outerbase, om, x): modandbase.cpp:459-480 + build :547-626.

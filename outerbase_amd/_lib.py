@@ -31,7 +31,7 @@ HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 
 _BASE = {
     "int": C.c_int, "double": C.c_double, "uint64_t": C.c_uint64,
-    "int64_t": C.c_int64, "void": None, "char": C.c_char, "size_t": C.c_size_t,
+    "int64_t": C.c_int64, "uint32_t": C.c_uint32, "uint16_t": C.c_uint16, "void": None, "char": C.c_char, "size_t": C.c_size_t,
 }
 _HANDLES = ("obhip_model", "obhip_basis", "obhip_terms", "obhip_comm", "obhip_lpdf",
             "obhip_predictor")

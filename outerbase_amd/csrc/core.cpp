@@ -374,6 +374,23 @@ int obhip_terms::prepare(const std::vector<int64_t> &cap,
                      [&](uint32_t a, uint32_t b) { return nz[a] > nz[b]; });
     OB_TRY(sperm.upload(order.data(), order.size()));
   }
+  // shared sub-products: stars of four terms that differ in one factor (share.cpp)
+  OB_TRY(obhip::build_share_tables(hc.data(), p_pad, W, sh));
+  if (sh.ok) {
+    OB_TRY(sh_cols.upload(sh.cols.data(), sh.cols.size()));
+    OB_TRY(sh_term.upload(sh.term.data(), sh.term.size()));
+    OB_TRY(sh_shape.upload(sh.shape.data(), sh.shape.size()));
+    if (sh.left_term.empty()) {  // (never an empty upload: the kernels take the pointers)
+      sh.left_term.push_back(0);
+      sh.left_cols.assign(W, 0);
+    }
+    OB_TRY(sh_left_term.upload(sh.left_term.data(), sh.left_term.size()));
+    OB_TRY(sh_left_cols.upload(sh.left_cols.data(), sh.left_cols.size()));
+    std::vector<uint16_t>().swap(sh.cols);
+    std::vector<uint32_t>().swap(sh.term);
+    std::vector<uint32_t>().swap(sh.left_term);
+    std::vector<uint16_t>().swap(sh.left_cols);
+  }
   OB_TRY(ucol.upload(used.data(), used.size()));
   uint64_t Mc = 1;
   for (uint64_t l = 0; l < d; ++l) Mc += (uint64_t)cap[l];
@@ -424,7 +441,7 @@ int device_cus(int device) {
 
 extern "C" {
 
-int obhip_abi_version(void) { return 4; }
+int obhip_abi_version(void) { return 5; }
 
 const char *obhip_last_error(void) { return g_err.c_str(); }
 
@@ -539,6 +556,44 @@ int obhip_terms_info(const obhip_terms *t, uint64_t *p, uint64_t *d,
 int obhip_terms_maxlevels(const obhip_terms *t, int64_t *levels) {
   if (!t || !levels) return fail(OBHIP_ERR_INVALID, "null argument");
   std::copy(t->maxlev.begin(), t->maxlev.end(), levels);
+  return 0;
+}
+
+int obhip_terms_share_tables(const obhip_terms *t, uint64_t *info, uint32_t *term, uint32_t *shape,
+                             uint16_t *factor, uint32_t *left) {
+  if (!t || !info) return fail(OBHIP_ERR_INVALID, "null argument");
+  // the same tables obhip_terms::prepare uploads, on factor ids that do not depend on a basis'
+  // column layout: 1 + levels of the dimensions before + level - 1
+  std::vector<uint64_t> off(t->d + 1, 1);
+  for (uint64_t l = 0; l < t->d; ++l) off[l + 1] = off[l] + (uint64_t)t->maxlev[l];
+  if (off[t->d] > 65535) return fail(OBHIP_ERR_INVALID, "terms use more than 65535 basis columns");
+  const uint64_t W = std::max<uint64_t>(2, (t->max_nnz + 1) / 2 * 2);
+  const uint64_t p_pad = (t->p + 255) / 256 * 256;
+  std::vector<uint16_t> hc(p_pad * W, 0);
+  for (uint64_t k = 0; k < t->p; ++k) {
+    uint64_t nnz = 0;
+    for (uint64_t l = 0; l < t->d; ++l) nnz += t->lev[k * t->d + l] > 0;
+    uint64_t w = W - nnz;
+    for (uint64_t l = 0; l < t->d; ++l)
+      if (t->lev[k * t->d + l] > 0) hc[k * W + w++] = (uint16_t)(off[l] + t->lev[k * t->d + l] - 1);
+  }
+  obhip::ShareTables sh;
+  OB_TRY(obhip::build_share_tables(hc.data(), p_pad, W, sh));
+  if (!sh.ok) return fail(OBHIP_ERR_INVALID, "terms of more than 8 factors are not grouped into stars");
+  info[0] = p_pad;
+  info[1] = sh.nleft;
+  info[2] = sh.reads;
+  info[3] = sh.reads_plain;
+  info[4] = W;
+  info[5] = sh.lds_cycles;
+  info[6] = sh.lds_cycles0;
+  info[7] = sh.nsw_family;
+  info[8] = sh.nsw_plain;
+  info[9] = sh.reads_left;
+  if (term) std::copy(sh.term.begin(), sh.term.end(), term);
+  if (shape) std::copy(sh.shape.begin(), sh.shape.end(), shape);
+  if (factor) std::copy(sh.cols.begin(), sh.cols.end(), factor);
+  if (left) std::copy(sh.left_term.begin(), sh.left_term.end(), left);
   return 0;
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "obhip_internal.h"
 
 namespace obhip {
@@ -417,6 +419,152 @@ __device__ __forceinline__ int tl_variant_tail(int nzmax) {
 template <int W>
 __device__ __forceinline__ int tl_variant(int nzmax) {  // smallest variant that covers nzmax
   return max(nzmax, max(1, W - 3));
+}
+
+// ---- shared sub-products: the read pipeline of a star ---------------------------------------
+// (host side and the idea: csrc/share.cpp.)  A star is four terms; shape (P, S): P shared column
+// reads whose product q every term takes over, then S reads per term.  S = 1, P >= 1: a family of
+// terms that differ in one factor (P + 4 reads for four terms); P = 0: four unrelated terms of up
+// to S factors (the plain form, what TlPipe does).  The context C provides
+//   uint32_t ad[]                            flat LDS byte addresses of row 0 of the chunk: the star
+//                                            at A0: [P shared][term 0: S][term 1: S] ... in read order
+//   template <int RR> void row()             once per row, before its first product
+//   template <int RR, int UNIT> void use(v)  the product of term UNIT - U0 of the star at row RR
+// The reads of ROWS rows form one sequence; K of them are in flight (a ring of K registers: read i
+// lands in slot i mod K and is issued once read i - K has been used; LDS returns in order, so
+// s_waitcnt lgkmcnt(newest - last) releases a group, tied by "+v" to the registers it releases).
+template <int KEEP, int N, int I0, int RING>
+__device__ __forceinline__ void tl_waitr(double (&b)[RING]) {
+  static_assert(N >= 1 && N <= 8 && KEEP >= 0 && KEEP <= 15, "");
+#define OB_RG(j) "+v"(b[(I0 + (j)) % RING])
+  if constexpr (N == 1)
+    asm volatile("s_waitcnt lgkmcnt(%1)" : OB_RG(0) : "n"(KEEP) : "memory");
+  else if constexpr (N == 2)
+    asm volatile("s_waitcnt lgkmcnt(%2)" : OB_RG(0), OB_RG(1) : "n"(KEEP) : "memory");
+  else if constexpr (N == 3)
+    asm volatile("s_waitcnt lgkmcnt(%3)" : OB_RG(0), OB_RG(1), OB_RG(2) : "n"(KEEP) : "memory");
+  else if constexpr (N == 4)
+    asm volatile("s_waitcnt lgkmcnt(%4)" : OB_RG(0), OB_RG(1), OB_RG(2), OB_RG(3) : "n"(KEEP) : "memory");
+  else if constexpr (N == 5)
+    asm volatile("s_waitcnt lgkmcnt(%5)" : OB_RG(0), OB_RG(1), OB_RG(2), OB_RG(3), OB_RG(4) : "n"(KEEP) : "memory");
+  else if constexpr (N == 6)
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : OB_RG(0), OB_RG(1), OB_RG(2), OB_RG(3), OB_RG(4), OB_RG(5)
+                 : "n"(KEEP)
+                 : "memory");
+  else if constexpr (N == 7)
+    asm volatile("s_waitcnt lgkmcnt(%7)"
+                 : OB_RG(0), OB_RG(1), OB_RG(2), OB_RG(3), OB_RG(4), OB_RG(5), OB_RG(6)
+                 : "n"(KEEP)
+                 : "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : OB_RG(0), OB_RG(1), OB_RG(2), OB_RG(3), OB_RG(4), OB_RG(5), OB_RG(6), OB_RG(7)
+                 : "n"(KEEP)
+                 : "memory");
+#undef OB_RG
+}
+
+// A context with `static constexpr bool kFactored = true` takes the products apart instead:
+//   template <int RR> void prefix(q)            the product of the shared factors (1 for a plain star),
+//                                               once per row, after row() and before the row's terms
+//   template <int RR, int UNIT> void leaf(g)    term UNIT's own factor (plain: its whole product)
+// -- a sum over a star's terms is then q * sum_u c_u g_u (P + 4 multiply-adds per row instead of
+// P + 7), and a product with a row weight g_u * (q w).
+template <typename C, typename = void>
+struct tl_factored : std::false_type {};
+template <typename C>
+struct tl_factored<C, std::void_t<decltype(C::kFactored)>> : std::bool_constant<C::kFactored> {};
+
+template <int P, int S, int ROWS, int K, int A0 = 0, int U0 = 0, int ROW0 = 0>
+struct TlStar {
+  static constexpr int G = 4;
+  static constexpr int R = P + G * S;             // reads per row
+  static constexpr int T = ROWS * R;
+  static constexpr int E = (P > 0 ? 1 : 0) + G;   // groups per row: the shared part, the terms
+  static constexpr int NE = ROWS * E;
+  static_assert(S >= 1 && S <= 8 && P >= 0 && P <= 7 && K <= 16 && K >= P && K >= S, "");
+  static constexpr int ev_size(int e) { return (P > 0 && e % E == 0) ? P : S; }
+  static constexpr int ev_last(int e) {  // index of the last read of group e
+    const int row = e / E, g = e % E;
+    if (P > 0) return row * R + (g == 0 ? P : P + g * S) - 1;
+    return row * R + (g + 1) * S - 1;
+  }
+  template <int I, int END, typename C>
+  static __device__ __forceinline__ void issue(C &c, double (&buf)[K]) {
+    if constexpr (I < END) {
+      buf[I % K] = tl_rd<(ROW0 + I / R) * 8>(c.ad[A0 + I % R]);
+      issue<I + 1, END>(c, buf);
+    }
+  }
+  template <int EV, typename C>
+  static __device__ __forceinline__ void steps(C &c, double (&buf)[K], double &q) {
+    if constexpr (EV < NE) {
+      constexpr int last = ev_last(EV), size = ev_size(EV), first = last - size + 1;
+      constexpr int prev_last = EV == 0 ? -1 : ev_last(EV == 0 ? 0 : EV - 1);
+      constexpr int newest = prev_last + K < T - 1 ? prev_last + K : T - 1;  // issued so far
+      constexpr int row = EV / E, g = EV % E;
+      if constexpr (g == 0) c.template row<row>();
+      tl_waitr<newest - last, size, first % K, K>(buf);
+      double v = buf[first % K];
+#pragma unroll
+      for (int j = 1; j < size; ++j) v *= buf[(first + j) % K];
+      if constexpr (tl_factored<C>::value) {
+        if constexpr (P > 0 && g == 0) {
+          c.template prefix<row>(v);
+        } else {
+          if constexpr (P == 0 && g == 0) c.template prefix<row>(1.0);
+          c.template leaf<row, U0 + (P > 0 ? g - 1 : g)>(v);
+        }
+      } else if constexpr (P > 0 && g == 0) {
+        q = v;
+      } else {
+        if constexpr (P > 0) v *= q;
+        c.template use<row, U0 + (P > 0 ? g - 1 : g)>(v);
+      }
+      constexpr int upto = last + K < T - 1 ? last + K : T - 1;  // the group's registers are free
+      issue<newest + 1, upto + 1>(c, buf);
+      steps<EV + 1>(c, buf, q);
+    }
+  }
+  template <typename C>
+  static __device__ __forceinline__ void run(C &c) {
+    double buf[K];
+    double q = 1.0;
+    issue<0, (K < T ? K : T)>(c, buf);
+    steps<0>(c, buf, q);
+  }
+};
+
+// the instantiation for a star-wave's shape (P | S << 8, obhip_terms::sh_shape): stars with
+// P = 1 .. W - 1 shared factors, plain stars of W or W - 2 slots per term.  Wave-uniform.
+template <int W, int ROWS, int K, int A0 = 0, int U0 = 0, int ROW0 = 0, typename C>
+__device__ __forceinline__ void tl_star_run(C &c, uint32_t shape) {
+  const int P = (int)(shape & 0xffu);
+  constexpr int KS = K < W ? W : K;  // (a plain star of W slots needs W registers at least)
+  if ((shape >> 8) != 1u) {
+    if constexpr (W >= 4) {
+      if ((int)(shape >> 8) == W - 2) {
+        TlStar<0, W - 2, ROWS, KS, A0, U0, ROW0>::run(c);
+        return;
+      }
+    }
+    TlStar<0, W, ROWS, KS, A0, U0, ROW0>::run(c);
+  } else if (P <= 1) {
+    TlStar<1, 1, ROWS, K, A0, U0, ROW0>::run(c);
+  } else if (P == 2) {
+    if constexpr (W > 2) TlStar<2, 1, ROWS, K, A0, U0, ROW0>::run(c);
+  } else if (P == 3) {
+    if constexpr (W > 3) TlStar<3, 1, ROWS, K, A0, U0, ROW0>::run(c);
+  } else if (P == 4) {
+    if constexpr (W > 4) TlStar<4, 1, ROWS, K, A0, U0, ROW0>::run(c);
+  } else if (P == 5) {
+    if constexpr (W > 5) TlStar<5, 1, ROWS, K, A0, U0, ROW0>::run(c);
+  } else if (P == 6) {
+    if constexpr (W > 6) TlStar<6, 1, ROWS, K, A0, U0, ROW0>::run(c);
+  } else {
+    if constexpr (W > 7) TlStar<7, 1, ROWS, K, A0, U0, ROW0>::run(c);
+  }
 }
 
 // Slot (position in obhip_terms::sperm, terms by falling number of factors) of unit u of a

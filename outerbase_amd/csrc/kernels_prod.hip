@@ -1419,7 +1419,17 @@ int launch_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const do
                double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
                uint64_t tps, int variant, const double *stop0, const double *stop1);
 
+// kernels_hm3.hip: the two-phase kernel on shared sub-products (stars), 2049 .. 4096 terms
+bool hm3_supports(const obhip_terms &t);
+int launch_hm3(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,
+               double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
+               uint64_t tps, const double *stop0, const double *stop1);
+
 namespace {
+bool hm3_wanted() {
+  static const bool off = getenv("OBHIP_HM3") && atoi(getenv("OBHIP_HM3")) == 0;
+  return !off;
+}
 bool hm2_wanted() {
   static const bool off = getenv("OBHIP_HESSMULT_FUSED") && atoi(getenv("OBHIP_HESSMULT_FUSED")) == 0;
   static const bool v1 = getenv("OBHIP_HM_V1") && atoi(getenv("OBHIP_HM_V1")) != 0;
@@ -1435,7 +1445,8 @@ int hm2_variant() {
 // honours the stop flags of launch_hessmult_fused)
 bool hessmult_fused_skippable(const obhip_basis &b, obhip_terms &t) {
   if (t.prepare(b.md.cap, b.md.dims_h) != 0) return false;
-  return hm2_wanted() && !beyond_lds(t) && hm2_supports(t, false, hm2_variant());
+  if (!hm2_wanted() || beyond_lds(t)) return false;
+  return (hm3_wanted() && hm2_variant() == 0 && hm3_supports(t)) || hm2_supports(t, false, hm2_variant());
 }
 
 int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y,
@@ -1446,8 +1457,10 @@ int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_
   // OBHIP_HM_V1=1: the round-3 kernel (A/B runs); OBHIP_HM2_VARIANT: block shapes of k_hm2
   const int variant = hm2_variant();
   const int w2 = (int)(t.W / 2);
-  const bool use2 = hm2_wanted() && !beyond_lds(t) && hm2_supports(t, d_y != nullptr, variant);
-  if (d_stop0 && !use2) return fail(OBHIP_ERR_STATE, "hessmult: stop flags need the k_hm2 path");
+  // OBHIP_HM3=0: k_hm2 instead of the two-phase kernel on shared sub-products (A/B)
+  const bool use3 = hm2_wanted() && hm3_wanted() && variant == 0 && !beyond_lds(t) && hm3_supports(t);
+  const bool use2 = use3 || (hm2_wanted() && !beyond_lds(t) && hm2_supports(t, d_y != nullptr, variant));
+  if (d_stop0 && !use2) return fail(OBHIP_ERR_STATE, "hessmult: stop flags need the k_hm2 / k_hm3 path");
   // (8 terms of 6 factors per lane spill and run at half the speed of the two-kernel form: measured)
   const int numax = w2 <= 2 ? 8 : 4;
   if (!use2 &&
@@ -1466,7 +1479,11 @@ int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_
   OB_TRY(const_cast<obhip_basis &>(b).workspace((nsplit * t.p_pad + nsplit) * sizeof(double), (void **)&part));
   if ((d_yhat || d_ss) && !d_y) return fail(OBHIP_ERR_INVALID, "hessmult: yhat / residual sum need y");
   double *sspart = d_ss ? part + nsplit * t.p_pad : nullptr;
-  if (use2) {
+  if (use3) {
+    ProfScope ps("hessmult");
+    OB_TRY(launch_hm3(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps, d_stop0,
+                      d_stop1));
+  } else if (use2) {
     ProfScope ps("hessmult");
     OB_TRY(launch_hm2(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps, variant,
                       d_stop0, d_stop1));

@@ -219,6 +219,30 @@ struct ModelDev {
 }  // namespace obhip
 
 // ---- terms --------------------------------------------------------------------
+// star tables of a term set (csrc/share.cpp): p_pad / 4 stars of four terms that share all
+// factors but one (or, plain stars, nothing), in star-waves of 64
+namespace obhip {
+struct ShareTables {
+  bool ok = false;
+  uint64_t nstars = 0;       // 64 x (nsw_family + nsw_plain), the empty stars that fill the waves included
+  uint64_t nsw_family = 0;   // star-waves of family stars (shape (P, 1)) -- they come first
+  uint64_t nsw_plain = 0;    // star-waves of plain stars (shape (0, S)): the left-over terms four at a time
+  uint64_t nleft = 0;        // left-over terms (no family with four free members)
+  uint64_t reads = 0;        // column reads per row of the family star-waves: sum of P + 4
+  uint64_t reads_left = 0;   // of the plain star-waves: sum of 4 S
+  uint64_t reads_plain = 0;  // of the nnz-sorted scheme without sharing, 4 terms per lane (rounds 1-4)
+  uint64_t lds_cycles = 0;   // LDS cycles of all star-waves' reads with their bank conflicts (2 per read at best)
+  uint64_t lds_cycles0 = 0;  // the same before the half-wave / term-order search
+  std::vector<uint16_t> cols;   // nstars x 4 W used-column indices, laid out for the star-wave's shape
+  std::vector<uint32_t> term;   // nstars x 4 term indices (0xffffffff: none -- an empty star's)
+  std::vector<uint32_t> shape;  // per star-wave: P | S << 8
+  std::vector<uint32_t> left_term;  // nleft term indices
+  std::vector<uint16_t> left_cols;  // nleft x W used-column indices, right-aligned (0 = ones)
+};
+int build_share_tables(const uint16_t *hc, uint64_t p_pad, uint64_t W, ShareTables &out);
+bool share_wanted();  // OBHIP_SHARE=0: the kernels take the plain tables (A/B measurements)
+}  // namespace obhip
+
 struct obhip_terms {
   uint64_t uid = 0;                   // unique per object (caches keyed by terms use it)
   uint64_t p = 0, d = 0;
@@ -234,6 +258,13 @@ struct obhip_terms {
   obhip::DevBuf<uint32_t> sperm;      // p_pad: terms ordered by falling number of factors (stable)
   obhip::DevBuf<int32_t> cpos;        // compact column -> used index or -1 (Mc)
   uint64_t p_pad = 0;
+  // star tables (shared sub-products, csrc/share.cpp); sh.ok false: the kernels take sperm / cols
+  obhip::ShareTables sh;              // (host copies dropped after the upload; counts kept)
+  obhip::DevBuf<uint16_t> sh_cols;    // nstars x 4 W
+  obhip::DevBuf<uint32_t> sh_term;    // nstars x 4
+  obhip::DevBuf<uint32_t> sh_shape;   // nstars / 64
+  obhip::DevBuf<uint32_t> sh_left_term;  // nleft (at least one element)
+  obhip::DevBuf<uint16_t> sh_left_cols;  // nleft x W
   // per hyper-parameter views for the gradient products (kernels_grad.hip)
   std::vector<std::unique_ptr<obhip_terms>> ge_views;
   // the same restricted to the terms that HAVE the hyper-parameter's dimension, with

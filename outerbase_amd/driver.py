@@ -204,6 +204,21 @@ class HotPath:
         rhs = e2 * self.g.cpu().numpy()
         return float(np.linalg.norm(lhs - rhs) / np.linalg.norm(rhs))
 
+    def hessian_full_rel_err(self, H_want):
+        """max |H - H_want| / max |H_want| over ALL entries of H = e^{-2 sigma} B^T B + prior
+        (loglik_std.cpp:170-173, logpr_gauss.cpp:153-158) of this rank's rows, formed once more by
+        obhip_gram_dev into a buffer of its own: the fit's buffer holds the Cholesky factor in
+        its lower triangle and diagonal 128 x 128 blocks.  One rank (parity checks)."""
+        torch = self.torch
+        G2 = torch.empty((self.p, self.p), dtype=torch.float64, device=self.x.device)
+        call("obhip_gram_dev", self.basis, self.t._h, None, G2.data_ptr(), None)
+        torch.cuda.synchronize()
+        H = math.exp(-2 * self.sigma) * G2.cpu().numpy()
+        del G2
+        prec = 1.0 / (self.om.getvar(self.terms) * math.exp(2 * self.rho))
+        H[np.diag_indices(self.p)] += prec
+        return float(np.max(np.abs(H - H_want)) / np.max(np.abs(H_want)))
+
     def setup_inputs(self):
         """(Re)generate this rank's rows of the synthetic stream in HBM."""
         torch = self.torch

@@ -64,7 +64,7 @@ int main(int argc, char **argv) {
     fprintf(stderr, "no HIP device\n");
     return 3;
   }
-  if (obhip_abi_version() != 4) {
+  if (obhip_abi_version() != 5) {
     fprintf(stderr, "unexpected ABI version %d\n", obhip_abi_version());
     return 1;
   }

@@ -84,15 +84,21 @@ def test_headline_terms_fit_matches_oracle(case, rotation):
         err_H = max(np.max(np.abs(Hd - o["H"])[above]) if above.any() else 0.0,
                     np.max(np.abs(hp.diagH.cpu().numpy() - np.diag(o["H"])))) / np.max(np.abs(o["H"]))
         err_theta = relerr(hp.theta.cpu().numpy(), o["theta"])
-        print("%s / %s rotation: predictions %.3g, H %.3g, theta %.3g (relative, max norm)"
-              % (case, rotation, err_mean, err_H, err_theta))
+        # ALL of H, the diagonal 128 x 128 blocks included (round-4 verdict: those 3 % of the
+        # triangle -- the blocks the Gram kernel computes with its packed four-into-three diagonal
+        # schedule -- were compared through theta only): obhip_gram_dev does not factorise in
+        # place, so e^{-2 sigma} G + prior (loglik_std.cpp:170-173, logpr_gauss.cpp:153-158) can be
+        # compared entry by entry
+        err_Hfull = hp.hessian_full_rel_err(o["H"])
+        print("%s / %s rotation: predictions %.3g, H %.3g (all of it: %.3g), theta %.3g (relative, max norm)"
+              % (case, rotation, err_mean, err_H, err_Hfull, err_theta))
         assert err_mean <= 1e-6
         if rotation == "shared":
-            assert err_H <= 1e-10
+            assert err_H <= 1e-10 and err_Hfull <= 1e-10
         else:
             # two independent eigensolvers: the basis functions themselves differ at rounding
             # level times the conditioning of the knot sums
-            assert err_H <= 1e-6
+            assert err_H <= 1e-6 and err_Hfull <= 1e-6
         assert hp.newton_residual_rel() < 1e-10      # matrix-free stationarity of the device theta
     finally:
         hp.close()

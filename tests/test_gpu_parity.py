@@ -1530,13 +1530,13 @@ def test_host_buffer_predr_std_and_the_small_helpers():
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n,p", [(3000, 1100), (700, 520), (2500, 2048)])
+@pytest.mark.parametrize("n,p", [(3000, 1100), (700, 520), (2500, 2048), (1500, 4096)])
 def test_gram_diagonal_tiles_packed_four_into_three_blocks(n, p, monkeypatch):
     """The staged-design-matrix Gram kernel gives four consecutive diagonal 128 x 128 tiles to
     three workgroups (a diagonal tile has three distinct 64 x 64 quadrants, not four).  Same G
     as with one workgroup per diagonal tile (OBHIP_GRAM_DIAG4=0) up to summation order, exactly
     symmetric, and the oracle's B^T B; p = 1100: two groups and a left-over tile, 520: one group
-    and one left-over, 2048: four groups."""
+    and one left-over, 2048: four groups, 4096 (the headline's p): eight groups."""
     import ob_oracle as O
     import outerbase_amd as ob
     kinds = ["mat25"] * 8

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, "declared in include/obhip.h but not exported: %s" % missing
     extra = sorted(s for s in exported if s.startswith("obhip_") and s not in protos)
     assert not extra, "exported but not declared: %s" % extra
-    assert _lib.lib.obhip_abi_version() == 4
+    assert _lib.lib.obhip_abi_version() == 5
 
 
 def test_header_cites_reference_for_every_entry_point():
@@ -408,3 +408,96 @@ def test_shipping_library_has_no_fault_injector():
     assert b"obhip_testing_fault_inject_pair" in tst
     src = open(os.path.join(ROOT, "outerbase_amd", "csrc", "comm.cpp")).read()
     assert src.count("#ifdef OBHIP_TESTING") == 3 and "FAULT_INJECT" not in src
+
+
+def _check_star_tables(om_d, terms):
+    """The star tables of a term set (obhip_terms_share_tables): every padded term is in exactly
+    one family star or left over (and then in exactly one plain star), and every term's factors
+    are exactly its star's shared part plus its own slots."""
+    import outerbase_amd as ob
+    from outerbase_amd._lib import call, ptr
+    tt = ob.obmod._Terms(om_d, terms)
+    info = np.zeros(10, dtype=np.uint64)
+    call("obhip_terms_share_tables", tt._h, ptr(info), None, None, None, None)
+    p_pad, nleft, reads, reads_plain, W, lds_cyc, lds_cyc0, nswf, nswp, reads_left = (int(v) for v in info)
+    p, d = terms.shape
+    assert p_pad == (p + 255) // 256 * 256 and W == max(2, ((terms > 0).sum(1).max() + 1) // 2 * 2)
+    nst = 64 * (nswf + nswp)
+    assert nst <= p_pad // 4 + 128 and nswp == (nleft + 255) // 256
+    term = np.zeros(4 * nst, dtype=np.uint32)
+    shape = np.zeros(nswf + nswp, dtype=np.uint32)
+    fac = np.zeros(nst * 4 * W, dtype=np.uint16)
+    left = np.zeros(max(nleft, 1), dtype=np.uint32)
+    call("obhip_terms_share_tables", tt._h, ptr(info), ptr(term), ptr(shape), ptr(fac), ptr(left))
+    left = left[:nleft]
+    term = term.reshape(nst, 4)
+    none = 0xffffffff
+    fam_terms = term[:64 * nswf][term[:64 * nswf] != none]
+    plain_terms = term[64 * nswf:][term[64 * nswf:] != none]
+    assert sorted(fam_terms.tolist() + left.tolist()) == list(range(p_pad))       # a partition
+    assert sorted(plain_terms.tolist()) == sorted(left.tolist())
+    maxlev = terms.max(0)
+    off = 1 + np.concatenate([[0], np.cumsum(maxlev)])
+    want = [sorted(int(off[l] + terms[k, l] - 1) for l in range(d) if terms[k, l] > 0) for k in range(p)]
+    want += [[] for _ in range(p_pad - p)]
+    fac = fac.reshape(nst, 4 * W)
+    tot = tot_left = 0
+    for s in range(nst):
+        P, S = int(shape[s // 64]) & 0xff, int(shape[s // 64]) >> 8
+        if s // 64 < nswf:
+            assert S == 1 and 1 <= P < W
+        else:
+            assert P == 0 and S in (W, max(W - 2, 1) if W >= 4 else W)
+        shared = [int(v) for v in fac[s, :P] if v]
+        for j in range(4):
+            own = [int(v) for v in fac[s, P + j * S:P + (j + 1) * S] if v]
+            if term[s, j] == none:
+                assert not own                                          # an empty slot
+            else:
+                assert sorted(shared + own) == want[int(term[s, j])]
+        assert not fac[s, P + 4 * S:].any()
+    for w in range(nswf + nswp):
+        c = (int(shape[w]) & 0xff) + 4 * (int(shape[w]) >> 8)
+        if w < nswf:
+            tot += c
+        else:
+            tot_left += c
+    assert tot == reads and tot_left == reads_left
+    assert 2 * (reads + reads_left) <= lds_cyc <= lds_cyc0
+    return nleft, reads, reads_plain
+
+
+def test_star_tables_of_downward_closed_and_arbitrary_term_sets():
+    """Shared sub-products (csrc/share.cpp): on selectterms' downward-closed sets
+    (modandbase.cpp:419-436) nearly every term lands in a star of four that differ in one factor
+    and the column reads per row fall by 40-50 %; a term set that is NOT downward-closed
+    (caller-supplied terms) is accepted all the same -- what finds no family goes into plain
+    stars."""
+    import ob_oracle as O
+    import outerbase_amd as ob
+    kinds = ["mat25"] * 20
+    om_o, om_d = make_pair(kinds, O.bench_knots(kinds))
+    terms = om_d.selectterms(4096)                                      # the headline term set
+    nleft, reads, reads_plain = _check_star_tables(om_d, terms)
+    assert nleft <= 64 and reads <= 0.55 * reads_plain and reads_plain == 194
+    kinds = ["mat25pow"] * 8
+    om_o, om_d = make_pair(kinds, O.bench_knots(kinds))
+    nleft, reads, reads_plain = _check_star_tables(om_d, om_d.selectterms(3000))    # six-factor terms
+    assert nleft <= 192 and reads <= 0.65 * reads_plain
+    # not downward-closed: random multi-indices, a few of them sharing factors by chance
+    rng = np.random.default_rng(5)
+    kinds = ["mat25"] * 12
+    om_o, om_d = make_pair(kinds, O.bench_knots(kinds))
+    for p, nnz in ((700, 4), (300, 2), (1500, 7)):
+        t = np.zeros((p, 12), dtype=np.int64)
+        for k in range(p):
+            dims = rng.choice(12, size=int(rng.integers(0, nnz + 1)), replace=False)
+            t[k, dims] = rng.integers(1, 6, len(dims))
+        t = np.unique(t, axis=0)
+        nleft, reads, reads_plain = _check_star_tables(om_d, t)
+        assert nleft > 0
+    # isolated terms only: everything plain, nothing shared
+    t = np.zeros((40, 12), dtype=np.int64)
+    for k in range(40):
+        t[k, [(3 * k) % 12, (3 * k + 1) % 12]] = 1 + k % 5, 1 + (k // 5) % 5
+    _check_star_tables(om_d, np.unique(t, axis=0))
