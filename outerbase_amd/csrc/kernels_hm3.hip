@@ -21,7 +21,8 @@
 //            lane = (row, wave partial)); the update() form also writes yhat and the residual sum;
 //   phase B (the 64 rows again, B^T w):  acc_k += prod_k w_r, the weight of a row one v_readlane
 //            pair (as k_tmm_tl) -- no cross-lane traffic at all.
-// Three workgroup barriers per tile instead of seventeen, ~60 VGPRs less than k_hm2 (no products
+// Two workgroup barriers per tile instead of seventeen (the hand-over from one tile to the next is
+// a counter of landed shares, not a barrier: see the tile loop), ~60 VGPRs less than k_hm2 (no products
 // kept), so 12 reads in flight per wave; the waves run their phases decoupled, LDS reads of one
 // under the reductions of another.  The tile is double-buffered by LDS-direct loads as in k_hm2.
 //
@@ -130,6 +131,7 @@ k_hm3(const double *__restrict__ bm, const double *__restrict__ scale, const uin
   double *ssw = wrow + 64;                            // [WAVES] residual sums (epilogue)
   double *la = ssw + WAVES;                           // [nleft] coefficients of the left-over terms
   uint32_t *lad = (uint32_t *)(la + kHm3LeftMax);     // [nleft][W] their columns' offsets in a tile (doubles)
+  uint32_t *landed = lad + kHm3LeftMax * W;           // waves whose share of a prefetched tile is in LDS
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
   const uint32_t tile_bytes = (uint32_t)tile_doubles * 8u;
   const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
@@ -169,6 +171,7 @@ k_hm3(const double *__restrict__ bm, const double *__restrict__ scale, const uin
   for (int jj = 0; jj < kHm3NL; ++jj) accl[jj] = 0.0;
   const uint32_t shape = live ? (uint32_t)__builtin_amdgcn_readfirstlane((int)shshape[wave]) : (1u | (1u << 8));
   for (int i = threadIdx.x; i < WAVES * kHm3RedPitch; i += WAVES * 64) red[i] = 0.0;  // absent waves: zero
+  if (threadIdx.x == 0) *landed = 0u;
 
   // next tile -> the other buffer, by LDS-direct loads; the last wave also fetches the rows' scale
   // and y (requested BEFORE the LDS-direct loads and only used at the top of the next tile: the
@@ -194,23 +197,48 @@ k_hm3(const double *__restrict__ bm, const double *__restrict__ scale, const uin
                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(l0 + (uint32_t)u * (kTlPitch * 8))));
     }
   };
-  if (t0 < t1) prefetch(t0, 0);
+  // Tile hand-over.  Two barriers per tile are data dependencies (phase A -> middle -> phase B);
+  // the third of the first version -- "the next tile has landed and nobody reads the other buffer
+  // any more", at the top of a tile -- made every wave wait for the slowest one's phase B.  Now:
+  // the next tile is requested right after the first barrier of a tile (every wave is past the
+  // previous tile, whose buffer it overwrites), a wave reports its share as landed after the first
+  // 16 rows of its phase B (s_waitcnt vmcnt(0), then one LDS add), and before phase A of the next
+  // tile a wave only waits until all 16 have reported -- which, as a rule, they did long ago: a
+  // wave that is through with phase B goes on into the next tile while others still work.
+  auto land = [&](int bnext) {  // my share of the prefetched tile (and, last wave, its weights)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == WAVES - 1) {  // per row (lane = row): vA = c_a s^2, vB = c_b s y  ->  w = vA tot + vB
+      double *wn = wts + bnext * 256;
+      wn[lane] = ca * scn * scn;
+      if (RO) {
+        wn[64 + lane] = cb * scn * yn;
+        wn[128 + lane] = scn;
+        wn[192 + lane] = yn;
+      }
+    }
+    if (lane == 0) __hip_atomic_fetch_add(landed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  __syncthreads();  // red, la, lad and the counter are initialised -- before any wave reports a share
+  if (t0 < t1) {
+    prefetch(t0, 0);
+    land(0);
+  }
   double ssacc = 0.0;  // lanes (lane & 15) == 0: sum over their rows of (yhat - y)^2
 
   for (uint64_t tile = t0; tile < t1; ++tile) {
     const int bsel = (int)((tile - t0) & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed
     double *wt = wts + bsel * 256;
-    if (wave == WAVES - 1) {  // per row (lane = row): vA = c_a s^2, vB = c_b s y  ->  w = vA tot + vB
-      wt[lane] = ca * scn * scn;
-      if (RO) {
-        wt[64 + lane] = cb * scn * yn;
-        wt[128 + lane] = scn;
-        wt[192 + lane] = yn;
-      }
+    {  // every wave's share of this tile is in LDS (reported by land(): 16 per tile)
+      // (bounded: every wave reports unconditionally, so the wait cannot last; should it ever, the
+      // wave goes on after ~0.3 s and poisons its results instead of hanging the GPU)
+      const uint32_t want = (uint32_t)(tile - t0 + 1) * WAVES;
+      int spins = 0;
+      while (__builtin_amdgcn_readfirstlane(
+                 (int)__hip_atomic_load(landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < (int)want &&
+             ++spins < (1 << 22))
+        __builtin_amdgcn_s_sleep(2);
+      if (spins >= (1 << 22)) acc[0] = __builtin_nan("");
     }
-    __syncthreads();  // tile and weights complete; every wave is done with the other buffer
-    if (tile + 1 < t1) prefetch(tile + 1, bsel ^ 1);
 
     // ---- phase A: per-wave row sums of sum_k a_k prod_k, 8 rows at a time --------------------
     if (live) {
@@ -243,7 +271,12 @@ k_hm3(const double *__restrict__ bm, const double *__restrict__ scale, const uin
         }
       }
     }
-    __syncthreads();  // every wave's row sums are in red
+    // (s_barrier behind an lgkmcnt wait only: __syncthreads would also wait for the vector-memory
+    // counter, i.e. at the second barrier for the tile requested a moment before)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's row sums are in red -- and every wave is past the previous tile
+    asm volatile("" ::: "memory");
+    if (tile + 1 < t1) prefetch(tile + 1, bsel ^ 1);
 
     // ---- middle: tot_r over the waves, w_r; wave w takes rows 4 w .. 4 w + 3 ------------------
     // lane = (row, part): part < 16 indexes the waves' partial sums and the left-over terms
@@ -289,7 +322,9 @@ k_hm3(const double *__restrict__ bm, const double *__restrict__ scale, const uin
         wrow[row] = wv;
       }
     }
-    __syncthreads();  // the row weights are complete (and red may be overwritten)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the row weights are complete (and red may be overwritten)
+    asm volatile("" ::: "memory");
 
     // ---- phase B: acc_k += prod_k w_r -----------------------------------------------------------
     // after the last rows: row 0 of the other buffer
@@ -300,6 +335,7 @@ k_hm3(const double *__restrict__ bm, const double *__restrict__ scale, const uin
       for (int rc = 0; rc < kTileRows; rc += 16) {
         cb_.rc = rc;
         tl_star_run<W, 16, K>(cb_, shape);
+        if (rc == 0 && tile + 1 < t1) land(bsel ^ 1);
         const int32_t step = rc + 16 < kTileRows ? 16 * 8 : step_last;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -307,9 +343,8 @@ k_hm3(const double *__restrict__ bm, const double *__restrict__ scale, const uin
           asm volatile("" : "+v"(ad[i]));
         }
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) ad[i] += bsel ? -tile_bytes : tile_bytes;
+    } else if (tile + 1 < t1) {
+      land(bsel ^ 1);
     }
   }
   if (ok) {
@@ -379,7 +414,7 @@ int run_hm3(const obhip_basis &b, obhip_terms &t, const double *d_a, const doubl
 size_t hm3_lds_bytes(const obhip_terms &t) {
   return ((size_t)2 * t.Mu * kTlPitch + 2 * 256 + kHm3Waves * kHm3RedPitch + 64 + kHm3Waves + kHm3LeftMax) *
              sizeof(double) +
-         (size_t)kHm3LeftMax * t.W * sizeof(uint32_t);
+         ((size_t)kHm3LeftMax * t.W + 4) * sizeof(uint32_t);
 }
 
 }  // namespace
