@@ -1110,6 +1110,34 @@ int dispatch_mm_tl(const obhip_basis &b, obhip_terms &t, const double *d_a, doub
 #undef OB_ML
 }
 
+// kernels_star.hip: the kernels on shared sub-products (stars of four terms), from 9 star-waves up
+bool star_supports(const obhip_terms &t, bool one_block, bool dual = false);
+int launch_star_hess(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,
+                     double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
+                     uint64_t tps, const double *stop0, const double *stop1);
+int launch_star_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, bool squared, double *part,
+                    const double *d_a2, double *part2, unsigned nsplit, uint64_t ntiles, uint64_t tps);
+int launch_star_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, bool squared, double *d_out,
+                   double *mpart, unsigned nsplit, uint64_t ntiles, uint64_t tps);
+
+namespace {
+bool hm3_wanted() {
+  static const bool off = getenv("OBHIP_HM3") && atoi(getenv("OBHIP_HM3")) == 0;
+  return !off;
+}
+// one workgroup per CU (two tiles of the used columns in LDS), a range of tiles each; the terms in
+// workgroups of 16 star-waves
+void star_grid(const obhip_basis &b, const obhip_terms &t, uint64_t &nsplit, uint64_t &pblocks, uint64_t &ntiles,
+               uint64_t &tps) {
+  ntiles = b.n_pad / kTileRows;
+  pblocks = (t.sh.nsw_family + 15) / 16;
+  nsplit = std::max<uint64_t>(1, (uint64_t)device_cus(b.device) / pblocks);
+  nsplit = std::min(nsplit, std::max<uint64_t>(1, ntiles / 4));
+  tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+}
+}  // namespace
+
 int mm_tl_supports(const obhip_terms &t) {
   const int w2 = (int)(t.W / 2);
   return w2 >= 1 && w2 <= kMaxW2 &&
@@ -1123,6 +1151,26 @@ int launch_mm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d
     return launch_mm_generic(b, t, d_a, d_out, squared ? 1 : 0, 0);
   }
   static const bool force_rows = getenv("OBHIP_MM_LANE_ROW") != nullptr;
+  if (!force_rows && hm3_wanted() && star_supports(t, false)) {  // shared sub-products (kernels_star.hip)
+    uint64_t nsplit, pblocks, ntiles, tps;
+    star_grid(b, t, nsplit, pblocks, ntiles, tps);
+    double *mpart = nullptr;
+    if (pblocks > 1)
+      OB_TRY(const_cast<obhip_basis &>(b).workspace(pblocks * b.n_pad * sizeof(double), (void **)&mpart));
+    ProfScope ps(squared ? "sqmm" : "mm");
+    OB_TRY(launch_star_mm(b, t, d_a, squared, d_out, mpart, (unsigned)nsplit, ntiles, tps));
+    if (pblocks > 1) {
+      const dim3 g2((unsigned)((b.n + 255) / 256));
+      if (squared)
+        hipLaunchKernelGGL(k_mm_tl_sum<true>, g2, dim3(256), 0, cur_stream(), mpart, (int)pblocks, b.n_pad,
+                           b.scale.p, b.n, d_out);
+      else
+        hipLaunchKernelGGL(k_mm_tl_sum<false>, g2, dim3(256), 0, cur_stream(), mpart, (int)pblocks, b.n_pad,
+                           b.scale.p, b.n, d_out);
+      OB_HIP(hipGetLastError());
+    }
+    return 0;
+  }
   if (!mm_tl_supports(t) || force_rows) {
     ProfScope ps(squared ? "sqmm" : "mm");
     return squared ? dispatch_mm<1>(b, t, d_a, d_out) : dispatch_mm<0>(b, t, d_a, d_out);
@@ -1274,6 +1322,23 @@ int launch_tmm_dual(const obhip_basis &b, obhip_terms &t, const double *d_a, dou
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   static const bool off = getenv("OBHIP_TMM_DUAL") && atoi(getenv("OBHIP_TMM_DUAL")) == 0;
   const int w2 = (int)(t.W / 2);
+  if (!off && !beyond_lds(t) && hm3_wanted() && star_supports(t, false, true)) {  // shared sub-products
+    uint64_t nsplit, pblocks, ntiles, tps;
+    star_grid(b, t, nsplit, pblocks, ntiles, tps);
+    double *part = nullptr;
+    OB_TRY(const_cast<obhip_basis &>(b).workspace(2 * nsplit * t.p_pad * sizeof(double), (void **)&part));
+    double *part2 = part + nsplit * t.p_pad;
+    {
+      ProfScope ps("tmm_dual");
+      OB_TRY(launch_star_tmm(b, t, d_a, false, part, d_a2, part2, (unsigned)nsplit, ntiles, tps));
+    }
+    hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0, cur_stream(), part,
+                       (int)nsplit, t.p_pad, (int)t.p, d_out);
+    hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0, cur_stream(), part2,
+                       (int)nsplit, t.p_pad, (int)t.p, d_out2);
+    OB_HIP(hipGetLastError());
+    return 0;
+  }
   if (off || beyond_lds(t) || !tmm_tl_supports(t) || w2 > 3) return kNotFused;
   const bool pf = t.Mu <= (uint64_t)kTlWaves * kTlPre;  // (else the tile is loaded between the barriers)
   const uint64_t ntiles = b.n_pad / kTileRows, p_pad = t.p_pad;
@@ -1337,6 +1402,19 @@ int launch_tmm(const obhip_basis &b, obhip_terms &t, const double *d_a, double *
   const uint64_t p_pad = t.p_pad;  // multiple of 256 (obhip_terms::prepare)
   double *part = nullptr;
   static const bool force_rows = getenv("OBHIP_TMM_LANE_ROW") != nullptr;
+  if (!force_rows && hm3_wanted() && star_supports(t, false)) {  // shared sub-products (kernels_star.hip)
+    uint64_t nsplit, pblocks, nt, tps;
+    star_grid(b, t, nsplit, pblocks, nt, tps);
+    OB_TRY(const_cast<obhip_basis &>(b).workspace(nsplit * p_pad * sizeof(double), (void **)&part));
+    {
+      ProfScope ps(squared ? "sqtmm" : "tmm");
+      OB_TRY(launch_star_tmm(b, t, d_a, squared, part, nullptr, nullptr, (unsigned)nsplit, nt, tps));
+    }
+    hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0,
+                       cur_stream(), part, (int)nsplit, p_pad, (int)t.p, d_out);
+    OB_HIP(hipGetLastError());
+    return 0;
+  }
   if (tmm_tl_supports(t) && !force_rows) {
     // term-per-lane kernel: the fewest blocks along p that the register budget allows
     const int npmax = t.W / 2 <= 2 ? 4 : 2;
@@ -1419,17 +1497,7 @@ int launch_hm2(const obhip_basis &b, obhip_terms &t, const double *d_a, const do
                double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
                uint64_t tps, int variant, const double *stop0, const double *stop1);
 
-// kernels_hm3.hip: the two-phase kernel on shared sub-products (stars), 2049 .. 4096 terms
-bool hm3_supports(const obhip_terms &t);
-int launch_hm3(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,
-               double cb, double *part, double *d_yhat, double *sspart, unsigned nsplit, uint64_t ntiles,
-               uint64_t tps, const double *stop0, const double *stop1);
-
 namespace {
-bool hm3_wanted() {
-  static const bool off = getenv("OBHIP_HM3") && atoi(getenv("OBHIP_HM3")) == 0;
-  return !off;
-}
 bool hm2_wanted() {
   static const bool off = getenv("OBHIP_HESSMULT_FUSED") && atoi(getenv("OBHIP_HESSMULT_FUSED")) == 0;
   static const bool v1 = getenv("OBHIP_HM_V1") && atoi(getenv("OBHIP_HM_V1")) != 0;
@@ -1446,7 +1514,7 @@ int hm2_variant() {
 bool hessmult_fused_skippable(const obhip_basis &b, obhip_terms &t) {
   if (t.prepare(b.md.cap, b.md.dims_h) != 0) return false;
   if (!hm2_wanted() || beyond_lds(t)) return false;
-  return (hm3_wanted() && hm2_variant() == 0 && hm3_supports(t)) || hm2_supports(t, false, hm2_variant());
+  return (hm3_wanted() && hm2_variant() == 0 && star_supports(t, true)) || hm2_supports(t, false, hm2_variant());
 }
 
 int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y,
@@ -1458,7 +1526,7 @@ int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_
   const int variant = hm2_variant();
   const int w2 = (int)(t.W / 2);
   // OBHIP_HM3=0: k_hm2 instead of the two-phase kernel on shared sub-products (A/B)
-  const bool use3 = hm2_wanted() && hm3_wanted() && variant == 0 && !beyond_lds(t) && hm3_supports(t);
+  const bool use3 = hm2_wanted() && hm3_wanted() && variant == 0 && !beyond_lds(t) && star_supports(t, true);
   const bool use2 = use3 || (hm2_wanted() && !beyond_lds(t) && hm2_supports(t, d_y != nullptr, variant));
   if (d_stop0 && !use2) return fail(OBHIP_ERR_STATE, "hessmult: stop flags need the k_hm2 / k_hm3 path");
   // (8 terms of 6 factors per lane spill and run at half the speed of the two-kernel form: measured)
@@ -1481,8 +1549,8 @@ int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_
   double *sspart = d_ss ? part + nsplit * t.p_pad : nullptr;
   if (use3) {
     ProfScope ps("hessmult");
-    OB_TRY(launch_hm3(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps, d_stop0,
-                      d_stop1));
+    OB_TRY(launch_star_hess(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps,
+                            d_stop0, d_stop1));
   } else if (use2) {
     ProfScope ps("hessmult");
     OB_TRY(launch_hm2(b, t, d_a, d_y, ca, cb, part, d_yhat, sspart, (unsigned)nsplit, ntiles, tps, variant,
