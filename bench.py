@@ -155,6 +155,18 @@ def fit_vs_oracle(HotPath, shard_rows, kinds, knots, p, rows, rank, world, trans
     O, om = oracle_model(kinds, knots)
     out = {"rows": rows, "p": p}
     row0, n_local = shard_rows(rank, world, rows)
+    # rank 0: the oracle's fit first (its H is what the device's full H is compared with below)
+    theta_o = H_o = want = None
+    if rank == 0:
+        t0 = time.perf_counter()
+        terms_o = om.selectterms(p)
+        x, y = O.synth_xy(42, 0, rows, kinds)
+        cent, sca = y.mean(), y.std(ddof=1)
+        theta_o, H_o = O.fit_newton(O.OuterBase(om, x), terms_o, (y - cent) / sca)
+        k = min(pred_rows, n_local)
+        xnew, _ = O.synth_xy(43, 0, k, kinds)
+        want = cent + sca * O.predict_mean(om, terms_o, theta_o, xnew)
+        out["oracle_seconds"] = time.perf_counter() - t0
     runs = {}
     for name, rot in (("own_eigensolver", None),
                       ("shared_rotation", (om.rotmat, om.basisvar, om.maxlevel))):
@@ -166,27 +178,23 @@ def fit_vs_oracle(HotPath, shard_rows, kinds, knots, p, rows, rank, world, trans
         k = min(pred_rows, n_local)
         runs[name] = dict(terms=h.terms.copy(), mean=h.mean[:k].cpu().numpy(),
                           theta=h.theta.cpu().numpy(), cent=h.y_cent, sca=h.y_sca,
-                          H_upper=None, diagH=h.diagH.cpu().numpy())
+                          H_upper=None, diagH=h.diagH.cpu().numpy(), H_full_err=None)
         if rank == 0:
             # H above its diagonal 128 x 128 blocks (the Cholesky factor overwrote the lower
             # triangle and those blocks); the diagonal of H is kept aside by the fit
             runs[name]["H_upper"] = h.G.cpu().numpy()
+            # ALL of H, diagonal blocks included: formed once more by obhip_gram_dev into a buffer
+            # of its own (one rank: the rows of this rank are all rows)
+            if world == 1 and np.array_equal(runs[name]["terms"], terms_o):
+                runs[name]["H_full_err"] = h.hessian_full_rel_err(H_o)
         h.close()
         del h
         torch.cuda.empty_cache()
     if rank != 0:
         return None
     terms = runs["shared_rotation"]["terms"]
-    out["terms_equal_oracle_selection"] = bool(np.array_equal(terms, om.selectterms(p)))
+    out["terms_equal_oracle_selection"] = bool(np.array_equal(terms, terms_o))
     out["terms_equal_between_eigensolvers"] = bool(np.array_equal(terms, runs["own_eigensolver"]["terms"]))
-    t0 = time.perf_counter()
-    x, y = O.synth_xy(42, 0, rows, kinds)
-    cent, sca = y.mean(), y.std(ddof=1)
-    theta_o, H_o = O.fit_newton(O.OuterBase(om, x), terms, (y - cent) / sca)
-    k = len(runs["shared_rotation"]["mean"])
-    xnew, _ = O.synth_xy(43, 0, k, kinds)
-    want = cent + sca * O.predict_mean(om, terms, theta_o, xnew)
-    out["oracle_seconds"] = time.perf_counter() - t0
     blk = np.arange(p) // 128
     iu = np.nonzero(blk[None, :] > blk[:, None])
     for name, r in runs.items():
@@ -195,8 +203,10 @@ def fit_vs_oracle(HotPath, shard_rows, kinds, knots, p, rows, rank, world, trans
             e["hessian_max_rel_err"] = float(max(
                 np.max(np.abs(r["H_upper"][iu] - H_o[iu])) if len(iu[0]) else 0.0,
                 np.max(np.abs(r["diagH"] - np.diag(H_o)))) / np.max(np.abs(H_o)))
+            e["hessian_full_max_rel_err"] = r["H_full_err"]
             e["theta_max_rel_err"] = float(np.max(np.abs(r["theta"] - theta_o)) / np.max(np.abs(theta_o)))
         out[name] = e
+    out["hessian_full_max_rel_err"] = out["shared_rotation"].get("hessian_full_max_rel_err")
     # the figure the tier asks for: device fit + predict vs the reference path's restatement on
     # the same inputs with NOTHING shared
     out["theta_vs_oracle_rows"] = out["own_eigensolver"]["predict_max_rel_err"]
@@ -468,7 +478,64 @@ def secondary_rooflines(hp, prof):
     return out
 
 
-def obfit_evaluation(kinds, knots, p, n, torch, _lib, reps=3):
+def config0_obfit(torch, _lib):
+    """BASELINE.json configs[0]: Borehole d=8, n=1000, p=256 through obfit + obpred -- the one
+    configuration at the scale of the reference's own vignette (vignettes/gettingstarted.Rmd:59-68,
+    R/fitting.R:27-155).  Device leg: outerbase_amd.fitting.obfit / obpred (every data-sized step a
+    device call), wall time, profiled launches and host round trips.  CPU leg (BASELINE.md section 3,
+    C1): oracle/ob_harness.py, the NumPy restatement of the same two-stage flow, on the host cores --
+    the stated baseline of this entry, like `cpu_baseline` a checker timed, never the product."""
+    import numpy as np
+    import outerbase_amd as ob
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ob_oracle as O
+    import ob_harness as H
+    rng = np.random.default_rng(0)
+    n, d, numb = 1000, 8, 256
+    x = rng.random((n, d))
+    y = O.borehole8d(x)
+    xt = rng.random((500, d))
+    yt = O.borehole8d(xt)
+
+    def counters():
+        a, b, ms = C.c_uint64(0), C.c_uint64(0), C.c_double(0)
+        _lib.call("obhip_profile_get", b"*", C.byref(a), C.byref(ms))
+        _lib.call("obhip_profile_get", b"host_syncs", C.byref(b), None)
+        return a.value, b.value, ms.value
+    ob.obfit(x[:200], y[:200], numb=50, seed=0)          # first use: instantiations, pool
+    torch.cuda.synchronize()
+    _lib.call("obhip_profile_reset")
+    _lib.call("obhip_profile_enable", 1)
+    l0, s0, _ = counters()
+    t0 = time.perf_counter()
+    m = ob.obfit(x, y, numb=numb, seed=0)
+    t1 = time.perf_counter()
+    pred = ob.obpred(m, xt)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    l1, s1, kms = counters()
+    _lib.call("obhip_profile_enable", 0)
+    rmse = float(np.sqrt(np.mean((pred["mean"] - yt) ** 2)) / np.std(yt))
+    out = {"workload": "BASELINE.json configs[0]: Borehole d=8 n=1000 p=256 mat25pow, obfit (two stages, "
+                       "BFGS over the hyper-parameters, PCG inside) + obpred (mean and var) at 500 new points",
+           "device": {"obfit_s": t1 - t0, "obpred_ms": (t2 - t1) * 1e3, "profiled_launches": l1 - l0,
+                      "profiled_kernel_ms": kms, "host_round_trips": s1 - s0,
+                      "test_rmse_over_sd": rmse, "var_min": float(np.min(pred["var"]))}}
+    del m
+    numbr = min(n // 2, numb, 80 * d)
+    sub = np.random.default_rng(0).choice(n, size=min(n, 3 * numbr), replace=False)
+    t0 = time.perf_counter()
+    mo = H.obfit(x, y, numb, ["mat25pow"] * d, sub)
+    t1 = time.perf_counter()
+    pm = H.obpred_mean(mo, xt)
+    out["cpu"] = {"kind": "port", "what": "oracle/ob_harness.py (NumPy restatement of R/fitting.R:27-137 and the "
+                  "lpdf classes under it)", "obfit_s": t1 - t0, "cores": host_threads(),
+                  "test_rmse_over_sd": float(np.sqrt(np.mean((pm - yt) ** 2)) / np.std(yt)),
+                  "bfgs_iterations": [len(t) for t in mo["traces"]]}
+    return out
+
+
+def obfit_evaluation(kinds, knots, p, n, torch, _lib, reps=3, maxlev=None, what="the headline rows and terms"):
     """One second-stage function evaluation of obfit (R/fitting.R:123-136 through BFGS_lpdf ->
     .lpdfwrapper, R/optimization.R: updatehyp, updateom, updatepara, lpdf$optcg, then value and
     gradients) on the bench's rows and terms: lpdfvec(loglik_gauss, logpr_gauss) with the marginal
@@ -493,6 +560,12 @@ def obfit_evaluation(kinds, knots, p, n, torch, _lib, reps=3):
     ob.setcovfs(om, kinds)
     ob.setknot(om, bench_knots(kinds, knots))
     terms = om.selectterms(p)
+    if maxlev is not None:
+        # (obfit's term sets at this shape keep fewer levels than selectterms at the default
+        # hyper-parameters: its length scales grow and the eigenvalues fall faster)
+        t4 = om.selectterms(4 * p)
+        terms = t4[t4.max(1) <= maxlev][:p]
+        assert len(terms) == p
     lik = ob.loglik_gauss(om, terms, yh, xh)
     pr = ob.logpr_gauss(om, terms)
     vec = ob.lpdfvec(lik, pr)
@@ -521,12 +594,14 @@ def obfit_evaluation(kinds, knots, p, n, torch, _lib, reps=3):
         if cnt.value:
             phases[name] = {"launches_per_evaluation": cnt.value / reps, "ms_per_evaluation": round(tot.value / reps, 3)}
     _lib.call("obhip_profile_enable", 0)
-    out = {"workload": "one second-stage obfit function evaluation on the headline rows and terms: updatehyp, "
+    out = {"workload": "one second-stage obfit function evaluation on " + what + ": updatehyp, "
                        "updateom, updatepara, lpdf$optcg (device PCG, tol 1e-3, <= 100 steps), then value, "
                        "%d hyper-parameter and 2 parameter gradients with the marginal adjustment "
                        "(lpdfvec of loglik_gauss and logpr_gauss)" % len(hyp),
            "ms_per_evaluation": ms, "cg_iterations": int(vec.cgiters) if hasattr(vec, "cgiters") else None,
-           "phases": phases, "gradhyp_norm": float(np.linalg.norm(np.asarray(vec.gradhyp)))}
+           "phases": phases, "gradhyp_norm": float(np.linalg.norm(np.asarray(vec.gradhyp))),
+           "d": d, "p": p, "n": n, "covariance": "/".join(sorted(set(kinds))),
+           "factors_per_term_max": int((terms > 0).sum(1).max()), "levels_max": int(terms.max())}
     del vec, lik, pr
     return out
 
@@ -586,6 +661,16 @@ def main():
     # reduce-scatter / all-gather pair switches this communicator to ncclAllReduce in-process,
     # a wrong all-reduce ends the run with a message (obhip_comm_selftest_dev)
     selftest = hp.comm_selftest()
+    if world > 1 or transport:
+        # every rank, on stderr: a failed first RCCL contact on a multi-GPU node must be diagnosable
+        # from that rank's log alone (n8.err of the driver's scaling run)
+        ci = hp.comm_info()
+        sys.stderr.write("[bench rank %d/%d] exchange: transport=%s path=%s ranks=%s rccl_ranks=%s "
+                         "rccl_version=%s bytes_per_fit=%s selftest=%s\n"
+                         % (rank, world, ci.get("transport"), ci.get("path"), ci.get("ranks"),
+                            ci.get("rccl_ranks"), ci.get("rccl_version"), ci.get("bytes_per_fit"),
+                            json.dumps(selftest)))
+        sys.stderr.flush()
 
     elapsed, per_step = timed_steps(hp, args.steps, args.warmup, sync, torch, dist, world)
     prof = kernel_profile(hp, _lib, torch)
@@ -605,6 +690,28 @@ def main():
         dt = float(tt.item())
         split[name + "_ms"] = dt * 1e3
         split[name + "_only_points_per_s"] = float(n_total) / dt
+
+    # obpred returns mean AND var (R/fitting.R:149-155; pred_gauss: var = B^2 (1 / diag H) + e^{2 sigma},
+    # loglik_gauss.cpp:223-227): the fused predictor with the variance on, same rows
+    if args.backend == "newton":
+        cv = 1.0 / hp.diagH
+        var = torch.empty_like(hp.mean)
+
+        def predict_with_var():
+            _lib.call("obhip_predict_dev", hp.om._h, hp.t._h, hp.theta.data_ptr(), hp.xnew.data_ptr(), hp.n,
+                 hp.mean.data_ptr(), cv.data_ptr(), hp.sigma, var.data_ptr())
+        predict_with_var()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            predict_with_var()
+        sync()
+        tt = torch.tensor([(time.perf_counter() - t0) / 2], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        split["predict_with_var_ms"] = float(tt.item()) * 1e3
+        split["predict_var_min"] = float(var.min().item())
+        del cv, var
 
     # what a host-buffer caller pays on top: x, y, xnew in, mean out over PCIe
     # (pinned buffers); reported beside `value`, never part of it
@@ -705,11 +812,23 @@ def main():
 
     # obfit's function evaluation on the same problem (north_star's entry point runs these by the
     # hundred): one process, after everything that is timed
-    obfit_eval = None
+    obfit_eval = obfit_eval_pow = config0 = None
     if headline and world == 1 and not transport and not args.no_obfit_eval:
         torch.cuda.empty_cache()
         _lib.call("obhip_trim_pool")
         obfit_eval = obfit_evaluation(kinds, args.knots, args.p, n_total, torch, _lib)
+        torch.cuda.empty_cache()
+        _lib.call("obhip_trim_pool")
+        # obfit's DEFAULT covariance (R/fitting.R:66, listcov R/outersupport.R:195-226): mat25pow, two
+        # hyper-parameters per dimension, terms of up to six factors at d = 8
+        obfit_eval_pow = obfit_evaluation(
+            ["mat25pow"] * 8, 40, 4096, n_total, torch, _lib, maxlev=12,
+            what="%d seed-42 rows of the d = 8 Borehole surface with obfit's default covariance "
+                 "(mat25pow), selectterms' 4096 terms of at most 12 levels" % n_total)
+        torch.cuda.empty_cache()
+        _lib.call("obhip_trim_pool")
+        if not args.no_cpu_baseline:
+            config0 = config0_obfit(torch, _lib)
 
     if rank != 0:
         if world > 1:
@@ -762,7 +881,10 @@ def main():
         "config3": config3,
         "configs": others,
         "obfit_eval": obfit_eval,
+        "obfit_eval_mat25pow_d8": obfit_eval_pow,
     }
+    if config0 is not None:
+        out["configs"] = [config0] + out["configs"]
     if transport:
         out["sim_ranks"] = vworld
         out["config"]["parallelism"] = (

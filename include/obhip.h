@@ -86,7 +86,11 @@ int obhip_synchronize(void);
  * OBHIP_POOL_MB, default 8192, of cached memory); this hands the cached blocks back to the
  * driver. */
 int obhip_trim_pool(void);
-/* Per-kernel hipEvent timing (used by bench.py for the roofline line). */
+/* Per-kernel hipEvent timing (used by bench.py for the roofline line).  obhip_profile_get: the
+ * launches and device time of one profiled scope ("gram", "cholesky", "hessmult", ...); "*" = all
+ * scopes together; "host_syncs" = the number of times the library has blocked on the device
+ * since it was loaded (launches; total_ms = 0): the host round trips of a call sequence are the
+ * difference of two readings. */
 int obhip_profile_enable(int on);
 int obhip_profile_reset(void);
 int obhip_profile_get(const char *kernel, uint64_t *launches, double *total_ms);

@@ -126,6 +126,7 @@ struct ProfEntry {
   double total_ms = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
+std::atomic<uint64_t> obhip::g_host_syncs{0};
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::map<std::string, ProfEntry> g_prof;
@@ -495,7 +496,24 @@ int obhip_profile_reset(void) {
 
 int obhip_profile_get(const char *kernel, uint64_t *launches, double *total_ms) {
   if (!kernel) return fail(OBHIP_ERR_INVALID, "null argument");
+  if (std::string(kernel) == "host_syncs") {  // blocking waits for the device since the library was loaded
+    if (launches) *launches = obhip::g_host_syncs.load();
+    if (total_ms) *total_ms = 0;
+    return 0;
+  }
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (std::string(kernel) == "*") {  // all profiled scopes together
+    uint64_t n = 0;
+    double ms = 0;
+    for (auto &e : g_prof) {
+      prof_drain(e.second);
+      n += e.second.launches;
+      ms += e.second.total_ms;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    return 0;
+  }
   auto it = g_prof.find(kernel);
   if (it == g_prof.end()) {
     if (launches) *launches = 0;

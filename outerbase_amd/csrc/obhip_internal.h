@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +42,21 @@ int ensure_dyn_lds(const void *kernel, size_t bytes);  // dynamic LDS above 64 K
 int device_cus(int device);                            // compute units (cached per device)
 
 // ---- profiling --------------------------------------------------------------
+// every blocking wait of the library for the device goes through these (the macros below): counted,
+// so that a caller can ask how many host round trips a call sequence made
+// (obhip_profile_get("host_syncs"); bench.py reports it for the small-n obfit of configs[0])
+extern std::atomic<uint64_t> g_host_syncs;
+inline hipError_t counted_stream_sync(hipStream_t s) {
+  g_host_syncs.fetch_add(1, std::memory_order_relaxed);
+  return hipStreamSynchronize(s);
+}
+inline hipError_t counted_device_sync() {
+  g_host_syncs.fetch_add(1, std::memory_order_relaxed);
+  return hipDeviceSynchronize();
+}
+#define hipStreamSynchronize(s) obhip::counted_stream_sync(s)
+#define hipDeviceSynchronize() obhip::counted_device_sync()
+
 struct ProfScope {
   const char *name;
   hipEvent_t e0 = nullptr, e1 = nullptr;
