@@ -376,7 +376,8 @@ int obhip_terms::prepare(const std::vector<int64_t> &cap,
     OB_TRY(sperm.upload(order.data(), order.size()));
   }
   // shared sub-products: stars of four terms that differ in one factor (share.cpp)
-  OB_TRY(obhip::build_share_tables(hc.data(), p_pad, W, sh));
+  sh = obhip::ShareTables();
+  if (!no_share) OB_TRY(obhip::build_share_tables(hc.data(), p_pad, W, sh));
   if (sh.ok) {
     OB_TRY(sh_cols.upload(sh.cols.data(), sh.cols.size()));
     OB_TRY(sh_term.upload(sh.term.data(), sh.term.size()));

@@ -1261,6 +1261,7 @@ static void build_sparse_views(obhip_terms &t, const obhip_basis &b) {
     if (ix.empty()) continue;
     for (int delta = 0; delta < 2; ++delta) {
       auto v = std::make_unique<obhip_terms>();
+      v->no_share = true;  // (a view of the caller's terms: the per-hyper-parameter kernels take the plain tables)
       v->p = ix.size();
       v->d = de;
       v->lev.assign(v->p * de, 0);
@@ -1299,6 +1300,7 @@ static void build_sparse_views(obhip_terms &t, const obhip_basis &b) {
     auto close_group = [&](obhip_terms::GeGroup &g) {
       if (g.hyps.empty()) return;
       auto v = std::make_unique<obhip_terms>();
+      v->no_share = true;  // (a view of the caller's terms: the per-hyper-parameter kernels take the plain tables)
       v->p = g.off.back();
       v->d = de;
       v->lev.resize(v->p * de);
@@ -1426,6 +1428,7 @@ static bool build_d3_groups(obhip_terms &t, const obhip_basis &b) {
       G.off.push_back(G.off.back() + t.ge_sidx[mem[q].h0].size());
     }
     auto v = std::make_unique<obhip_terms>();
+    v->no_share = true;
     v->p = G.off.back();
     v->d = 0;
     v->p_pad = (v->p + 255) / 256 * 256;
@@ -1496,6 +1499,7 @@ obhip_terms *grad_view(obhip_terms &t, const obhip_basis &b, uint64_t h) {
   }
   if (!t.ge_views[h]) {
     auto v = std::make_unique<obhip_terms>();
+    v->no_share = true;
     v->p = t.p;
     v->d = de;
     v->lev.assign(t.p * de, 0);

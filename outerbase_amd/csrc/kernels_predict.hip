@@ -343,6 +343,10 @@ int dispatch_predict(const obhip_model &m, obhip_terms &t, const double *d_theta
 
 }  // namespace
 
+bool star_predict_supports(const obhip_terms &t);
+int launch_star_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, const double *d_x, uint64_t n,
+                        double *d_mean, const double *d_coeffvar, double e2sigma, double *d_var);
+
 int launch_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, const double *d_x,
                    uint64_t n, double *d_mean, const double *d_coeffvar, double e2sigma,
                    double *d_var) {
@@ -367,6 +371,9 @@ int launch_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, 
     return rc;
   }
   static const bool lane_row = getenv("OBHIP_PREDICT_LANE_ROW") != nullptr;
+  static const bool no_star = getenv("OBHIP_HM3") && atoi(getenv("OBHIP_HM3")) == 0;
+  if (!lane_row && !no_star && star_predict_supports(t))  // shared sub-products (kernels_star.hip)
+    return launch_star_predict(m, t, d_theta, d_x, n, d_mean, d_coeffvar, e2sigma, d_var);
   const int w2 = (int)(t.W / 2);
   if (!lane_row && w2 >= 1 && w2 <= 4 &&
       (t.Mu * kTlPitch + 3 * kTlWaves * kTileRows) * sizeof(double) <= 156 * 1024) {

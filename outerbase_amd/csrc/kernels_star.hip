@@ -490,6 +490,190 @@ k_star(const uint32_t *__restrict__ ucol /* = A.ucol: a kernel argument of its o
   }
 }
 
+// ---- the fused predictor on shared sub-products ---------------------------------------------------
+// predictor$update + $mean + $var of pred_gauss (src/lpdfs/loglik_gauss.cpp:214-227: a fresh
+// outerbase at the new rows, modandbase.cpp:547, then prodmm_ on basemat and on basematsq,
+// linalg.cpp:57-131) in one kernel, as k_predict_tl (kernels_predict.hip) -- the basis tile only
+// ever exists in LDS -- with the contraction of k_star: per 64-row tile the 16 waves evaluate the
+// dimensions (lane = row, wave w takes dimensions w, w + 16, ...) into the [column][65] tile, then
+// phase A with the stars in the lanes (mean: q sum_u theta_u g_u; VAR: q^2 sum_u cv_u g_u^2 beside
+// it) and the middle step (sum over the waves, the left-over terms, the row's basescale).
+template <int NA, bool VAR>
+struct StP {
+  static constexpr bool kFactored = true;
+  uint32_t (&ad)[NA];
+  const double (&th)[4];
+  const double (&cv)[VAR ? 4 : 1];
+  double acc[8];
+  double accv[VAR ? 8 : 1];
+  double q, t, t2;
+  template <int RR>
+  __device__ __forceinline__ void row() {}
+  template <int RR>
+  __device__ __forceinline__ void prefix(double qv) {
+    q = qv;
+  }
+  template <int RR, int UNIT>
+  __device__ __forceinline__ void leaf(double g) {
+    t = UNIT == 0 ? g * th[0] : fma(g, th[UNIT], t);
+    if constexpr (VAR) {
+      const double gg = g * g;
+      t2 = UNIT == 0 ? gg * cv[0] : fma(gg, cv[UNIT], t2);
+    }
+    if constexpr (UNIT == 3) {
+      acc[RR] = fma(q, t, acc[RR]);
+      if constexpr (VAR) accv[RR] = fma(q * q, t2, accv[RR]);
+    }
+  }
+};
+
+// 8 accumulators x 64 lanes -> tile rows rc .. rc + 7 of redw[.]
+__device__ __forceinline__ void st_reduce8(const double (&acc)[8], double *__restrict__ redw, int rc, int lane) {
+  double s4[4], s2[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s4[i] = swap32_sum(acc[i], acc[i + 4]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) s2[i] = swap16_sum(s4[i], s4[i + 2]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    double v = row16_ror_add<8>(s2[i]);
+    v = row16_ror_add<4>(v);
+    v = row16_ror_add<2>(v);
+    v = row16_ror_add<1>(v);
+    if ((lane & 15) == 0) redw[rc + i + 2 * (lane >> 4)] = v;
+  }
+}
+
+template <int W2, int K, bool VAR>
+__global__ void __launch_bounds__(kStWaves * 64, 4)
+k_star_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka, const double *__restrict__ kb,
+               const double *__restrict__ kc, const double *__restrict__ rot, const double *__restrict__ tab,
+               const int *__restrict__ cpos, int d, int Mu, const uint32_t *__restrict__ shcols,
+               const uint32_t *__restrict__ shterm, const uint32_t *__restrict__ shshape, int nswf,
+               const uint32_t *__restrict__ left_term, const uint32_t *__restrict__ left_colsw, int nleft, int p,
+               const double *__restrict__ theta, const double *__restrict__ coeffvar, double e2sigma,
+               const double *__restrict__ x, uint64_t n, uint64_t ntiles, uint64_t tiles_per_split,
+               double *__restrict__ mean, double *__restrict__ var) {
+  extern __shared__ double lds[];
+  constexpr int W = 2 * W2, NA = 4 * W, WAVES = kStWaves;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *red = lds + (size_t)Mu * kTlPitch;         // [WAVES][65] mean partials
+  double *redv = red + WAVES * kStRedPitch;           // [WAVES][65] variance partials
+  double *reds = redv + WAVES * kStRedPitch;          // [WAVES][65] basescale partials
+  double *la = reds + WAVES * kStRedPitch;            // [nleft] theta of the left-over terms
+  double *lcv = la + kStLeftMax;                      // [nleft] coeffvar
+  uint32_t *lad = (uint32_t *)(lcv + kStLeftMax);     // [nleft][W] column offsets (doubles)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
+  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
+  const uint64_t t1 = min(ntiles, t0 + tiles_per_split);
+
+  const uint64_t sg = (uint64_t)wave * 64 + lane;
+  const bool live = wave < nswf;
+  uint32_t ad[NA];
+  double th[4], cv[VAR ? 4 : 1];
+#pragma unroll
+  for (int i = 0; i < NA / 2; ++i) {
+    const uint32_t cw = live ? shcols[sg * (NA / 2) + i] : 0u;
+    ad[2 * i] = lds0 + (cw & 0xffffu) * (kTlPitch * 8);
+    ad[2 * i + 1] = lds0 + (cw >> 16) * (kTlPitch * 8);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t kt = live ? shterm[sg * 4 + u] : 0xffffffffu;
+    th[u] = kt < (uint32_t)p ? theta[kt] : 0.0;
+    if constexpr (VAR) cv[u] = kt < (uint32_t)p ? coeffvar[kt] : 0.0;
+  }
+  for (int j = threadIdx.x; j < nleft; j += WAVES * 64) {
+    const uint32_t kt = left_term[j];
+    la[j] = kt < (uint32_t)p ? theta[kt] : 0.0;
+    lcv[j] = VAR && kt < (uint32_t)p ? coeffvar[kt] : 0.0;
+  }
+  for (int i = threadIdx.x; i < nleft * W2; i += WAVES * 64) {
+    const uint32_t cw = left_colsw[i];
+    lad[2 * i] = (cw & 0xffffu) * kTlPitch;
+    lad[2 * i + 1] = (cw >> 16) * kTlPitch;
+  }
+  const uint32_t shape = live ? (uint32_t)__builtin_amdgcn_readfirstlane((int)shshape[wave]) : (1u | (1u << 8));
+  for (int i = threadIdx.x; i < 2 * WAVES * kStRedPitch; i += WAVES * 64) red[i] = 0.0;  // red, redv: absent waves
+
+  const StoreLdsPitch store{lds, cpos, lane};
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    __syncthreads();  // the previous tile's middle step is through with the tile and the partials
+    {  // basis at the new rows, lane = row
+      const uint64_t row = tile * kTileRows + lane;
+      const bool valid = row < n;
+      double sc = 1.0;
+      for (int l = wave; l < d; l += WAVES) {
+        const DimDesc D = dims[l];
+        const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
+        sc *= build_dim_any(D, ka, kb, kc, rot, tab, xv, store);
+      }
+      if (wave == 0) lds[lane] = 1.0;  // used column 0 = all ones
+      reds[wave * kStRedPitch + lane] = sc;
+    }
+    __syncthreads();  // tile built
+    if (live) {
+      StP<NA, VAR> c{ad, th, cv, {}, {}, 1.0, 0.0, 0.0};
+#pragma unroll 1
+      for (int rc = 0; rc < kTileRows; rc += 8) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          c.acc[r] = 0.0;
+          if constexpr (VAR) c.accv[r] = 0.0;
+        }
+        tl_star_run<W, 8, K>(c, shape);
+        const int32_t step = rc + 8 < kTileRows ? 8 * 8 : -(kTileRows - 8) * 8;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          ad[i] += (uint32_t)step;
+          asm volatile("" : "+v"(ad[i]));
+        }
+        st_reduce8(c.acc, red + wave * kStRedPitch, rc, lane);
+        if constexpr (VAR) st_reduce8(c.accv, redv + wave * kStRedPitch, rc, lane);
+      }
+    }
+    __syncthreads();  // every wave's row sums are in red / redv
+    {  // middle: lane = (row, part); wave w takes rows 4 w .. 4 w + 3
+      const int row = 4 * wave + (lane >> 4), prt = lane & 15;
+      const double *tb = lds + row;
+      double t = red[prt * kStRedPitch + row];
+      double tv = VAR ? redv[prt * kStRedPitch + row] : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < kStNL; ++jj) {
+        const int j = jj * 16 + prt;
+        if (jj * 16 < nleft && j < nleft) {
+          double v = 1.0;
+#pragma unroll
+          for (int e = 0; e < W; ++e) v *= tb[lad[j * W + e]];
+          t = fma(la[j], v, t);
+          if (VAR) tv = fma(lcv[j], v * v, tv);
+        }
+        if (jj % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+      }
+      double s = reds[prt * kStRedPitch + row];  // the 16 waves' basescale factors of the row
+      t = row16_ror_add<8>(t);
+      t = row16_ror_add<4>(t);
+      t = row16_ror_add<2>(t);
+      t = row16_ror_add<1>(t);
+      if (VAR) {
+        tv = row16_ror_add<8>(tv);
+        tv = row16_ror_add<4>(tv);
+        tv = row16_ror_add<2>(tv);
+        tv = row16_ror_add<1>(tv);
+      }
+      // product over the 16 lanes of the row (waves beyond the dimensions hold 1)
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) s *= __shfl_xor(s, off, 64);
+      const uint64_t grow = tile * kTileRows + row;
+      if (prt == 0 && grow < n) {
+        mean[grow] = t * s;
+        if (VAR) var[grow] = tv * (s * s) + e2sigma;  // loglik_gauss.cpp:224-225
+      }
+    }
+  }
+}
+
 }  // namespace
 
 size_t star_lds_bytes(const obhip_terms &t) {
@@ -551,6 +735,49 @@ StArgs star_args(const obhip_basis &b, const obhip_terms &t, uint64_t ntiles, ui
   return A;
 }
 }  // namespace
+
+size_t star_predict_lds_bytes(const obhip_terms &t) {
+  return ((size_t)t.Mu * kTlPitch + 3 * kStWaves * kStRedPitch + 2 * kStLeftMax) * sizeof(double) +
+         (size_t)kStLeftMax * t.W * sizeof(uint32_t);
+}
+// the fused predictor takes: all family stars in one workgroup (9 .. 16 star-waves)
+bool star_predict_supports(const obhip_terms &t) {
+  const int w2 = (int)(t.W / 2);
+  return share_wanted() && t.sh.ok && w2 >= 1 && w2 <= 3 && t.sh.nsw_family >= 9 && t.sh.nsw_family <= 16 &&
+         t.sh.nleft <= (uint64_t)kStLeftMax && star_predict_lds_bytes(t) <= (size_t)156 * 1024;
+}
+int launch_star_predict(const obhip_model &m, obhip_terms &t, const double *d_theta, const double *d_x, uint64_t n,
+                        double *d_mean, const double *d_coeffvar, double e2sigma, double *d_var) {
+  const size_t lds = star_predict_lds_bytes(t);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t ntiles = (n + kTileRows - 1) / kTileRows;
+  uint64_t nsplit = std::min<uint64_t>(ntiles, (uint64_t)device_cus(dev));
+  const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  const bool wv = d_coeffvar != nullptr && d_var != nullptr;
+#define OB_SP(W2_, K_, VAR_)                                                                                  \
+  do {                                                                                                        \
+    OB_TRY(ensure_dyn_lds((const void *)k_star_predict<W2_, K_, VAR_>, lds));                                 \
+    hipLaunchKernelGGL((k_star_predict<W2_, K_, VAR_>), dim3((unsigned)nsplit), dim3(kStWaves * 64), lds,     \
+                       cur_stream(), t.pred_md.dims.p, t.pred_md.ka.p, t.pred_md.kb.p, t.pred_md.kc.p,        \
+                       t.pred_md.rot.p, t.pred_md.tab.p, t.cpos.p, (int)m.d, (int)t.Mu,                       \
+                       (const uint32_t *)t.sh_cols.p, t.sh_term.p, t.sh_shape.p, (int)t.sh.nsw_family,        \
+                       t.sh_left_term.p, (const uint32_t *)t.sh_left_cols.p, (int)t.sh.nleft, (int)t.p,       \
+                       d_theta, d_coeffvar, e2sigma, d_x, n, ntiles, tps, d_mean, d_var);                     \
+  } while (0)
+  switch ((int)(t.W / 2) * 2 + (wv ? 1 : 0)) {
+    case 2: OB_SP(1, 12, false); break;
+    case 3: OB_SP(1, 12, true); break;
+    case 4: OB_SP(2, 12, false); break;
+    case 5: OB_SP(2, 10, true); break;
+    case 6: OB_SP(3, 10, false); break;
+    default: OB_SP(3, 8, true); break;
+  }
+#undef OB_SP
+  OB_HIP(hipGetLastError());
+  return 0;
+}
 
 // B^T (c_a B a + c_b y): d_y null = the Hessian product
 int launch_star_hess(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y, double ca,

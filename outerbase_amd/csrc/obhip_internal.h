@@ -277,6 +277,7 @@ struct obhip_terms {
   uint64_t p_pad = 0;
   // star tables (shared sub-products, csrc/share.cpp); sh.ok false: the kernels take sperm / cols
   obhip::ShareTables sh;              // (host copies dropped after the upload; counts kept)
+  bool no_share = false;              // views of another term set (gradient passes): no star tables
   obhip::DevBuf<uint16_t> sh_cols;    // nstars x 4 W
   obhip::DevBuf<uint32_t> sh_term;    // nstars x 4
   obhip::DevBuf<uint32_t> sh_shape;   // nstars / 64
