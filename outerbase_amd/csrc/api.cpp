@@ -344,7 +344,7 @@ int obhip_fit_newton(const obhip_basis *b, const obhip_terms *t, const obhip_mod
 namespace {
 
 constexpr int kCgThreads = 1024;
-enum { S_VAL = 0, S_VALDIFF, S_NUM, S_DENOM, S_ALPHA, S_DONE, S_NEXT, S_NUM0, S_GP, S_FINITE, S_VALO, S_COUNT = 16 };
+enum { S_VAL = 0, S_VALDIFF, S_NUM, S_DENOM, S_ALPHA, S_DONE, S_NEXT, S_NUM0, S_GP, S_FINITE, S_VALO, S_ITERS, S_COUNT = 16 };
 
 struct CgVecs {
   double *theta, *grad, *rm, *pv, *q, *mdiag;
@@ -413,6 +413,7 @@ k_cg_init(CgVecs v, const double *__restrict__ sq, double e2, double *__restrict
     scal[S_NUM0] = -1.0;
     scal[S_DONE] = 0.0;
     scal[S_NEXT] = 0.0;
+    scal[S_ITERS] = 0.0;
   }
 }
 
@@ -431,6 +432,9 @@ __global__ void __launch_bounds__(kCgThreads)
 k_cg_iter(CgVecs v, double tol, double *__restrict__ scal) {
   __shared__ double red[3 * kCgThreads / 64];
   __shared__ double sh[4];
+  // the loop has ended (a launch enqueued ahead of the host's look at the break conditions: the
+  // batched form of fit_cg_dev_impl): nothing to do
+  if (PART != 2 && (scal[S_DONE] != 0.0 || scal[S_NEXT] != 0.0)) return;
   if (PART != 2) {
     double d[3] = {0.0, 0.0, 0.0};  // num = grad . rm, denom = q . pv, gp = grad . pv
     for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) {
@@ -462,6 +466,7 @@ k_cg_iter(CgVecs v, double tol, double *__restrict__ scal) {
     }
     __syncthreads();
     if (sh[0] != 0.0) return;
+    if (threadIdx.x == 0) scal[S_ITERS] += 1.0;  // steps made (the host's k when it enqueues ahead)
     const double alpha = sh[1];
     for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) v.theta[k] = fma(alpha, v.pv[k], v.theta[k]);
     if (PART == 1) return;
@@ -628,7 +633,20 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
     const char *re = getenv("OBHIP_CG_REFRESH");
     const uint64_t refresh = re ? (uint64_t)std::max(1, atoi(re)) : 16;
     bool exact = true;  // grad / val come from update(), not from the recurrence
-    for (k = 0; k < maxit; ++k) {  // fit.cpp:71-85
+    // Small problems (the reference's own scale: n = 1000, p = 256 takes ~40 us of kernels per
+    // iteration and ~90 us for the host to read the five scalars back): `batch` iterations are
+    // enqueued before the host looks -- every kernel of an iteration returns at once when an earlier
+    // one ended the loop (k_cg_iter's guard, the stop flags of the Hessian product), the device
+    // counts the steps made (S_ITERS).  Same iterates, same iteration count, a fraction of the
+    // host round trips.  OBHIP_CG_BATCH sets the batch (1 = off); default 8 below 2^22 rows x terms.
+    const char *be = getenv("OBHIP_CG_BATCH");
+    const uint64_t batch = be ? (uint64_t)std::max(1, atoi(be))
+                              : ((double)b->n_pad * (double)t.p_pad <= 4194304.0 ? 8 : 1);
+    const bool batched = batch > 1 && can_spec && !many;
+    // one iteration with the host in the loop; returns kStop when the loop ends (k then counts the
+    // iterations made), 0 to go on, an error code otherwise
+    constexpr int kStop = -100;
+    auto iteration = [&]() -> int {  // fit.cpp:71-85
       const bool full = (k + 1) % refresh == 0;
       if (full)
         hipLaunchKernelGGL(k_cg_iter<1>, dim3(1), dim3(kCgThreads), 0, st, v, tol, scal.p);
@@ -637,7 +655,7 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
       OB_HIP(hipGetLastError());
       if (full) {  // the break conditions come first: a converged iterate takes no update()
         OB_TRY(d2h(hs, scal.p, (S_NEXT + 1) * sizeof(double)));
-        if (hs[S_DONE] != 0.0) break;
+        if (hs[S_DONE] != 0.0) return kStop;
         OB_TRY(update());
         hipLaunchKernelGGL(k_cg_iter<2>, dim3(1), dim3(kCgThreads), 0, st, v, tol, scal.p);
         OB_HIP(hipGetLastError());
@@ -645,13 +663,36 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
       const bool spec = can_spec && !full;
       if (spec) OB_TRY(hessmult(true));
       OB_TRY(d2h(hs, scal.p, (S_NEXT + 1) * sizeof(double)));  // the host sync of an iteration
-      if (hs[S_DONE] != 0.0) break;
+      if (hs[S_DONE] != 0.0) return kStop;
       exact = full;
-      if (hs[S_NEXT] != 0.0) {  // the next iteration would stop at once: k + 1 iterations made,
-        ++k;                    // and its Hessian product is not needed
-        break;
-      }
+      ++k;
+      if (hs[S_NEXT] != 0.0) return kStop;  // the next iteration would stop at once: its Hessian product is not needed
       if (!spec) OB_TRY(hessmult());
+      return 0;
+    };
+    for (k = 0; k < maxit;) {
+      if (batched && (k + 1) % refresh != 0) {
+        // up to `batch` plain iterations, never across a refresh iteration (that one keeps the
+        // host in the loop)
+        uint64_t nb = 0;
+        while (nb < batch && k + nb < maxit && (k + nb + 1) % refresh != 0) {
+          hipLaunchKernelGGL(k_cg_iter<0>, dim3(1), dim3(kCgThreads), 0, st, v, tol, scal.p);
+          OB_HIP(hipGetLastError());
+          OB_TRY(hessmult(true));
+          ++nb;
+        }
+        OB_TRY(d2h(hs, scal.p, (S_ITERS + 1) * sizeof(double)));  // ONE host sync per batch
+        exact = false;
+        if (hs[S_DONE] != 0.0 || hs[S_NEXT] != 0.0) {
+          k = (uint64_t)hs[S_ITERS];
+          break;
+        }
+        k += nb;
+        continue;
+      }
+      const int rc = iteration();
+      if (rc == kStop) break;
+      if (rc != 0) return rc;
     }
     // the value reported is a true evaluation (callers that re-evaluate anyway pass
     // val_out = NULL and save the two passes)
