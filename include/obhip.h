@@ -193,13 +193,15 @@ int obhip_terms_maxlevels(const obhip_terms *t, int64_t *levels);
  * four free members are *left over* (any term set is accepted; one that is not downward-closed
  * just leaves more over): they are listed, and also packed four at a time into plain stars
  * (nothing shared) behind the family stars.  Stars come in star-waves of 64, filled up with empty
- * stars.  info (10 entries):
+ * stars.  info (11 entries):
  *   [0] p_pad, [1] left-over terms, [2] column reads per row of the family star-waves (sum of
  *   P + 4), [3] of the scheme without sharing (4 terms per lane, terms by falling number of
  *   factors: rounds 1-4), [4] W, the column slots per term, [5] LDS cycles of all star-waves' reads
  *   with their bank conflicts (2 per read at best; column u of the [column][65] tile lies in bank
  *   pair u mod 32), [6] the same before the search over the stars' half-waves and term orders that
- *   minimises them, [7] family star-waves, [8] plain star-waves, [9] reads per row of the latter.
+ *   minimises them, [7] family star-waves, [8] plain star-waves, [9] reads per row of the latter, [10] the LDS
+ *   cycles of [5] once the library has also chosen which tile index (bank pair) every used column
+ *   gets -- what it uploads; the tables returned here keep the level-based ids (11 entries).
  * With S = 64 ([7] + [8]) stars in all -- S <= p_pad / 4 + 128 -- the optional outputs are:
  * term (4 S entries): the four term indices of star 0, of star 1, ... (0xffffffff: none);
  * shape ([7] + [8] entries): per star-wave P | S << 8 (family star-waves first: S = 1);

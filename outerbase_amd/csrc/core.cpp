@@ -362,6 +362,18 @@ int obhip_terms::prepare(const std::vector<int64_t> &cap,
       if (t > 0) hc[k * W + w++] = pos[(uint32_t)(dims[l].ccol0 + t - 1)];
     }
   }
+  // shared sub-products: stars of four terms that differ in one factor (share.cpp).  The star
+  // layout also picks the tile index of every used column (its LDS bank pair): `used` and the
+  // column lists above are renumbered to match before anything is uploaded.
+  sh = obhip::ShareTables();
+  if (!no_share) OB_TRY(obhip::build_share_tables(hc.data(), p_pad, W, sh, true, used.size()));
+  if (sh.ok) {
+    if (sh.relabel.size() != used.size()) return fail(OBHIP_ERR_STATE, "share tables: column count");
+    std::vector<uint32_t> used2(used.size());
+    for (size_t u = 0; u < used.size(); ++u) used2[sh.relabel[u]] = used[u];
+    used.swap(used2);
+    for (uint16_t &c : hc) c = sh.relabel[c];
+  }
   OB_TRY(cols.upload(hc.data(), hc.size()));
   // Slot order of the term-per-lane kernels: by falling number of factors, so that the 64 x NU
   // consecutive slots a wave owns hold terms of (nearly) one length and the wave reads only
@@ -375,9 +387,6 @@ int obhip_terms::prepare(const std::vector<int64_t> &cap,
                      [&](uint32_t a, uint32_t b) { return nz[a] > nz[b]; });
     OB_TRY(sperm.upload(order.data(), order.size()));
   }
-  // shared sub-products: stars of four terms that differ in one factor (share.cpp)
-  sh = obhip::ShareTables();
-  if (!no_share) OB_TRY(obhip::build_share_tables(hc.data(), p_pad, W, sh));
   if (sh.ok) {
     OB_TRY(sh_cols.upload(sh.cols.data(), sh.cols.size()));
     OB_TRY(sh_term.upload(sh.term.data(), sh.term.size()));
@@ -609,6 +618,11 @@ int obhip_terms_share_tables(const obhip_terms *t, uint64_t *info, uint32_t *ter
   info[7] = sh.nsw_family;
   info[8] = sh.nsw_plain;
   info[9] = sh.reads_left;
+  {  // ... and with the library's choice of the columns' tile indices (what obhip_terms::prepare uploads)
+    obhip::ShareTables sh2;
+    OB_TRY(obhip::build_share_tables(hc.data(), p_pad, W, sh2, true, off[t->d]));
+    info[10] = sh2.lds_cycles;
+  }
   if (term) std::copy(sh.term.begin(), sh.term.end(), term);
   if (shape) std::copy(sh.shape.begin(), sh.shape.end(), shape);
   if (factor) std::copy(sh.cols.begin(), sh.cols.end(), factor);

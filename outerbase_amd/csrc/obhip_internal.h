@@ -255,8 +255,10 @@ struct ShareTables {
   std::vector<uint32_t> shape;  // per star-wave: P | S << 8
   std::vector<uint32_t> left_term;  // nleft term indices
   std::vector<uint16_t> left_cols;  // nleft x W used-column indices, right-aligned (0 = ones)
+  std::vector<uint16_t> relabel;    // used-column index the caller passed -> index the tables are written in
 };
-int build_share_tables(const uint16_t *hc, uint64_t p_pad, uint64_t W, ShareTables &out);
+int build_share_tables(const uint16_t *hc, uint64_t p_pad, uint64_t W, ShareTables &out, bool renumber = false,
+                       uint64_t ncol = 0);
 bool share_wanted();  // OBHIP_SHARE=0: the kernels take the plain tables (A/B measurements)
 }  // namespace obhip
 

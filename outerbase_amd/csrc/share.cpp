@@ -72,6 +72,7 @@ struct Layout {
   std::vector<Star> *stars;
   std::vector<int> wP, wS;          // shape per star-wave
   std::vector<uint16_t> sc;         // nst x 4 W: col(i, j) of the current arrangement (refresh)
+  std::vector<uint16_t> relabel;    // column -> the index it gets in the LDS tile (its bank pair: & 31)
   void refresh(uint64_t i) {
     for (int j = 0; j < slots(i / 64); ++j) sc[i * 4 * W + j] = col(i, j);
   }
@@ -111,7 +112,7 @@ struct Layout {
     int worst = 1;
     for (uint64_t i = 32 * h; i < 32 * h + 32; ++i) {
       const uint16_t c = sc[i * 4 * W + j];
-      const int b = c & 31;
+      const int b = relabel[c] & 31;
       bool dup = false;
       for (int k = 0; k < cnt[b] && k < 8; ++k) dup = dup || seen[b][k] == c;
       if (dup) continue;
@@ -131,6 +132,65 @@ uint64_t layout_cost(const Layout &L) {
   uint64_t t = 0;
   for (uint64_t h = 0; h < L.nst / 32; ++h) t += (uint64_t)L.half_cost(h);
   return t;
+}
+
+// Which tile index (hence bank pair) a column gets is the library's choice too: columns that are
+// read by different lanes of one half-wave in one slot should sit on different bank pairs.  From
+// the arrangement at hand: cooc[c][c'] = number of (half-wave, slot) reads in which both occur;
+// columns by falling weight, each to the bank pair with room left where it meets the least
+// co-occurrence (indices 1 .. ncol - 1 are dealt in order to the 32 bank pairs; 0, the ones column,
+// stays).
+void renumber_columns(Layout &L, uint64_t ncol) {
+  std::vector<uint32_t> cooc(ncol * ncol, 0);
+  std::vector<uint16_t> seen;
+  for (uint64_t h = 0; h < L.nst / 32; ++h)
+    for (int j = 0; j < L.slots(h / 2); ++j) {
+      seen.clear();
+      for (uint64_t i = 32 * h; i < 32 * h + 32; ++i) {
+        const uint16_t c = L.sc[i * 4 * L.W + j];
+        if (std::find(seen.begin(), seen.end(), c) == seen.end()) seen.push_back(c);
+      }
+      for (size_t a = 0; a < seen.size(); ++a)
+        for (size_t b = a + 1; b < seen.size(); ++b) {
+          cooc[(size_t)seen[a] * ncol + seen[b]] += 1;
+          cooc[(size_t)seen[b] * ncol + seen[a]] += 1;
+        }
+    }
+  std::vector<uint64_t> weight(ncol, 0);
+  for (uint64_t c = 0; c < ncol; ++c)
+    for (uint64_t e = 0; e < ncol; ++e) weight[c] += cooc[c * ncol + e];
+  std::vector<uint32_t> order;
+  for (uint64_t c = 1; c < ncol; ++c) order.push_back((uint32_t)c);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+  int cap[32];
+  for (int b = 0; b < 32; ++b) cap[b] = 0;
+  for (uint64_t l = 1; l < ncol; ++l) cap[l & 31] += 1;
+  std::vector<std::vector<uint32_t>> members(32);
+  members[0].push_back(0);  // the ones column
+  for (uint32_t c : order) {
+    int best = -1;
+    uint64_t bestcost = 0;
+    for (int b = 0; b < 32; ++b) {
+      if (cap[b] == 0) continue;
+      uint64_t cost = 0;
+      for (uint32_t e : members[b]) cost += cooc[(size_t)c * ncol + e];
+      if (best < 0 || cost < bestcost || (cost == bestcost && cap[b] > cap[best])) {
+        best = b;
+        bestcost = cost;
+      }
+    }
+    members[best].push_back(c);
+    cap[best] -= 1;
+  }
+  L.relabel.assign(ncol, 0);
+  for (int b = 0; b < 32; ++b) {
+    uint32_t next = b == 0 ? 32 : (uint32_t)b;  // (index 0 is taken by the ones column)
+    for (uint32_t c : members[b]) {
+      if (c == 0) continue;
+      L.relabel[c] = (uint16_t)next;
+      next += 32;
+    }
+  }
 }
 
 void reduce_conflicts(Layout &L) {
@@ -196,7 +256,10 @@ bool share_wanted() {
 }
 
 // hc: p_pad x W used-column indices per term (0 = the ones column; obhip_terms::prepare's table)
-int build_share_tables(const uint16_t *hc, uint64_t p_pad, uint64_t W, ShareTables &out) {
+// renumber: also choose the columns' indices (out.relabel: old -> new; the tables are written in
+// the new indices, the caller renumbers its own column lists)
+int build_share_tables(const uint16_t *hc, uint64_t p_pad, uint64_t W, ShareTables &out, bool renumber,
+                       uint64_t ncol_in) {
   out = ShareTables();
   if (p_pad == 0 || p_pad % 256 != 0 || W < 2 || W > 8 || W % 2) return 0;  // (not shareable: ok stays false)
   std::vector<Key> fac(p_pad);
@@ -282,7 +345,7 @@ int build_share_tables(const uint16_t *hc, uint64_t p_pad, uint64_t W, ShareTabl
   out.left_cols.assign(rest.size() * W, 0);
   for (size_t i = 0; i < rest.size(); ++i) {
     const Key &f = fac[rest[i]];
-    for (size_t e = 0; e < f.size(); ++e) out.left_cols[i * W + (W - f.size()) + e] = f[e];
+    for (size_t e = 0; e < f.size(); ++e) out.left_cols[i * W + (W - f.size()) + e] = f[e];  // (relabelled below)
   }
   // family stars by falling number of reads, equal shapes by shared part (the lanes of a wave then
   // read the same shared columns: LDS broadcasts); star-waves filled up with empty stars of
@@ -341,16 +404,28 @@ int build_share_tables(const uint16_t *hc, uint64_t p_pad, uint64_t W, ShareTabl
     (plain ? out.reads_left : out.reads) += (uint64_t)(L.wP[w] + 4 * L.wS[w]);
   }
   // which half-wave a star sits in and the order of its terms: fewest LDS bank conflicts
+  uint64_t ncol = std::max<uint64_t>(1, ncol_in);  // (the caller's column count, or what the terms use)
+  for (uint64_t k = 0; k < p_pad; ++k)
+    for (uint16_t c : fac[k]) ncol = std::max<uint64_t>(ncol, (uint64_t)c + 1);
+  L.relabel.resize(ncol);
+  for (uint64_t c = 0; c < ncol; ++c) L.relabel[c] = (uint16_t)c;
   L.sc.assign(nst * NA, 0);
   for (uint64_t i = 0; i < nst; ++i) L.refresh(i);
   out.lds_cycles0 = layout_cost(L);
   reduce_conflicts(L);
+  // ... and which bank pair a column lies on (the caller renumbers its used columns accordingly),
+  // then the arrangement once more for the new banks
+  if (renumber) {
+    renumber_columns(L, ncol);
+    reduce_conflicts(L);
+  }
   out.lds_cycles = layout_cost(L);
+  out.relabel = L.relabel;
   // ad[0 .. P): the shared factors, right-aligned (ones in front); ad[P + j S .. P + (j + 1) S):
   // term j's own factor(s), right-aligned, ascending
   for (uint64_t i = 0; i < nst; ++i) {
     for (int j = 0; j < 4; ++j) out.term[i * 4 + j] = stars[i].term[j] < p_pad ? stars[i].term[j] : 0xffffffffu;
-    for (int j = 0; j < L.slots(i / 64); ++j) out.cols[i * NA + j] = L.sc[i * NA + j];
+    for (int j = 0; j < L.slots(i / 64); ++j) out.cols[i * NA + j] = L.relabel[L.sc[i * NA + j]];
   }
   // what the nnz-sorted plain scheme of rounds 1-4 issues at 4 terms per lane (for the record)
   {
@@ -365,6 +440,7 @@ int build_share_tables(const uint16_t *hc, uint64_t p_pad, uint64_t W, ShareTabl
       out.reads_plain += 2 * std::max(a, lo) + 2 * std::max(b, lo);
     }
   }
+  for (uint16_t &c : out.left_cols) c = L.relabel[c];
   out.nstars = nst;
   out.ok = true;
   return 0;

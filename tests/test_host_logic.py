@@ -417,9 +417,9 @@ def _check_star_tables(om_d, terms):
     import outerbase_amd as ob
     from outerbase_amd._lib import call, ptr
     tt = ob.obmod._Terms(om_d, terms)
-    info = np.zeros(10, dtype=np.uint64)
+    info = np.zeros(11, dtype=np.uint64)
     call("obhip_terms_share_tables", tt._h, ptr(info), None, None, None, None)
-    p_pad, nleft, reads, reads_plain, W, lds_cyc, lds_cyc0, nswf, nswp, reads_left = (int(v) for v in info)
+    p_pad, nleft, reads, reads_plain, W, lds_cyc, lds_cyc0, nswf, nswp, reads_left, lds_cyc_re = (int(v) for v in info)
     p, d = terms.shape
     assert p_pad == (p + 255) // 256 * 256 and W == max(2, ((terms > 0).sum(1).max() + 1) // 2 * 2)
     nst = 64 * (nswf + nswp)
@@ -463,7 +463,7 @@ def _check_star_tables(om_d, terms):
         else:
             tot_left += c
     assert tot == reads and tot_left == reads_left
-    assert 2 * (reads + reads_left) <= lds_cyc <= lds_cyc0
+    assert 2 * (reads + reads_left) <= lds_cyc <= lds_cyc0 and 2 * (reads + reads_left) <= lds_cyc_re <= lds_cyc0
     return nleft, reads, reads_plain
 
 

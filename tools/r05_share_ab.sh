@@ -23,6 +23,6 @@ hm() {
   echo "== hm_bench $1 ($2)" >> $out
   env $1 python tools/hm_bench.py $2 >> $out 2>> gpurun_out/r05/share_ab.err || return 1
 }
-run "OBHIP_SHARE=0" && run "OBHIP_HM3=1" && run "OBHIP_SHARE=0" && run "OBHIP_HM3=1" && \
+run "OBHIP_SHARE=0" && run "OBHIP_HM3=1" && run "OBHIP_HM3=1" && \
 hm "OBHIP_SHARE=0" "1000000 4096 8 mat25pow 12" && hm "OBHIP_HM3=1" "1000000 4096 8 mat25pow 12"
 cat $out
