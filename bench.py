@@ -436,7 +436,7 @@ def kernel_profile(hp, _lib, torch, nprof=2):
     return prof
 
 
-def secondary_rooflines(hp, prof):
+def secondary_rooflines(hp, prof, _lib, np):
     """Achieved fractions of the kernels beside the Gram, from the live hipEvent averages and
     the algorithmic bytes / flops of DESIGN.md section 4 (per point: build reads 8 d and
     writes 8 (Mc + 1); a product pass reads 8 (Mc + 1) + 8; the design-matrix copy writes 8 p;
@@ -444,6 +444,14 @@ def secondary_rooflines(hp, prof):
     n, p, d, Mc = float(hp.n), float(hp.p), float(hp.d), float(hp.ncols)
     nnz = float(hp.terms_info["nnz_total"])
     out = {}
+    # shared sub-products (csrc/share.cpp): what the star kernels read per row -- wave instructions
+    # of 64 lanes x 8 bytes -- when the term set is in their domain (9 .. 16 family star-waves for
+    # the one-workgroup kernels, few left-over terms)
+    info = np.zeros(11, dtype=np.uint64)
+    _lib.call("obhip_terms_share_tables", hp.t._h, info.ctypes.data, None, None, None, None)
+    star = 9 <= int(info[7]) and int(info[1]) <= 192 and \
+        os.environ.get("OBHIP_SHARE", "1") != "0" and os.environ.get("OBHIP_HM3", "1") != "0"
+    star_reads = float(info[2] + info[9])      # family star-waves + the plain star-wave's worth of left-over terms
 
     def hbm(name, kernel, byts, extra=None):
         if name not in prof:
@@ -455,20 +463,27 @@ def secondary_rooflines(hp, prof):
             e.update(extra(ms))
         out[name] = e
 
-    def lds(ms):
+    def lds(ms, passes=1.0):
+        if star:
+            b = 512.0 * n * star_reads * passes
+            return {"lds_GBs": b / ms / 1e6, "lds_frac": b / ms / 1e6 / LDS_PEAK_GBS,
+                    "lds_reads_per_row": star_reads * passes, "lds_reads_per_row_unshared": float(info[3]),
+                    "bound": "LDS read latency / VALU issue (neither pipe saturated: profiles/r05_pmc_products.txt)"}
         b = 8.0 * n * nnz
         return {"lds_GBs": b / ms / 1e6, "lds_frac": b / ms / 1e6 / LDS_PEAK_GBS,
                 "bound": "lds (term-per-lane column reads)"}
     hbm("build_basis", "k_build_basis", n * 8 * (d + Mc + 1),
         lambda ms: {"bound": "latency (bisection + table reads per dimension; interval tables in LDS)"})
     hbm("materialize_B", "k_materialize_tl", n * 8 * (Mc + 1 + p), lambda ms: {"bound": "hbm write"})
-    hbm("tmm", "k_tmm_tl", n * 8 * (Mc + 2), lds)
-    hbm("mm", "k_mm_tl", n * 8 * (Mc + 2), lds)
-    # the PCG's fused Hessian product / update() pass: one read of the basis, ONE set of column
-    # reads (the two-kernel form makes two)
-    hbm("hessmult", "k_hm2 (k_hm_tl for terms it does not take)", n * 8 * (Mc + 2), lds)
-    hbm("tmm_dual", "k_tmm_tl<DUAL>", n * 8 * (Mc + 2), lds)
-    hbm("predict", "k_predict_tl", n * 8 * (d + 1), lds)
+    one_wg = star and int(info[7]) <= 16
+    hbm("tmm", "k_star<OP_TMM>" if star else "k_tmm_tl", n * 8 * (Mc + 2), lds)
+    hbm("mm", "k_star<OP_MM>" if star else "k_mm_tl", n * 8 * (Mc + 2), lds)
+    # the PCG's fused Hessian product / update() pass: one read of the basis; k_star forms every
+    # product twice (phase A, phase B), k_hm2 once
+    hbm("hessmult", "k_star<OP_HESS / OP_UPDATE>" if one_wg else "k_hm2 (k_hm_tl for terms it does not take)",
+        n * 8 * (Mc + 2), (lambda ms: lds(ms, 2.0)) if one_wg else lds)
+    hbm("tmm_dual", "k_star<OP_TMM, DUAL>" if star else "k_tmm_tl<DUAL>", n * 8 * (Mc + 2), lds)
+    hbm("predict", "k_star_predict" if one_wg else "k_predict_tl", n * 8 * (d + 1), lds)
     if "cholesky" in prof:
         ms = prof["cholesky"]["avg_ms"]
         fl = p ** 3 / 3.0
@@ -935,7 +950,7 @@ def main():
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                            "avg_launch_ms": prof["mm"]["avg_ms"],
                            "note": "LDS-bound kernel, see roofline_secondary"}
-    out["roofline_secondary"] = secondary_rooflines(hp, prof)
+    out["roofline_secondary"] = secondary_rooflines(hp, prof, _lib, np)
     if not args.no_cpu_baseline and world == 1:
         # the CPU leg: the oracle as the timed baseline (parity_check above is the other place
         # this file touches oracle/, as the checker of this very run)
