@@ -31,11 +31,16 @@ constexpr int kGT = 128;  // output tile edge (terms)
 // form then applies to the accumulated sum (last chunk only).
 __device__ __forceinline__ uint64_t tri_row(uint64_t i, uint64_t p) { return i * p - i * (i - 1) / 2; }
 
+// Grid: (tile pairs, 4 quadrants x 4 slices of 16 rows).  Until round 4 a workgroup walked the four
+// quadrants of its tile pair one after the other: 36 workgroups at p = 1024 (BASELINE configs[1]),
+// each a chain of 4 x 16 x nsplit dependent loads -- 0.22 ms for 67 MB.  Same sums in the same order
+// per element; only who computes them changed.
+constexpr int kRedRows = 16;  // rows of a quadrant per workgroup
 __global__ void __launch_bounds__(256)
 k_gram_reduce(const double *__restrict__ part, int npairs, int nsplit, int nb, int p,
               double *__restrict__ G, int acc, int packed, int form, double e2,
               const double *__restrict__ prec, double *__restrict__ diagH) {
-  __shared__ double S[64 * 65];  // one 64 x 64 quadrant, so that the mirror goes out in rows too
+  __shared__ double S[kRedRows * 65];  // the slice, so that the mirror goes out in row segments too
   int I = 0, rem = blockIdx.x;
   while (rem >= nb - I) {
     rem -= nb - I;
@@ -43,41 +48,41 @@ k_gram_reduce(const double *__restrict__ part, int npairs, int nsplit, int nb, i
   }
   const int J = I + rem;
   const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
-  for (int qd = 0; qd < 4; ++qd) {
-    const int qr = qd >> 1, qc = qd & 1;
-    if (I == J && qr > qc) continue;  // diagonal tiles: the lower-left quadrant is the mirror
-    const bool dq = I == J && qr == qc;  // quadrant on the diagonal of G
-    const int gi0 = I * kGT + qr * 64, gj0 = J * kGT + qc * 64;
-    // sum of the row-split partials, 64 consecutive doubles per wave load
-    for (int r = r4; r < 64; r += 4) {
-      const int e = (qr * 64 + r) * kGT + qc * 64 + c;
-      double s = 0.0;
+  const int qd = (int)blockIdx.y / (64 / kRedRows), r0 = ((int)blockIdx.y % (64 / kRedRows)) * kRedRows;
+  const int qr = qd >> 1, qc = qd & 1;
+  if (I == J && qr > qc) return;  // diagonal tiles: the lower-left quadrant is the mirror
+  const bool dq = I == J && qr == qc;  // quadrant on the diagonal of G
+  const int gi0 = I * kGT + qr * 64, gj0 = J * kGT + qc * 64;
+  // sum of the row-split partials, 64 consecutive doubles per wave load
+  for (int r = r0 + r4; r < r0 + kRedRows; r += 4) {
+    const int e = (qr * 64 + r) * kGT + qc * 64 + c;
+    double s = 0.0;
 #pragma unroll 8
-      for (int k = 0; k < nsplit; ++k) s += part[((uint64_t)k * npairs + blockIdx.x) * (kGT * kGT) + e];
-      const bool in = gi0 + r < p && gj0 + c < p;
-      if (in && !(dq && c < r)) {  // the entry (gi0 + r, gj0 + c), j >= i
-        const uint64_t i = (uint64_t)(gi0 + r), j = (uint64_t)(gj0 + c);
-        double *g = packed ? &G[tri_row(i, p) + (j - i)] : &G[i * p + j];
-        if (acc) s += *g;
-        if (form) {
-          s *= e2;
-          if (i == j) {
-            s += prec[i];
-            if (diagH) diagH[i] = s;
-          }
+    for (int k = 0; k < nsplit; ++k) s += part[((uint64_t)k * npairs + blockIdx.x) * (kGT * kGT) + e];
+    const bool in = gi0 + r < p && gj0 + c < p;
+    if (in && !(dq && c < r)) {  // the entry (gi0 + r, gj0 + c), j >= i
+      const uint64_t i = (uint64_t)(gi0 + r), j = (uint64_t)(gj0 + c);
+      double *g = packed ? &G[tri_row(i, p) + (j - i)] : &G[i * p + j];
+      if (acc) s += *g;
+      if (form) {
+        s *= e2;
+        if (i == j) {
+          s += prec[i];
+          if (diagH) diagH[i] = s;
         }
-        *g = s;
       }
-      S[r * 65 + c] = s;
+      *g = s;
     }
-    if (packed) continue;  // no mirror, and S is not read
-    __syncthreads();
-    for (int r = r4; r < 64; r += 4) {
-      // mirrored: G[gj0 + r][gi0 + c] = S[c][r], strictly below the diagonal of G only
-      if (gj0 + r < p && gi0 + c < p && !(dq && c >= r))
-        G[(uint64_t)(gj0 + r) * p + gi0 + c] = S[c * 65 + r];
-    }
-    __syncthreads();
+    S[(r - r0) * 65 + c] = s;
+  }
+  if (packed) return;  // no mirror, and S is not read
+  __syncthreads();
+  // mirrored: G[gj0 + r][gi0 + r0 + cc] = S[cc][r], strictly below the diagonal of G only; a thread
+  // takes column cc of the slice (16 consecutive doubles of a row of G per 16 threads)
+  const int cc = threadIdx.x & (kRedRows - 1);
+  for (int r = threadIdx.x / kRedRows; r < 64; r += 256 / kRedRows) {
+    if (gj0 + r < p && gi0 + r0 + cc < p && !(dq && r0 + cc >= r))
+      G[(uint64_t)(gj0 + r) * p + gi0 + r0 + cc] = S[cc * 65 + r];
   }
 }
 
@@ -88,7 +93,7 @@ int launch_gram_reduce(const double *part, int npairs, int nsplit, int nb, int p
   ProfScope ps("gram_reduce");
   const int form = sink.form && last ? 1 : 0;
   if (form && !sink.prec) return fail(OBHIP_ERR_INVALID, "gram sink: form without the prior precisions");
-  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)npairs), dim3(256), 0, cur_stream(), part, npairs,
+  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)npairs, 4 * (64 / kRedRows)), dim3(256), 0, cur_stream(), part, npairs,
                      nsplit, nb, p, sink.out, accumulate ? 1 : 0, sink.packed ? 1 : 0, form, sink.e2,
                      sink.prec, sink.diagH);
   OB_HIP(hipGetLastError());
