@@ -193,7 +193,7 @@ void renumber_columns(Layout &L, uint64_t ncol) {
   }
 }
 
-void reduce_conflicts(Layout &L) {
+void reduce_conflicts(Layout &L, uint64_t moves_per_star) {
   std::vector<Star> &st = *L.stars;
   const uint64_t nh = L.nst / 32;
   // classes of exchangeable stars: same kind, same number of shared factors / of slots needed
@@ -210,7 +210,7 @@ void reduce_conflicts(Layout &L) {
   };
   std::vector<int> hc(nh);
   for (uint64_t h = 0; h < nh; ++h) hc[h] = L.half_cost(h);
-  const uint64_t moves = std::min<uint64_t>(400000, 150 * L.nst);
+  const uint64_t moves = std::min<uint64_t>(400000, moves_per_star * L.nst);
   for (uint64_t it = 0; it < moves; ++it) {
     const uint64_t r = next();
     const uint64_t i = (r >> 8) % L.nst;
@@ -412,13 +412,17 @@ int build_share_tables(const uint16_t *hc, uint64_t p_pad, uint64_t W, ShareTabl
   L.sc.assign(nst * NA, 0);
   for (uint64_t i = 0; i < nst; ++i) L.refresh(i);
   out.lds_cycles0 = layout_cost(L);
-  reduce_conflicts(L);
-  // ... and which bank pair a column lies on (the caller renumbers its used columns accordingly),
-  // then the arrangement once more for the new banks
+  // (moves per star: OBHIP_SHARE_MOVES, default 30.  At the headline terms, LDS cycles per row /
+  // host time of the tables: 10 moves 247 / 0.05 s, 30: 245 / 0.12 s, 60: 240 / 0.2 s, 150: 234 / 0.4 s,
+  // from 311 unsearched; the kernels gain 0.4 % from 258 -> 231, a new term set pays the host time once)
+  static const uint64_t mps = getenv("OBHIP_SHARE_MOVES") ? (uint64_t)std::max(0, atoi(getenv("OBHIP_SHARE_MOVES"))) : 30;
+  // ... and which bank pair a column lies on (the caller renumbers its used columns accordingly):
+  // a short search for the co-occurrence counts, the numbering, then the arrangement for the new banks
   if (renumber) {
+    reduce_conflicts(L, std::min<uint64_t>(mps, 20));
     renumber_columns(L, ncol);
-    reduce_conflicts(L);
   }
+  reduce_conflicts(L, mps);
   out.lds_cycles = layout_cost(L);
   out.relabel = L.relabel;
   // ad[0 .. P): the shared factors, right-aligned (ones in front); ad[P + j S .. P + (j + 1) S):
