@@ -43,6 +43,7 @@ int require_device() {
 }
 
 hipStream_t cur_stream() { return g_stream; }
+void set_cur_stream(hipStream_t s) { g_stream = s; }
 
 // ---- device memory pool (see obhip_internal.h) ------------------------------------------
 namespace {

@@ -729,6 +729,54 @@ int launch_gram_panel(const obhip_basis &bc, obhip_terms &t, const GramSink &sin
     return fail(OBHIP_ERR_HIP, "not enough free HBM for even one row chunk of the design matrix");
   b.bmat_terms = 0;  // the buffer no longer holds the whole matrix of any terms
   if (b.bmat.n < (size_t)ctiles * kTileRows * t.p_pad) OB_TRY(b.bmat.alloc((size_t)ctiles * kTileRows * t.p_pad));
+  // OBHIP_GRAM_OVERLAP=1 (A/B, round-4 verdict): chunk k + 1 staged on a second stream, into a second
+  // buffer, while chunk k is multiplied.  Measured at the headline with two and four chunks
+  // (DESIGN.md section 10.8): nothing to gain -- the Gram's two workgroups per CU leave no LDS for a
+  // staging workgroup beside them, so the copy runs in slots the Gram gives up.  Off by default.
+  static const bool overlap = getenv("OBHIP_GRAM_OVERLAP") && atoi(getenv("OBHIP_GRAM_OVERLAP")) != 0;
+  if (overlap && ctiles < ntiles) {
+    DevBuf<double> second;
+    OB_TRY(second.alloc((size_t)ctiles * kTileRows * t.p_pad));
+    hipStream_t mainst = cur_stream(), side = nullptr;
+    OB_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    hipEvent_t ev0, evM[2], evG[2];
+    OB_HIP(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+      OB_HIP(hipEventCreateWithFlags(&evM[i], hipEventDisableTiming));
+      OB_HIP(hipEventCreateWithFlags(&evG[i], hipEventDisableTiming));
+    }
+    OB_HIP(hipEventRecord(ev0, mainst));  // the basis is built on the caller's stream
+    OB_HIP(hipStreamWaitEvent(side, ev0, 0));
+    int rc = 0;
+    uint64_t c = 0;
+    for (uint64_t t0 = 0; t0 < ntiles && rc == 0; t0 += ctiles, ++c) {
+      const uint64_t nt = std::min(ctiles, ntiles - t0);
+      const int buf = (int)(c & 1);
+      double *Bp = buf ? second.p : b.bmat.p;
+      RowView view(b, t0, nt);
+      if (c >= 2) (void)hipStreamWaitEvent(side, evG[buf], 0);  // the product that read this buffer is done
+      set_cur_stream(side);
+      {
+        ProfScope ps("materialize_B");
+        rc = materialize_any(view.v, t, Bp);
+      }
+      (void)hipEventRecord(evM[buf], side);
+      set_cur_stream(mainst);
+      if (rc) break;
+      (void)hipStreamWaitEvent(mainst, evM[buf], 0);
+      rc = gram_of_staged(b, Bp, nt, t, sink, t0 != 0, t0 + nt >= ntiles);
+      (void)hipEventRecord(evG[buf], mainst);
+    }
+    (void)hipStreamSynchronize(side);
+    (void)hipStreamSynchronize(mainst);  // (the second buffer goes back to the pool below)
+    (void)hipEventDestroy(ev0);
+    for (int i = 0; i < 2; ++i) {
+      (void)hipEventDestroy(evM[i]);
+      (void)hipEventDestroy(evG[i]);
+    }
+    (void)hipStreamDestroy(side);
+    return rc;
+  }
   for (uint64_t t0 = 0; t0 < ntiles; t0 += ctiles) {
     const uint64_t nt = std::min(ctiles, ntiles - t0);
     RowView view(b, t0, nt);

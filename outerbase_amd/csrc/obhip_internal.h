@@ -34,6 +34,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 int require_device();
 hipStream_t cur_stream();
+void set_cur_stream(hipStream_t s);  // (internal: a second stream inside one entry point; restored before it returns)
 // model state stamps are drawn from one process-wide counter: device tables cached under
 // (model address, stamp) can then never be taken for those of another model that came to live at
 // the same address
