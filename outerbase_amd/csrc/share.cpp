@@ -15,16 +15,22 @@
 //     whole groups of four at a time, members that do not fill a group stay free for their other
 //     families;
 //   * what is left over (no family with four free members; any term set, downward-closed or not)
-//     goes four at a time into *plain* stars: no shared part, S column slots per term;
-//   * stars are ordered by falling number of reads and cut into star-waves of 64 (one per wave
-//     and unit); a star-wave's shape (P, S) is the maximum over its members (shorter prefixes are
-//     padded with the ones column at the front; a star-wave that holds a plain star is plain).
+//     is listed (k_star multiplies those few terms out in its middle step) and also packed four
+//     at a time into *plain* stars -- no shared part, S column slots per term -- behind the family
+//     stars, for kernels that take whole star-waves only;
+//   * family stars are ordered by falling number of shared factors and cut into star-waves of 64
+//     (one per wave), filled up with empty stars; a star-wave's shape (P, S) is the maximum over its
+//     members (shorter prefixes are padded with the ones column at the front);
+//   * a seeded local search then places the stars (half-wave, order of the four terms) and numbers
+//     the used columns for few LDS bank conflicts (below).
 // Device side: TlStar in device_common.h runs the read pipeline of a shape; the kernels pick the
 // instantiation per star-wave by a wave-uniform branch.
 //
-// At the headline term set (d = 20, p = 4096, 12 177 factors in all) a block issues 106 column
-// reads per row instead of 194 (tools/term_share_stats.py); d = 8 mat25pow with six-factor terms
-// 117 instead of 206; BASELINE configs[4]'s 16 384 terms 394 instead of 768.
+// At the headline term set (d = 20, p = 4096, 12 177 factors in all) a block issues 97 column
+// reads per row for the 4052 family terms + 16 for the plain star-wave of the 44 left-over ones,
+// instead of 194; d = 8 mat25pow with six-factor terms 100 + 24 instead of 224; BASELINE
+// configs[4]'s 16 384 terms 384 + 16 instead of 768 (obhip_terms_share_tables reports these numbers
+// for any term set; tests/test_host_logic.py checks the tables themselves).
 #include <algorithm>
 #include <map>
 #include <queue>
