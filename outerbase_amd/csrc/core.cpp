@@ -197,6 +197,8 @@ int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
     D.rotoff = (int)hrot.size();
     D.ccol0 = (int)ccol;
     D.tab = -1;
+    D.gwin = 0;
+    D.g0 = D.ginv = 0.0;
     ccol += (uint64_t)c;
     const double *hy = &m.hyp[m.hypst[l]];
     const double a = 2.0, b = 0.25;  // covfuncs.h:42,53-54,66
@@ -270,6 +272,36 @@ int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
       double *us = &htab[D.tab];
       for (uint64_t j = 0; j < ml; ++j) us[j] = hka[o + ord[j]];
       for (uint64_t j = ml; j < mu; ++j) us[j] = us[ml - 1];
+      // Interval search.  J = number of knots with u_j <= u(x).  For (nearly) equidistant knots --
+      // the reference tests' grid, obfit's quantile knots of evenly spread inputs -- the guess
+      // J0 = floor((u - u_0) (m - 1) / (u_{m-1} - u_0)) + 1 is off by at most one, and the device
+      // settles J with 2 E independent reads of the sorted knots around J0 (one round trip)
+      // instead of seven dependent bisection steps.  Whether that holds is CHECKED here, for every
+      // interval, with the very expression the device evaluates: the guess at both ends of the
+      // interval [u_{J-1}, u_J) must lie within E - 1 of J (one interval of slack for u values
+      // the device computes a rounding away from a knot).  Otherwise gwin stays 0: bisection.
+      if (ml >= 4 && us[ml - 1] > us[0]) {
+        const double g0 = us[0], ginv = (double)(ml - 1) / (us[ml - 1] - us[0]);
+        auto guess = [&](double u) {
+          double q = std::floor((u - g0) * ginv) + 1.0;
+          q = std::min(std::max(q, 0.0), (double)ml);
+          return (int64_t)q;
+        };
+        int64_t worst = 0;
+        for (uint64_t J = 0; J <= ml; ++J) {
+          // u in [us[J-1], us[J]) (J = 0: below the first knot, J = m: from the last knot on)
+          const double a_ = J >= 1 ? us[J - 1] : us[0] - 1.0 / ginv;
+          const double b_ = J < ml ? std::nextafter(us[J], -INFINITY) : us[ml - 1] + 1.0 / ginv;
+          if (J < ml && J >= 1 && !(us[J] > us[J - 1])) continue;  // (an empty interval: repeated knots)
+          worst = std::max(worst, std::llabs(guess(a_) - (int64_t)J));
+          worst = std::max(worst, std::llabs(guess(b_) - (int64_t)J));
+        }
+        if (worst <= 1) {
+          D.gwin = (int)worst + 1;  // 1 or 2: reads J0 - E .. J0 + E - 1
+          D.g0 = g0;
+          D.ginv = ginv;
+        }
+      }
       double *cf = us + mu;
       // e^{-d_j} = e^{u_j} e^{-ref} (j < J) or e^{-u_j} e^{ref}: |u| < 150, far from the range's end
       std::vector<long double> ep(ml), em(ml);

@@ -150,15 +150,33 @@ __device__ __forceinline__ double build_dim_tab(const DimDesc &D, const double *
   typedef double dd2 __attribute__((ext_vector_type(2)));
   const double ux = (KIND == OBHIP_COV_MAT25 ? xv / D.p0 : pow(xv, D.p0) / D.p1) - D.p2;
   const double *__restrict__ us = tab + D.tab;
-  int lo = 0, hi = D.m;  // u_(lo-1) <= ux < u_(hi)
-  for (int it = 0; it < 7; ++it) {  // m <= 127
-    const int mid = (lo + hi) >> 1;
-    const bool open = lo < hi;
-    const bool le = us[min(mid, D.m - 1)] <= ux;
-    lo = open && le ? mid + 1 : lo;
-    hi = open && !le ? mid : hi;
+  int J;
+  if (D.gwin > 0) {
+    // (nearly) equidistant knots: the host has checked that the guess is within gwin - 1 of J for
+    // every u (ModelDev::build), so J = (knots below the window) + (knots of the window <= u):
+    // 2 gwin INDEPENDENT reads instead of seven dependent ones.  (NaN: J0 = 0, J = 0, as the
+    // bisection gives.)
+    double q = floor((ux - D.g0) * D.ginv) + 1.0;
+    q = fmin(fmax(q, 0.0), (double)D.m);
+    const int J0 = (int)q, w0 = max(J0 - D.gwin, 0);
+    int cnt = 0;
+    for (int k = 0; k < 2 * D.gwin; ++k) {  // (wave-uniform trip count: 2 or 4)
+      const int idx = J0 - D.gwin + k;
+      const bool in = idx >= 0 && idx < D.m;
+      cnt += in && us[min(max(idx, 0), D.m - 1)] <= ux ? 1 : 0;
+    }
+    J = w0 + cnt;
+  } else {
+    int lo = 0, hi = D.m;  // u_(lo-1) <= ux < u_(hi)
+    for (int it = 0; it < 7; ++it) {  // m <= 127
+      const int mid = (lo + hi) >> 1;
+      const bool open = lo < hi;
+      const bool le = us[min(mid, D.m - 1)] <= ux;
+      lo = open && le ? mid + 1 : lo;
+      hi = open && !le ? mid : hi;
+    }
+    J = lo;
   }
-  const int J = lo;
   const double t = ux - us[max(J - 1, 0)];
   const double em = J == 0 ? 0.0 : exp(-t), ep = J == D.m ? 0.0 : exp(t);
   const dd2 *__restrict__ cf = (const dd2 *)(us + ((D.m + 1) & ~1) + (size_t)J * D.ncol * 6);

@@ -218,7 +218,11 @@ struct DimDesc {
   int rotoff;  // offset into rot (doubles)
   int ccol0;   // compact column of level 1 (level t -> ccol0 + t - 1)
   int tab;     // offset (doubles) of the dimension's interval tables in ModelDev::tab, -1: none
+  int gwin;    // interval search of the tables: 0 = seven bisection steps; E > 0: the guess
+               // J0 = floor((u - g0) ginv) + 1 is within E - 1 of the interval for every u (checked on
+               // the host), so 2 E independent reads around it settle it in one round trip
   double p0, p1, p2;  // kernel constants (see kernels_basis.hip)
+  double g0, ginv;    // the guess of gwin: first sorted knot (in u), (m - 1) / (last - first)
 };
 
 struct ModelDev {
