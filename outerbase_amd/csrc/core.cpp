@@ -293,8 +293,8 @@ int ModelDev::build(const obhip_model &m, const std::vector<int64_t> &cap_in) {
           const double a_ = J >= 1 ? us[J - 1] : us[0] - 1.0 / ginv;
           const double b_ = J < ml ? std::nextafter(us[J], -INFINITY) : us[ml - 1] + 1.0 / ginv;
           if (J < ml && J >= 1 && !(us[J] > us[J - 1])) continue;  // (an empty interval: repeated knots)
-          worst = std::max(worst, std::llabs(guess(a_) - (int64_t)J));
-          worst = std::max(worst, std::llabs(guess(b_) - (int64_t)J));
+          worst = std::max<int64_t>(worst, (int64_t)std::llabs(guess(a_) - (int64_t)J));
+          worst = std::max<int64_t>(worst, (int64_t)std::llabs(guess(b_) - (int64_t)J));
         }
         if (worst <= 1) {
           D.gwin = (int)worst + 1;  // 1 or 2: reads J0 - E .. J0 + E - 1
