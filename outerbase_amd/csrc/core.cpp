@@ -127,7 +127,7 @@ struct ProfEntry {
   double total_ms = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
-std::atomic<uint64_t> obhip::g_host_syncs{0};
+std::atomic<uint64_t> g_host_syncs{0};
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::map<std::string, ProfEntry> g_prof;

@@ -6,10 +6,11 @@
 // H is p x p, row-major, full symmetric storage on entry; on exit its lower
 // triangle holds L (H = L L^T), the strict upper triangle is scratch.
 //
-// Two 64-column panels per trailing update (rank 128) from p = 4096 up: panel j, a strip update
-// of the next 64 columns only, panel j + 1, then ONE pass over the trailing matrix with both
-// panels (k = 128, staged through LDS in parts).  The trailing update reads and writes the whole
-// trailing triangle; this halves that traffic.
+// Several 64-column panels per trailing update (two from p = 4096, four from p = 8192): panel j, a
+// strip update of the next 64 columns only with the panels of the pass so far, panel j + 1, ...,
+// then ONE pass over the trailing matrix with all panels of the pass (k = 128 or 256, staged
+// through LDS in parts).  The trailing update reads and writes the whole trailing triangle; every
+// doubling of the panels per pass halves that traffic.
 //   k_chol_panel2: every workgroup re-factorises the 64 x 64 diagonal block itself
 //                  (cheaper than a launch boundary) -- four 16-column blocks, wave 0 in
 //                  registers, the columns to the right on the matrix cores by all waves --
@@ -595,12 +596,23 @@ __global__ void k_form_hessian(double *__restrict__ G, const double *__restrict_
 
 }  // namespace
 
-// z (p), info (64 doubles reserved), k-major copies of two panels Wt (128 rows of
-// chol_pitch(p) doubles), scratch block for L_jj (64 x 64), the inverses of the 16 x 16
+// z (p), info (64 doubles reserved), k-major copies of the panels of a pass Wt (64 rows of
+// chol_pitch(p) doubles each), scratch block for L_jj (64 x 64), the inverses of the 16 x 16
 // diagonal sub-blocks (1024 doubles per 64 columns)
 static uint64_t chol_pitch(uint64_t p) { return (p + 127) / 128 * 128 + 128; }
+// panels per trailing pass (OBHIP_CHOL_PANELS: 1, 2, 4 or 8 for A/B runs)
+static int chol_panels(uint64_t p) {
+  static const int forced = [] {
+    const char *e = getenv("OBHIP_CHOL_PANELS");
+    const int v = e ? atoi(e) : 0;
+    return v == 1 || v == 2 || v == 4 || v == 8 ? v : 0;
+  }();
+  if (forced) return forced;
+  return p >= 8192 ? 4 : (p >= 4096 ? 2 : 1);
+}
 uint64_t newton_workspace_bytes(uint64_t p) {
-  return (p + 64 + 2 * NB * chol_pitch(p) + NB * NB + ((p + NB - 1) / NB) * 1024) * sizeof(double);
+  return (p + 64 + (uint64_t)chol_panels(p) * NB * chol_pitch(p) + NB * NB + ((p + NB - 1) / NB) * 1024) *
+         sizeof(double);
 }
 
 int launch_form_hessian(uint64_t p, double *d_G, const double *d_prec, double e2, double *d_diagH) {
@@ -621,10 +633,10 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
   int *info = (int *)(z + p);
   double *Wt = z + p + 64;
   const int pw = (int)chol_pitch(p64);
-  double *Ljj = Wt + (size_t)2 * NB * pw;
+  double *Ljj = Wt + (size_t)chol_panels(p64) * NB * pw;
   double *Iinv = Ljj + NB * NB;  // [p / 64][4][16][16]: inverses of the 16 x 16 diagonal sub-blocks
   hipStream_t st = cur_stream();
-  OB_HIP(hipMemsetAsync(Wt, 0, sizeof(double) * 2 * NB * pw, st));  // rows beyond p stay zero
+  OB_HIP(hipMemsetAsync(Wt, 0, sizeof(double) * chol_panels(p64) * NB * pw, st));  // rows beyond p stay zero
   OB_HIP(hipMemcpyAsync(z, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, st));
   OB_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
   {
@@ -642,19 +654,30 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
       hipLaunchKernelGGL(k_chol_panel2, dim3((unsigned)(nrowblk + 1)), dim3(256), 0, st, d_H, z, Wt,
                          pw, p, j0, info, Ljj, wt_row0, Iinv);
     };
-    // Two panels per trailing pass: half the passes over the trailing matrix for one more (strip)
-    // launch per pair of panels.  p = 16384: 60.1 -> 41.2 ms; p = 4096: 2.26 -> 2.17 ms (with the
-    // 128 x 128 update tiles and the slower panel step of before it cost 5 % there).
-    const bool two = p >= (getenv("OBHIP_CHOL_TWO_FROM") ? atoi(getenv("OBHIP_CHOL_TWO_FROM")) : 4096);
+    // Several panels per trailing pass (chol_panels): panel, then a strip update of the next 64
+    // columns only with all panels of the pass so far (left-looking inside the pass), ..., then ONE
+    // pass over the trailing matrix with all of them (k = 64 x panels).  The trailing update reads
+    // and writes the whole trailing triangle, 8 flops per byte at k = 128: two panels halve that
+    // traffic against one (p = 16384: 60.1 -> 41.2 ms; p = 4096: 2.26 -> 2.17 ms), four halve it again.
+    const int npan = chol_panels(p64);
     // 64 x 64 tiles (a quarter of the MFMAs and loads per workgroup, three workgroups per CU)
     // unless there are thousands of 128 x 128 ones: p = 4096 2.67 -> 2.27 ms with them
     // throughout, p = 16384 43.8 -> 41.0 ms with them below 5000 tiles
     const int t64_below = getenv("OBHIP_CHOL_T64") ? atoi(getenv("OBHIP_CHOL_T64")) : 5000;
     // trailing rows / columns from t0 on with the panel(s) in Wt; strip: the next 64 columns only
-    auto update = [&](int t0, int kparts, int strip, int ljj_j0, int zj0, int zk0) {
+    // full updates of at least this many 128 x 128 tiles on the Gram kernel's body (launch_syrk_sub;
+    // the z part and L_jj stay with k_chol_update, launched without tiles)
+    static const int atb_from = getenv("OBHIP_CHOL_ATB") ? atoi(getenv("OBHIP_CHOL_ATB")) : 1500;
+    auto update = [&](int t0, int kparts, int strip, int ljj_j0, int zj0, int zk0) -> int {
       const int m = p - t0;
       const int nt128 = (m + 127) / 128, work128 = strip ? nt128 : nt128 * (nt128 + 1) / 2;
       const int nz = (m + 255) / 256;
+      if (!strip && atb_from > 0 && work128 >= atb_from && ((uintptr_t)(Wt + t0) & 15) == 0) {
+        hipLaunchKernelGGL((k_chol_update<64, 32>), dim3((unsigned)nz), dim3(256), 0, st, d_H, z, Wt, pw, p, t0,
+                           kparts, 0, 0, ljj_j0, zj0, zk0, Ljj);
+        return launch_syrk_sub(Wt + t0, (uint64_t)pw, (uint64_t)m, (uint64_t)kparts * NB,
+                               d_H + (size_t)t0 * p + t0, (uint64_t)p);
+      }
       if (work128 < t64_below) {
         const int nt = (m + 63) / 64, work = strip ? nt : nt * (nt + 1) / 2;
         hipLaunchKernelGGL((k_chol_update<64, 32>), dim3((unsigned)(work + nz)), dim3(256), 0, st, d_H, z,
@@ -663,30 +686,22 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
         hipLaunchKernelGGL((k_chol_update<128, 32>), dim3((unsigned)(work128 + nz)), dim3(256), 0, st, d_H,
                            z, Wt, pw, p, t0, kparts, strip, work128, ljj_j0, zj0, zk0, Ljj);
       }
+      return 0;
     };
-    for (int j0 = 0; !two && j0 < p; j0 += NB) {
-      panel(j0, 0);
-      if (p - (j0 + NB) <= 0) {
-        OB_TRY(place_ljj(j0));
-        break;
+    for (int j0 = 0, done = 0; !done && j0 < p; j0 += npan * NB) {
+      for (int i = 0; i < npan; ++i) {
+        const int jp = j0 + i * NB;
+        panel(jp, i * NB);
+        if (p - (jp + NB) <= 0) {
+          OB_TRY(place_ljj(jp));
+          done = 1;
+          break;
+        }
+        // not the last panel of the pass: the next panel's 64 columns (all rows below) with the
+        // panels so far; the last: the trailing matrix once with all panels.  Either way z for
+        // everything below with this panel, and this panel's L_jj into place.
+        OB_TRY(update(jp + NB, i + 1, i + 1 < npan ? 1 : 0, jp, jp, i * NB));
       }
-      update(j0 + NB, 1, 0, j0, j0, 0);
-    }
-    for (int j0 = 0; two && j0 < p; j0 += 2 * NB) {
-      panel(j0, 0);
-      if (p - (j0 + NB) <= 0) {
-        OB_TRY(place_ljj(j0));
-        break;
-      }
-      // the next panel's 64 columns (all rows below), z for everything below, L_jj of panel j0
-      update(j0 + NB, 1, 1, j0, j0, 0);
-      panel(j0 + NB, NB);
-      if (p - (j0 + 2 * NB) <= 0) {
-        OB_TRY(place_ljj(j0 + NB));
-        break;
-      }
-      // the trailing matrix once with both panels (k = 128), z with the second panel
-      update(j0 + 2 * NB, 2, 0, j0 + NB, j0 + NB, NB);
     }
     OB_HIP(hipGetLastError());
   }

@@ -796,9 +796,15 @@ constexpr int kGeNU = 4, kGeSteps = 16, kGeInflight = 8;
 
 // SQF: the unit's product is squared before it enters the MFMA (the squared stores' products are
 // the squares of the plain ones: the double-buffered kernel stages the raw columns by LDS-direct loads)
-template <int WE, int W, int NHB, bool SQF = false>
+// N4: further groups of FOUR hyper-parameters on v_mfma_f64_4x4x4_4b_f64 (a quarter of the matrix-pipe
+// time of a 16-block: 20 hyper-parameters cost 1.25 blocks instead of 2).  There the product is the A
+// operand -- lane (block (l >> 2) & 3, i = l & 3, k = l >> 4) holds A_blk[i][k], which IS term
+// t16 = l & 15 at row r4 = l >> 4 -- and the weight of hyper-parameter l & 3 at the same row the B
+// operand B_blk[k][j = l & 3], the same in all four blocks; D_blk[i][j] lands in lane (i = l >> 4,
+// blk, j = l & 3): term 4 blk + (l >> 4), hyper-parameter l & 3.
+template <int WE, int W, int NHB, bool SQF = false, int N4 = 0>
 struct GePipe {
-  static constexpr int NU = kGeNU, TOT = kGeSteps * kGeNU;
+  static constexpr int NU = kGeNU, TOT = kGeSteps * kGeNU, NWT = NHB + N4;
   static constexpr int D = (kGeInflight / WE) > 0 ? kGeInflight / WE : 1;
   // units issued once step U has issued (the prologue issues units 0 .. D-2)
   static constexpr int issued(int U) { return U + D < TOT ? U + D : TOT; }
@@ -806,7 +812,7 @@ struct GePipe {
   // LDS reads queued behind the weights of step s when step s waits for them
   static constexpr int newer_w(int s) {
     const int units = s == 0 ? issued(0) : issued(s * NU) - issued((s - 1) * NU);
-    const int v = units * WE + (wnext(s) ? NHB : 0);
+    const int v = units * WE + (wnext(s) ? NWT : 0);
     return v < 15 ? v : 15;
   }
   // LDS reads queued behind the reads of unit U when step U waits for them
@@ -814,7 +820,7 @@ struct GePipe {
     const int units = (TOT - 1 - U) < (D - 1) ? (TOT - 1 - U) : (D - 1);
     int wr = 0;
     for (int S = (U - D + 1 > 0 ? U - D + 1 : 0); S <= U; ++S)
-      if (S % NU == 0 && wnext(S / NU)) wr += NHB;
+      if (S % NU == 0 && wnext(S / NU)) wr += NWT;
     const int v = units * WE + wr;
     return v < 15 ? v : 15;
   }
@@ -828,7 +834,11 @@ struct GePipe {
   template <int S, typename C>
   static __device__ __forceinline__ void issue_w(C &c, double (&w)[12]) {
 #pragma unroll
-    for (int hb = 0; hb < NHB; ++hb) w[(S % 2) * NHB + hb] = tl_rd<S * 32>(c.aw[hb]);
+    for (int hb = 0; hb < NHB; ++hb) w[(S % 2) * NWT + hb] = tl_rd<S * 32>(c.aw[hb]);
+    if constexpr (N4 > 0) {
+#pragma unroll
+      for (int q = 0; q < N4; ++q) w[(S % 2) * NWT + NHB + q] = tl_rd<S * 32>(c.aw4[q]);
+    }
   }
   template <int U, typename C>
   static __device__ __forceinline__ void steps(C &c, double (&buf)[12], double (&w)[12]) {
@@ -837,7 +847,7 @@ struct GePipe {
       if constexpr (U + D - 1 < TOT) issue<U + D - 1>(c, buf);
       if constexpr (unit == 0) {
         if constexpr (wnext(st)) issue_w<st + 1>(c, w);
-        tl_waitn<newer_w(st), NHB, (st % 2) * NHB>(w);
+        tl_waitn<newer_w(st), NWT, (st % 2) * NWT>(w);
       }
       tl_waitn<newer_u(U), WE, s>(buf);
       double v = buf[s];
@@ -846,8 +856,14 @@ struct GePipe {
       if constexpr (SQF) v = v * v;
 #pragma unroll
       for (int hb = 0; hb < NHB; ++hb)
-        c.acc[unit][hb] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[(st % 2) * NHB + hb], v,
+        c.acc[unit][hb] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[(st % 2) * NWT + hb], v,
                                                                c.acc[unit][hb], 0, 0, 0);
+      if constexpr (N4 > 0) {
+#pragma unroll
+        for (int q = 0; q < N4; ++q)
+          c.acc4[unit][q] =
+              __builtin_amdgcn_mfma_f64_4x4x4f64(v, w[(st % 2) * NWT + NHB + q], c.acc4[unit][q], 0, 0, 0);
+      }
       steps<U + 1>(c, buf, w);
     }
   }
@@ -867,23 +883,25 @@ struct GePipe {
   }
 };
 
-template <int W, int NHB>
+template <int W, int NHB, int N4 = 0>
 struct GeCtx {
   uint32_t ad[kGeNU][W];
-  uint32_t aw[NHB];
-  ge_d4 acc[kGeNU][NHB];
+  uint32_t aw[NHB > 0 ? NHB : 1];
+  ge_d4 acc[kGeNU][NHB > 0 ? NHB : 1];
+  uint32_t aw4[N4 > 0 ? N4 : 1];
+  double acc4[kGeNU][N4 > 0 ? N4 : 1];
 };
 
-template <int W, int NHB, bool SQF = false>
-__device__ __forceinline__ void ge_tile(GeCtx<W, NHB> &c, int we) {
+template <int W, int NHB, bool SQF = false, int N4 = 0>
+__device__ __forceinline__ void ge_tile(GeCtx<W, NHB, N4> &c, int we) {
   if (we == W) {
-    GePipe<W, W, NHB, SQF>::run(c);
+    GePipe<W, W, NHB, SQF, N4>::run(c);
   } else if (we == W - 1) {
-    GePipe<W - 1, W, NHB, SQF>::run(c);
+    GePipe<W - 1, W, NHB, SQF, N4>::run(c);
   } else if (W >= 3 && we == W - 2) {
-    GePipe<(W >= 3 ? W - 2 : 1), W, NHB, SQF>::run(c);
+    GePipe<(W >= 3 ? W - 2 : 1), W, NHB, SQF, N4>::run(c);
   } else {
-    GePipe<(W >= 4 ? W - 3 : 1), W, NHB, SQF>::run(c);
+    GePipe<(W >= 4 ? W - 3 : 1), W, NHB, SQF, N4>::run(c);
   }
 }
 
@@ -974,7 +992,10 @@ k_tmm_ge0(const double *__restrict__ bm, const double *__restrict__ scale,
 // products are formed as squares of the plain products (GePipe<SQF>).  k_tmm_ge0 above loads its
 // tile between two barriers: with two blocks per CU one computes while the other loads, but at a
 // few microseconds of compute per tile the matrix pipe still idled half of the time.
-template <int W2, bool SQ>
+// N4: hyper-parameters h0 + 16 .. h0 + 16 + 4 N4 ride along in groups of four (GePipe); NHB = 0:
+// groups of four only (the last 1 to 8 hyper-parameters in a pass of their own, whose matrix
+// instructions take a quarter or half of a 16-block's time).
+template <int W2, bool SQ, int N4, int NHB = 1>
 __global__ void __launch_bounds__(1024, 4)
 k_tmm_ge0_db(const double *__restrict__ bm, const double *__restrict__ scale,
              const uint32_t *__restrict__ ucol, int Mu, uint64_t Mtot,
@@ -982,7 +1003,8 @@ k_tmm_ge0_db(const double *__restrict__ bm, const double *__restrict__ scale,
              const int *__restrict__ ge0abs, int nhyp, int h0, const double *__restrict__ a, uint64_t n,
              uint64_t ntiles, uint64_t tiles_per_split, uint64_t p_pad, double *__restrict__ part) {
   extern __shared__ double lds[];
-  constexpr int W = 2 * W2, NHB = 1, HS = 16, NW = 16;
+  constexpr int W = 2 * W2, H16 = 16 * NHB, HS = H16 + 4 * N4, NW = 16;
+  static_assert(NHB <= 1 && HS <= 24 && HS >= 4, "");
   const int lane = threadIdx.x & 63, t16 = lane & 15, r4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_split;
@@ -990,7 +1012,7 @@ k_tmm_ge0_db(const double *__restrict__ bm, const double *__restrict__ scale,
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
   const uint32_t tile_bytes = (uint32_t)(Mu + HS) * (kTlPitch * 8);
 
-  GeCtx<W, NHB> c;
+  GeCtx<W, NHB, N4> c;
   int nzmax = 1;
 #pragma unroll
   for (int g = 0; g < kGeNU; ++g) {
@@ -1006,25 +1028,34 @@ k_tmm_ge0_db(const double *__restrict__ bm, const double *__restrict__ scale,
     }
     nzmax = max(nzmax, tl_nnz<W2>(cw));
     c.acc[g][0] = ge_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < (N4 > 0 ? N4 : 1); ++q) c.acc4[g][q] = 0.0;
   }
   c.aw[0] = lds0 + (uint32_t)(Mu + t16) * (kTlPitch * 8) + r4 * 8;
+#pragma unroll
+  for (int q = 0; q < (N4 > 0 ? N4 : 1); ++q)
+    c.aw4[q] = lds0 + (uint32_t)(Mu + H16 + 4 * q + (lane & 3)) * (kTlPitch * 8) + r4 * 8;
   const int we = tl_variant<W>(wave_max_i32(nzmax));
   const bool live = ((uint64_t)blockIdx.y * NW + wave) * 64 < p_pad;
   // wave h stages weight column h: a s (SQ: a s^2) times ge[h, 0] (SQ: 2 ge[h, 0]) of the row = lane
-  const int wcol = h0 + wave < nhyp ? ge0abs[h0 + wave] : -1;
+  // (the first waves a second one, column 16 + h, where groups of four ride along with a 16-block)
+  constexpr bool kSecond = NHB > 0 && N4 > 0;
+  const int wcol = (wave < HS && h0 + wave < nhyp) ? ge0abs[h0 + wave] : -1;
+  const int wcol2 = (kSecond && wave < 4 * N4 && h0 + 16 + wave < nhyp) ? ge0abs[h0 + 16 + wave] : -1;
 
   // next tile -> the other buffer.  (The weight column's two loads are requested BEFORE the
   // LDS-direct loads and used at the top of the next tile: the compiler's vmcnt bookkeeping does
   // not see the inline-asm loads, a use right here would wait for all of them.)
-  double gvn = 0.0, wrn = 0.0;
+  double gvn = 0.0, wrn = 0.0, gvn2 = 0.0;
   auto prefetch = [&](uint64_t tile, int bsel) {
     const char *tb = (const char *)(bm + tile * Mtot * kTileRows);
     const uint64_t row = tile * kTileRows + lane;
-    gvn = wrn = 0.0;
+    gvn = wrn = gvn2 = 0.0;
     if (row < n && wcol >= 0) {
       const double sc = scale[row];
       wrn = a[row] * (SQ ? sc * sc : sc);
       gvn = ((const double *)tb)[(size_t)wcol * kTileRows + lane];
+      if (kSecond && wcol2 >= 0) gvn2 = ((const double *)tb)[(size_t)wcol2 * kTileRows + lane];
     }
     const uint32_t l0 = lds0 + (bsel ? tile_bytes : 0u);
     for (int u = wave; u < Mu; u += NW) {
@@ -1048,10 +1079,13 @@ k_tmm_ge0_db(const double *__restrict__ bm, const double *__restrict__ scale,
   for (uint64_t tile = t0; tile < t1; ++tile) {
     const int bsel = (int)((tile - t0) & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed
-    lds[(bsel ? tile_bytes / 8 : 0) + (Mu + wave) * kTlPitch + lane] = wrn * (SQ ? 2.0 * gvn : gvn);
+    if (wave < HS)
+      lds[(bsel ? tile_bytes / 8 : 0) + (Mu + wave) * kTlPitch + lane] = wrn * (SQ ? 2.0 * gvn : gvn);
+    if (kSecond && wave < 4 * N4)
+      lds[(bsel ? tile_bytes / 8 : 0) + (Mu + 16 + wave) * kTlPitch + lane] = wrn * (SQ ? 2.0 * gvn2 : gvn2);
     __syncthreads();  // tile and weights complete; every wave is done with the other buffer
     if (tile + 1 < t1) prefetch(tile + 1, bsel ^ 1);
-    if (live) ge_tile<W, NHB, SQ>(c, we);
+    if (live) ge_tile<W, NHB, SQ, N4>(c, we);
     // on to the other buffer
     const uint32_t delta = bsel ? 0u - tile_bytes : tile_bytes;
 #pragma unroll
@@ -1063,14 +1097,32 @@ k_tmm_ge0_db(const double *__restrict__ bm, const double *__restrict__ scale,
       }
     c.aw[0] += delta;
     asm volatile("" : "+v"(c.aw[0]));
+    if constexpr (N4 > 0) {
+#pragma unroll
+      for (int q = 0; q < N4; ++q) {
+        c.aw4[q] += delta;
+        asm volatile("" : "+v"(c.aw4[q]));
+      }
+    }
   }
 #pragma unroll
   for (int g = 0; g < kGeNU; ++g) {
     const uint64_t slot = ((uint64_t)blockIdx.y * NW + wave) * 64 + g * 16 + t16;
-    if (slot >= p_pad) continue;
-    const uint64_t k = sperm[slot];
+    if (NHB > 0 && slot < p_pad) {
+      const uint64_t k = sperm[slot];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) part[((uint64_t)blockIdx.x * HS + r4 + 4 * v) * p_pad + k] = c.acc[g][0][v];
+      for (int v = 0; v < 4; ++v) part[((uint64_t)blockIdx.x * HS + r4 + 4 * v) * p_pad + k] = c.acc[g][0][v];
+    }
+    if constexpr (N4 > 0) {
+      // D layout of v_mfma_f64_4x4x4_4b_f64: term 4 blk + (lane >> 4), hyper-parameter lane & 3
+      const uint64_t slot4 = ((uint64_t)blockIdx.y * NW + wave) * 64 + g * 16 + ((lane >> 2) & 3) * 4 + r4;
+      if (slot4 < p_pad) {
+        const uint64_t k4 = sperm[slot4];
+#pragma unroll
+        for (int q = 0; q < N4; ++q)
+          part[((uint64_t)blockIdx.x * HS + H16 + 4 * q + (lane & 3)) * p_pad + k4] = c.acc4[g][q];
+      }
+    }
   }
 }
 
@@ -1111,23 +1163,39 @@ int run_tmm_ge0_sq(const obhip_basis &src, obhip_terms &t, const int *d_c0, int 
   OB_HIP(hipGetLastError());
   return 0;
 }
-template <int W2, bool SQ>
+template <int W2, bool SQ, int N4, int NHB = 1>
 int run_tmm_ge0_db(const obhip_basis &src, obhip_terms &t, const int *d_c0, int nhyp, int h0,
                    const double *d_a, dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
-  const size_t lds = 2 * (t.Mu + 16) * kTlPitch * sizeof(double);
-  OB_TRY(ensure_dyn_lds((const void *)k_tmm_ge0_db<W2, SQ>, lds));
-  hipLaunchKernelGGL((k_tmm_ge0_db<W2, SQ>), grid, dim3(1024), lds, cur_stream(), src.bm.p, src.scale.p,
+  const size_t lds = 2 * (t.Mu + 16 * NHB + 4 * N4) * kTlPitch * sizeof(double);
+  OB_TRY(ensure_dyn_lds((const void *)k_tmm_ge0_db<W2, SQ, N4, NHB>, lds));
+  hipLaunchKernelGGL((k_tmm_ge0_db<W2, SQ, N4, NHB>), grid, dim3(1024), lds, cur_stream(), src.bm.p, src.scale.p,
                      t.ucol.p, (int)t.Mu, src.md.Mc, (const uint32_t *)t.cols.p, t.sperm.p, d_c0, nhyp, h0,
                      d_a, src.n, ntiles, tps, t.p_pad, part);
   OB_HIP(hipGetLastError());
   return 0;
 }
 template <int W2, int NHB>
-int run_tmm_ge0(bool sq, int nw, const obhip_basis &src, obhip_terms &t, const int *d_c0, int nhyp, int h0,
-                const double *d_a, dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
+int run_tmm_ge0(bool sq, int nw, int n4, const obhip_basis &src, obhip_terms &t, const int *d_c0, int nhyp,
+                int h0, const double *d_a, dim3 grid, uint64_t ntiles, uint64_t tps, double *part) {
   if (nw == 32) {  // (16 waves, two tile buffers)
-    if (sq) return run_tmm_ge0_db<W2, true>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
-    return run_tmm_ge0_db<W2, false>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+    if (n4 == -1) {  // groups of four only
+      if (sq) return run_tmm_ge0_db<W2, true, 1, 0>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+      return run_tmm_ge0_db<W2, false, 1, 0>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+    }
+    if (n4 == -2) {
+      if (sq) return run_tmm_ge0_db<W2, true, 2, 0>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+      return run_tmm_ge0_db<W2, false, 2, 0>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+    }
+    if (n4 == 1) {
+      if (sq) return run_tmm_ge0_db<W2, true, 1>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+      return run_tmm_ge0_db<W2, false, 1>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+    }
+    if (n4 == 2) {
+      if (sq) return run_tmm_ge0_db<W2, true, 2>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+      return run_tmm_ge0_db<W2, false, 2>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+    }
+    if (sq) return run_tmm_ge0_db<W2, true, 0>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
+    return run_tmm_ge0_db<W2, false, 0>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
   }
   if (nw == 16) {
     if (sq) return run_tmm_ge0_sq<W2, NHB, true, 16>(src, t, d_c0, nhyp, h0, d_a, grid, ntiles, tps, part);
@@ -1158,6 +1226,13 @@ int launch_tmm_ge0(obhip_basis &b, obhip_terms &t, bool squared, const double *d
   // ... and where TWO tiles fit the LDS, 16 waves with the next tile prefetched into the second
   // buffer (k_tmm_ge0_db; nw = 32 stands for it below)
   static const int force_nw = getenv("OBHIP_GE0_WAVES") ? atoi(getenv("OBHIP_GE0_WAVES")) : 0;
+  // Hyper-parameters beyond a multiple of 16 (d = 20 mat25: 4 of 20) in groups of four on the
+  // 4 x 4 x 4 matrix instruction instead of a mostly empty 16-block.  OBHIP_GE0_FOURS: 0 = never,
+  // 1 = 1 to 8 left over take a pass of their own (NHB = 0), 2 (default) = behind a 16-block they
+  // ride along with it (the products formed once; 22-39 registers of the W2 = 2 kernel spilled
+  // outside the read pipeline).  d = 20 mat25 at the headline terms, 20 hyper-parameters: dense part
+  // 5.47 / 4.52 / 3.50 ms, obfit evaluation 30.8 / 29.8 / 28.5 ms (tools/r05_fours_ab.sh).
+  static const int fours = getenv("OBHIP_GE0_FOURS") ? atoi(getenv("OBHIP_GE0_FOURS")) : 2;
   const size_t tile_lds = (t.Mu + 16) * kTlPitch * sizeof(double);
   const bool two_tiles = 2 * tile_lds <= 156 * 1024;
   bool one_per_cu = tile_lds > 80 * 1024;
@@ -1177,20 +1252,28 @@ int launch_tmm_ge0(obhip_basis &b, obhip_terms &t, bool squared, const double *d
   // 16 hyper-parameters per pass: with two 16-blocks per pass (NHB = 2) the 64 accumulator
   // registers of a wave no longer fit beside the pipeline and the compiler spills them in the
   // inner loop (measured 8.4 ms against 2 x 1.7 ms at C3)
-  for (int h0 = 0; h0 < nhyp; h0 += 16) {
-    const int nh = std::min(16, nhyp - h0), hs = 16;
+  for (int h0 = 0; h0 < nhyp;) {
+    const int rem = nhyp - h0;
+    // n4 > 0: 16 + 4 n4 hyper-parameters in this pass; n4 < 0: 4 |n4| only
+    int n4 = 0;
+    if (fours == 2 && nw == 32 && rem > 16 && rem <= 24) n4 = (rem - 16 + 3) / 4;
+    if (fours >= 1 && nw == 32 && rem <= 8) n4 = -((rem + 3) / 4);
+    if (n4 > 0 && 2 * (t.Mu + 16 + 4 * n4) * kTlPitch * sizeof(double) > 156 * 1024) n4 = 0;
+    const int nh = n4 > 0 ? rem : (n4 < 0 ? rem : std::min(16, rem));
+    const int hs = n4 > 0 ? 16 + 4 * n4 : (n4 < 0 ? -4 * n4 : 16);
     double *part = nullptr;
     OB_TRY(b.workspace(nsplit * hs * t.p_pad * sizeof(double), (void **)&part));
     switch (t.W / 2) {
-      case 1: OB_TRY((run_tmm_ge0<1, 1>(squared, nw, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
-      case 2: OB_TRY((run_tmm_ge0<2, 1>(squared, nw, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
-      case 3: OB_TRY((run_tmm_ge0<3, 1>(squared, nw, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
-      default: OB_TRY((run_tmm_ge0<4, 1>(squared, nw, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      case 1: OB_TRY((run_tmm_ge0<1, 1>(squared, nw, n4, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      case 2: OB_TRY((run_tmm_ge0<2, 1>(squared, nw, n4, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      case 3: OB_TRY((run_tmm_ge0<3, 1>(squared, nw, n4, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
+      default: OB_TRY((run_tmm_ge0<4, 1>(squared, nw, n4, src, t, dc0.p, nhyp, h0, d_a, grid, ntiles, tps, part))); break;
     }
     hipLaunchKernelGGL(k_ge0_reduce, dim3((unsigned)((t.p + 255) / 256), (unsigned)nh), dim3(256), 0,
                        cur_stream(), part, (int)nsplit, hs, t.p_pad, (int)t.p, nh,
                        d_out + (uint64_t)h0 * t.p);
     OB_HIP(hipGetLastError());
+    h0 += nh;
   }
   return 0;
 }

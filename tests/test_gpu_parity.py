@@ -574,24 +574,32 @@ def test_gradient_basis_tables_and_knot_loop_against_extended_precision(kind, mo
         assert max(err) < 2e-13, (path, err)
 
 
-def test_gradhyp_with_more_hyperparameters_than_one_pass_holds():
-    """26 hyper-parameters (the transposed streaming kernel takes 20 per pass) and 22
-    dimensions: matmul / tmatmul / sqcolsums _gradhyp against the oracle."""
+@pytest.mark.parametrize("kinds,nhyp", [
+    (["mat25"] * 18 + ["mat25pow", "mat25ang", "mat25pow", "mat25ang"], 26),   # 16 + 10: two 16-blocks
+    (["mat25"] * 20, 20),                       # 16 + 4: one group of four rides along (the headline's d)
+    (["mat25"] * 16 + ["mat25pow"] * 3, 22),    # 16 + 6: two groups of four ride along
+    (["mat25pow"] * 3, 6),                      # groups of four only
+    (["mat25"] * 3, 3),
+])
+def test_gradhyp_with_more_hyperparameters_than_one_pass_holds(kinds, nhyp):
+    """More hyper-parameters than one 16-block of the dense pass holds, and the shapes at which the
+    last few are contracted in groups of four on the 4 x 4 x 4 matrix instruction (k_tmm_ge0_db,
+    csrc/kernels_grad.hip): matmul / tmatmul / sqcolsums _gradhyp against the oracle."""
     import ob_oracle as O
     import outerbase_amd as ob
-    kinds = ["mat25"] * 18 + ["mat25pow", "mat25ang", "mat25pow", "mat25ang"]
     rng = np.random.default_rng(26)
     om_o, om_d = make_pair(kinds, knots_for(kinds, 16))
-    assert len(om_o.hypmatch) == 26
+    assert len(om_o.hypmatch) == nhyp
     n, p = 300, 260
     x = sample_x(rng, n, kinds)
     terms = om_o.selectterms(p)
     bo = O.OuterBase(om_o, x, dograd=True)
     bd = ob.outerbase(om_d, x)
     a, v = rng.standard_normal(p), rng.standard_normal(n)
-    assert relerr(bd.matmul_gradhyp(terms, a), O.ob_mm_gradhyp(bo, terms, a)[1]) < 1e-9
-    assert relerr(bd.tmatmul_gradhyp(terms, v), O.ob_tmm_gradhyp(bo, terms, v)[1]) < 1e-9
-    assert relerr(bd.sqcolsums_gradhyp(terms), O.ob_sqcolsums_gradhyp(bo, terms)) < 1e-9
+    tol = 1e-9 if terms.max() < 8 else 2e-7
+    assert relerr(bd.matmul_gradhyp(terms, a), O.ob_mm_gradhyp(bo, terms, a)[1]) < tol
+    assert relerr(bd.tmatmul_gradhyp(terms, v), O.ob_tmm_gradhyp(bo, terms, v)[1]) < tol
+    assert relerr(bd.sqcolsums_gradhyp(terms), O.ob_sqcolsums_gradhyp(bo, terms)) < tol
 
 
 @pytest.mark.parametrize("ss,nterms", [(400, 100),        # testmultgrad's defaults
@@ -942,6 +950,26 @@ def test_newton_solve_sizes_against_library_solve(p):
     cond = float(torch.linalg.cond(H))
     assert float((th - want).norm() / want.norm()) < 1e-13 * max(cond, 10.0)
     assert float((dH - torch.diagonal(H)).abs().max() / torch.diagonal(H).abs().max()) < 1e-14
+
+
+@pytest.mark.parametrize("panels", [1, 2, 4, 8])
+def test_cholesky_schedules_with_one_to_eight_panels_per_pass(panels):
+    """The blocked Cholesky with 1, 2, 4 and 8 panels per trailing pass (csrc/kernels_chol.hip: the
+    default is 1 below p = 4096, 2 from there, 4 from 8192) at sizes where a pass ends inside a
+    panel, right behind one, and in the middle of a pass; the solution and L itself against torch.
+    The setting is read once per process: a child process per schedule."""
+    import os
+    import subprocess
+    import sys
+    sizes = [1, 64, 65, 129, 200, 257, 449, 513, 640, 1000, 1217]
+    env = dict(os.environ, OBHIP_CHOL_PANELS=str(panels))
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "chol_schedule_worker.py")
+    r = subprocess.run([sys.executable, worker] + [str(v) for v in sizes], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln.split() for ln in r.stdout.splitlines() if ln.startswith(("ok", "BAD"))]
+    assert [int(ln[1]) for ln in lines] == sizes, r.stdout
+    assert all(ln[0] == "ok" for ln in lines), r.stdout
 
 
 def test_cholesky_with_more_workgroups_than_the_gpu_holds():
