@@ -151,6 +151,7 @@ __device__ __forceinline__ double build_dim_tab(const DimDesc &D, const double *
   const double ux = (KIND == OBHIP_COV_MAT25 ? xv / D.p0 : pow(xv, D.p0) / D.p1) - D.p2;
   const double *__restrict__ us = tab + D.tab;
   int J;
+  double uref;  // u_(J-1) (u_(0) for J = 0)
   if (D.gwin > 0) {
     // (nearly) equidistant knots: the host has checked that the guess is within gwin - 1 of J for
     // every u (ModelDev::build), so J = (knots below the window) + (knots of the window <= u):
@@ -158,14 +159,22 @@ __device__ __forceinline__ double build_dim_tab(const DimDesc &D, const double *
     // bisection gives.)
     double q = floor((ux - D.g0) * D.ginv) + 1.0;
     q = fmin(fmax(q, 0.0), (double)D.m);
-    const int J0 = (int)q, w0 = max(J0 - D.gwin, 0);
+    const int J0 = (int)q, w0 = max(J0 - 2, 0);
+    // always the window of gwin = 2 (J0 - 2 .. J0 + 1: a superset of gwin = 1's), its four values
+    // kept: the knot below u(x), u_(J-1), is one of them (J0 - 1 <= J <= J0 + 1), so the reference
+    // point costs selects instead of a second, dependent read
+    double wv[4];
     int cnt = 0;
-    for (int k = 0; k < 2 * D.gwin; ++k) {  // (wave-uniform trip count: 2 or 4)
-      const int idx = J0 - D.gwin + k;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = J0 - 2 + k;
       const bool in = idx >= 0 && idx < D.m;
-      cnt += in && us[min(max(idx, 0), D.m - 1)] <= ux ? 1 : 0;
+      wv[k] = us[min(max(idx, 0), D.m - 1)];
+      cnt += in && wv[k] <= ux ? 1 : 0;
     }
     J = w0 + cnt;
+    const int kr = max(J - 1, 0) - (J0 - 2);  // 0 .. 3
+    uref = kr <= 1 ? (kr == 0 ? wv[0] : wv[1]) : (kr == 2 ? wv[2] : wv[3]);
   } else {
     int lo = 0, hi = D.m;  // u_(lo-1) <= ux < u_(hi)
     for (int it = 0; it < 7; ++it) {  // m <= 127
@@ -176,8 +185,9 @@ __device__ __forceinline__ double build_dim_tab(const DimDesc &D, const double *
       hi = open && !le ? mid : hi;
     }
     J = lo;
+    uref = us[max(J - 1, 0)];
   }
-  const double t = ux - us[max(J - 1, 0)];
+  const double t = ux - uref;
   const double em = J == 0 ? 0.0 : exp(-t), ep = J == D.m ? 0.0 : exp(t);
   const dd2 *__restrict__ cf = (const dd2 *)(us + ((D.m + 1) & ~1) + (size_t)J * D.ncol * 6);
   double cl = 1.0, icl = 1.0;

@@ -600,16 +600,24 @@ __global__ void k_form_hessian(double *__restrict__ G, const double *__restrict_
 // chol_pitch(p) doubles each), scratch block for L_jj (64 x 64), the inverses of the 16 x 16
 // diagonal sub-blocks (1024 doubles per 64 columns)
 static uint64_t chol_pitch(uint64_t p) { return (p + 127) / 128 * 128 + 128; }
-// panels per trailing pass (OBHIP_CHOL_PANELS: 1, 2, 4 or 8 for A/B runs)
-static int chol_panels(uint64_t p) {
+// Panels of the trailing pass that starts with m rows and columns left (OBHIP_CHOL_PANELS: 1, 2, 4
+// or 8 throughout, for A/B runs).  The more panels, the fewer passes over the trailing matrix (HBM:
+// 8 flops per byte at two panels) but the more work in the strips between the panels, which a few
+// workgroups do: eight while the trailing matrix is large, two once it is small.
+static int chol_panels_at(uint64_t p, uint64_t m) {
   static const int forced = [] {
     const char *e = getenv("OBHIP_CHOL_PANELS");
     const int v = e ? atoi(e) : 0;
     return v == 1 || v == 2 || v == 4 || v == 8 ? v : 0;
   }();
+  static const uint64_t m8 = getenv("OBHIP_CHOL_M8") ? strtoull(getenv("OBHIP_CHOL_M8"), nullptr, 10) : 8192;
+  static const uint64_t m4 = getenv("OBHIP_CHOL_M4") ? strtoull(getenv("OBHIP_CHOL_M4"), nullptr, 10) : 4096;
   if (forced) return forced;
-  return p >= 8192 ? 4 : (p >= 4096 ? 2 : 1);
+  if (p < 4096) return 1;
+  return m >= m8 ? 8 : (m >= m4 ? 4 : 2);
 }
+// (the most any pass takes: the first)
+static int chol_panels(uint64_t p) { return chol_panels_at(p, p); }
 uint64_t newton_workspace_bytes(uint64_t p) {
   return (p + 64 + (uint64_t)chol_panels(p) * NB * chol_pitch(p) + NB * NB + ((p + NB - 1) / NB) * 1024) *
          sizeof(double);
@@ -658,26 +666,18 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
     // columns only with all panels of the pass so far (left-looking inside the pass), ..., then ONE
     // pass over the trailing matrix with all of them (k = 64 x panels).  The trailing update reads
     // and writes the whole trailing triangle, 8 flops per byte at k = 128: two panels halve that
-    // traffic against one (p = 16384: 60.1 -> 41.2 ms; p = 4096: 2.26 -> 2.17 ms), four halve it again.
-    const int npan = chol_panels(p64);
+    // traffic against one (p = 16384: 60.1 -> 41.2 ms; p = 4096: 2.26 -> 2.17 ms), four halve it again
+    // (36.0 ms), eight again (34.6); by the rows left at the start of a pass (chol_panels_at) 33.1 ms.
+    // (Strips with 64 instead of 32 k per staged part: 33.7 against 33.3 ms, not kept.)
     // 64 x 64 tiles (a quarter of the MFMAs and loads per workgroup, three workgroups per CU)
     // unless there are thousands of 128 x 128 ones: p = 4096 2.67 -> 2.27 ms with them
     // throughout, p = 16384 43.8 -> 41.0 ms with them below 5000 tiles
     const int t64_below = getenv("OBHIP_CHOL_T64") ? atoi(getenv("OBHIP_CHOL_T64")) : 5000;
     // trailing rows / columns from t0 on with the panel(s) in Wt; strip: the next 64 columns only
-    // full updates of at least this many 128 x 128 tiles on the Gram kernel's body (launch_syrk_sub;
-    // the z part and L_jj stay with k_chol_update, launched without tiles)
-    static const int atb_from = getenv("OBHIP_CHOL_ATB") ? atoi(getenv("OBHIP_CHOL_ATB")) : 1500;
     auto update = [&](int t0, int kparts, int strip, int ljj_j0, int zj0, int zk0) -> int {
       const int m = p - t0;
       const int nt128 = (m + 127) / 128, work128 = strip ? nt128 : nt128 * (nt128 + 1) / 2;
       const int nz = (m + 255) / 256;
-      if (!strip && atb_from > 0 && work128 >= atb_from && ((uintptr_t)(Wt + t0) & 15) == 0) {
-        hipLaunchKernelGGL((k_chol_update<64, 32>), dim3((unsigned)nz), dim3(256), 0, st, d_H, z, Wt, pw, p, t0,
-                           kparts, 0, 0, ljj_j0, zj0, zk0, Ljj);
-        return launch_syrk_sub(Wt + t0, (uint64_t)pw, (uint64_t)m, (uint64_t)kparts * NB,
-                               d_H + (size_t)t0 * p + t0, (uint64_t)p);
-      }
       if (work128 < t64_below) {
         const int nt = (m + 63) / 64, work = strip ? nt : nt * (nt + 1) / 2;
         hipLaunchKernelGGL((k_chol_update<64, 32>), dim3((unsigned)(work + nz)), dim3(256), 0, st, d_H, z,
@@ -688,7 +688,8 @@ int launch_newton_solve(uint64_t p64, double *d_H, const double *d_rhs, double *
       }
       return 0;
     };
-    for (int j0 = 0, done = 0; !done && j0 < p; j0 += npan * NB) {
+    for (int j0 = 0, done = 0, npan = 1; !done && j0 < p; j0 += npan * NB) {
+      npan = chol_panels_at(p64, (uint64_t)(p - j0));
       for (int i = 0; i < npan; ++i) {
         const int jp = j0 + i * NB;
         panel(jp, i * NB);

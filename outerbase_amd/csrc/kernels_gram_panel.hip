@@ -168,13 +168,10 @@ __device__ __forceinline__ void lds_rd_h1(const uint32_t (&baddr)[4], double (&b
 //   kAtbNorm   out[J][i] = sum over the 128 columns of tile J of C[i][c]^2 (C never stored):
 //              || L^-1 b_i ||^2 of predr_std with A = B^T (term-major), Bm = L^-T
 //   kAtbStore  C[I-tile rows][J-tile columns] stored row-major with leading dimension ldo
-//   kAtbSub    out[I-tile rows][J-tile columns] -= C on and below the diagonal, rows below `nb`
-//              (there the row count): the Cholesky's trailing update with A = Bm = the k-major
-//              copies of the pass's panels (launch_syrk_sub)
-// For kAtbNorm / kAtbStore the k range of column tile J ends at (J + 1) * 128 when `tri` says Bm is
+// For the last two the k range of column tile J ends at (J + 1) * 128 when `tri` says Bm is
 // upper triangular.  DBG: one block reports its s_memtime / s_memrealtime span (clock and
 // matrix-pipe cycles per chunk under load, OBHIP_GRAM_DBG=1); production carries none of it.
-constexpr int kAtbGram = 0, kAtbNorm = 1, kAtbStore = 2, kAtbSub = 3;
+constexpr int kAtbGram = 0, kAtbNorm = 1, kAtbStore = 2;
 __host__ __device__ inline uint64_t atb_task(uint64_t I, uint64_t J, uint64_t y, uint64_t type = 0) {
   return I | (J << 24) | (y << 48) | (type << 62);
 }
@@ -357,32 +354,6 @@ k_atb_dma2(const double *__restrict__ A, uint64_t ldA, const double *__restrict_
           const int col = wn * 64 + j * 16 + ((mblk + r) & 3) * 4 + me;
           out[(uint64_t)row * ldo + col] = acc[i][j][r];
         }
-  } else if constexpr (MODE == kAtbSub) {
-    if (I == J && wn > wm) return;  // strictly upper quadrant of a diagonal tile
-    double *out = part + ((uint64_t)I * kGT) * ldo + (uint64_t)J * kGT;
-    const int gr0 = I * kGT, gc0 = J * kGT;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = wm * 64 + i * 16 + mblk * 4 + mk;
-      // the 16 values of this row group first (one round trip), then the 16 stores
-      double h[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = wn * 64 + j * 16 + ((mblk + r) & 3) * 4 + me;
-          const bool in = gr0 + row < nb && gc0 + col <= gr0 + row;
-          h[j][r] = in ? out[(uint64_t)row * ldo + col] : 0.0;
-        }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = wn * 64 + j * 16 + ((mblk + r) & 3) * 4 + me;
-          const bool in = gr0 + row < nb && gc0 + col <= gr0 + row;
-          if (in) out[(uint64_t)row * ldo + col] = h[j][r] - acc[i][j][r];
-        }
-    }
   } else {
     // per output row the sum of squares over this wave's 64 columns: 16 values per lane and
     // row group i, then the 4 lanes (me) that hold the other columns of the row; the two
@@ -914,63 +885,6 @@ int launch_atb(int mode, const double *A, uint64_t ldA, uint64_t M, const double
   } else {
     return fail(OBHIP_ERR_INVALID, "launch_atb: unknown mode");
   }
-  OB_HIP(hipGetLastError());
-  return 0;
-}
-
-// H[i][j] -= sum_k Wt[k][i] Wt[k][j] for m > i >= j >= 0: the trailing update of the blocked Cholesky
-// (kernels_chol.hip) with the K = 64 x panels rows of the pass's k-major panel copies, on the Gram
-// kernel's body -- LDS-direct panel loads, hand-issued operand reads, 128 x 128 tiles, two blocks per
-// CU -- instead of k_chol_update's register-staged 16 x 16 x 4 tiles.  Wt: K x (>= m rounded up to
-// 128) doubles, zero beyond m, 16-byte aligned; H: the trailing matrix' first element, leading
-// dimension ldh.  The lower-triangular tile pairs go to the XCDs in 8 x 8 squares (one table per
-// number of tiles, kept).
-int launch_syrk_sub(const double *Wt, uint64_t ldw, uint64_t m, uint64_t K, double *H, uint64_t ldh) {
-  if (K % kTileRows || m == 0 || m >= (1ull << 30)) return fail(OBHIP_ERR_INVALID, "launch_syrk_sub: sizes");
-  const uint64_t mt = (m + kGT - 1) / kGT;
-  using Tab = std::shared_ptr<DevBuf<uint64_t>>;
-  static std::mutex mu;
-  static std::map<std::pair<int, uint64_t>, Tab> cache;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  Tab tabp;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    if (cache.size() > 1024) {  // (a process that factorises at hundreds of different sizes)
-      (void)hipDeviceSynchronize();
-      cache.clear();
-    }
-    Tab &slot = cache[std::make_pair(dev, mt)];
-    if (!slot) {
-      std::vector<std::vector<uint64_t>> seq(kXcd);
-      for (uint64_t bj = 0; bj * kSq < mt; ++bj)
-        for (uint64_t bi = bj; bi * kSq < mt; ++bi) {
-          int k = 0;
-          for (int q = 1; q < kXcd; ++q)
-            if (seq[q].size() < seq[k].size()) k = q;
-          for (uint64_t i = bi * kSq; i < std::min(mt, (bi + 1) * kSq); ++i)
-            for (uint64_t j = bj * kSq; j < std::min({mt, (bj + 1) * kSq, i + 1}); ++j)
-              seq[k].push_back(atb_task(i, j, 0));
-        }
-      size_t len = 0;
-      for (auto &q : seq) len = std::max(len, q.size());
-      std::vector<uint64_t> tab(len * kXcd, kAtbNoTask);
-      for (int k = 0; k < kXcd; ++k)
-        for (size_t q = 0; q < seq[k].size(); ++q) tab[q * kXcd + k] = seq[k][q];
-      slot = std::make_shared<DevBuf<uint64_t>>();
-      const int rc = slot->upload(tab.data(), tab.size());
-      if (rc) {
-        cache.erase(std::make_pair(dev, mt));
-        return rc;
-      }
-    }
-    tabp = slot;
-  }
-  const size_t lds = (size_t)2 * kCR * kTP * sizeof(double);
-  const uint64_t ktiles = K / kTileRows;
-  OB_TRY(ensure_dyn_lds((const void *)k_atb_dma2<kAtbSub, false>, lds));
-  hipLaunchKernelGGL((k_atb_dma2<kAtbSub, false>), dim3((unsigned)tabp->n), dim3(256), lds, cur_stream(), Wt,
-                     ldw, Wt, ldw, (int)m, 0, ktiles, ktiles, 0, tabp->p, H, ldh, nullptr);
   OB_HIP(hipGetLastError());
   return 0;
 }

@@ -544,7 +544,7 @@ __device__ __forceinline__ void st_reduce8(const double (&acc)[8], double *__res
   }
 }
 
-template <int W2, int K, bool VAR>
+template <int W2, int K, bool VAR, bool PFX>
 __global__ void __launch_bounds__(kStWaves * 64, 4)
 k_star_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka, const double *__restrict__ kb,
                const double *__restrict__ kc, const double *__restrict__ rot, const double *__restrict__ tab,
@@ -605,23 +605,44 @@ k_star_predict(const DimDesc *__restrict__ dims, const double *__restrict__ ka, 
   // waves that have the fewest reads per row in phase A take the second round of dimensions.
   const int tile_doubles = Mu * kTlPitch;
   const uint32_t tile_bytes = (uint32_t)tile_doubles * 8u;
+  // PFX: the row's inputs for the wave's first two dimensions of tile T + 1 are requested BEFORE
+  // phase A of tile T -- the build is a latency chain (input from HBM, interval search, table
+  // coefficients), and its first link, the longest, then lies behind phase A
+  double xn[2] = {0.5, 0.5};
+  auto fetch_x = [&](uint64_t tile) {
+    const uint64_t row = tile * kTileRows + lane;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int l = WAVES - 1 - wave + q * WAVES;
+      xn[q] = (row < n && l < d) ? x[(uint64_t)l * n + row] : 0.5;
+    }
+  };
   auto build = [&](uint64_t tile, int bsel) {  // lane = row
     const StoreLdsPitch store{lds + (bsel ? tile_doubles : 0), cpos, lane};
     const uint64_t row = tile * kTileRows + lane;
     const bool valid = row < n;
     double sc = 1.0;
-    for (int l = WAVES - 1 - wave; l < d; l += WAVES) {
+    int q = 0;
+    for (int l = WAVES - 1 - wave; l < d; l += WAVES, ++q) {
+      double xv;
+      if (PFX && q < 2)
+        xv = q == 0 ? xn[0] : xn[1];
+      else
+        xv = valid ? x[(uint64_t)l * n + row] : 0.5;
       const DimDesc D = dims[l];
-      const double xv = valid ? x[(uint64_t)l * n + row] : 0.5;
       sc *= build_dim_any(D, ka, kb, kc, rot, tab, xv, store);
     }
     if (wave == 0) store.lds[lane] = 1.0;  // used column 0 = all ones
     reds[(bsel * WAVES + wave) * kStRedPitch + lane] = sc;
   };
-  if (t0 < t1) build(t0, 0);
+  if (t0 < t1) {
+    if (PFX) fetch_x(t0);
+    build(t0, 0);
+  }
   __syncthreads();
   for (uint64_t tile = t0; tile < t1; ++tile) {
     const int bsel = (int)((tile - t0) & 1);
+    if (PFX && tile + 1 < t1) fetch_x(tile + 1);
     if (live) {
       StP<NA, VAR> c{ad, th, cv, {}, {}, 1.0, 0.0, 0.0};
 #pragma unroll 1
@@ -769,10 +790,21 @@ int launch_star_predict(const obhip_model &m, obhip_terms &t, const double *d_th
   const uint64_t tps = (ntiles + nsplit - 1) / nsplit;
   nsplit = (ntiles + tps - 1) / tps;
   const bool wv = d_coeffvar != nullptr && d_var != nullptr;
+  // (with the variance the kernel spills more for the two registers than the early request gains:
+  // 1.83 -> 1.88 ms; without, 1.35 -> 1.24 ms on the same box)
+  static const bool pfx_on = !(getenv("OBHIP_PREDICT_PFX") && atoi(getenv("OBHIP_PREDICT_PFX")) == 0);
+  const bool pfx = pfx_on && !wv;
 #define OB_SP(W2_, K_, VAR_)                                                                                  \
   do {                                                                                                        \
-    OB_TRY(ensure_dyn_lds((const void *)k_star_predict<W2_, K_, VAR_>, lds));                                 \
-    hipLaunchKernelGGL((k_star_predict<W2_, K_, VAR_>), dim3((unsigned)nsplit), dim3(kStWaves * 64), lds,     \
+    if (pfx)                                                                                                  \
+      OB_SP2(W2_, K_, VAR_, true);                                                                            \
+    else                                                                                                      \
+      OB_SP2(W2_, K_, VAR_, false);                                                                           \
+  } while (0)
+#define OB_SP2(W2_, K_, VAR_, PFX_)                                                                           \
+  do {                                                                                                        \
+    OB_TRY(ensure_dyn_lds((const void *)k_star_predict<W2_, K_, VAR_, PFX_>, lds));                           \
+    hipLaunchKernelGGL((k_star_predict<W2_, K_, VAR_, PFX_>), dim3((unsigned)nsplit), dim3(kStWaves * 64), lds, \
                        cur_stream(), t.pred_md.dims.p, t.pred_md.ka.p, t.pred_md.kb.p, t.pred_md.kc.p,        \
                        t.pred_md.rot.p, t.pred_md.tab.p, t.cpos.p, (int)m.d, (int)t.Mu,                       \
                        (const uint32_t *)t.sh_cols.p, t.sh_term.p, t.sh_shape.p, (int)t.sh.nsw_family,        \
@@ -788,6 +820,7 @@ int launch_star_predict(const obhip_model &m, obhip_terms &t, const double *d_th
     default: OB_SP(3, 8, true); break;
   }
 #undef OB_SP
+#undef OB_SP2
   OB_HIP(hipGetLastError());
   return 0;
 }

@@ -496,7 +496,6 @@ int grad_wdot_dev(const double *d_G, const double *d_w, uint64_t n, uint64_t nco
 int grad_tmm_host(obhip_basis &b, obhip_terms &t, bool squared, const double *d_a, double *out_host);
 // kernels_chol.hip
 uint64_t newton_workspace_bytes(uint64_t p);
-int launch_syrk_sub(const double *Wt, uint64_t ldw, uint64_t m, uint64_t K, double *H, uint64_t ldh);
 bool materialize_tl_supports(const obhip_terms &t);
 int launch_materialize_tl(const obhip_basis &b, obhip_terms &t, double *d_B, const double *d_y = nullptr,
                           double *d_g = nullptr);
