@@ -427,6 +427,91 @@ k_cg_q(CgVecs v, const double *__restrict__ raw, double e2) {
 // One iteration of fit.cpp:71-85.  PART 0: the whole step with gradient and value advanced
 // by the recurrence (the objective is exactly quadratic); PART 1: up to theta += alpha pv
 // (a full update() follows); PART 2: the rest of the step after that update().
+// The whole step (PART 0) for p <= 4 x 1024 with every vector element in registers: ONE round of
+// loads where the general form below re-reads what it has just written (its pointers may alias)
+// -- four dependent trips to memory and 18 us per iteration at p = 4096, a chain the Hessian
+// product waits behind.  Same sums in the same order (element k = thread + 1024 j, j ascending).
+__device__ __forceinline__ void cg_iter_regs(const CgVecs &v, double tol, double *__restrict__ scal,
+                                             double *red, double *sh) {
+  constexpr int E = 4;
+  double g[E], rm[E], q[E], pv[E], md[E], th[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const uint64_t k = threadIdx.x + (uint64_t)kCgThreads * j;
+    const bool in = k < v.p;
+    g[j] = in ? v.grad[k] : 0.0;
+    rm[j] = in ? v.rm[k] : 0.0;
+    q[j] = in ? v.q[k] : 0.0;
+    pv[j] = in ? v.pv[k] : 0.0;
+    md[j] = in ? v.mdiag[k] : 1.0;
+    th[j] = in ? v.theta[k] : 0.0;
+  }
+  double d[3] = {0.0, 0.0, 0.0};  // num = grad . rm, denom = q . pv, gp = grad . pv
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    d[0] = fma(g[j], rm[j], d[0]);
+    d[1] = fma(q[j], pv[j], d[1]);
+    d[2] = fma(g[j], pv[j], d[2]);
+  }
+  block_sum<3>(d, red);
+  if (threadIdx.x == 0) {
+    const double num = d[0], denom = d[1];
+    double num0 = scal[S_NUM0];
+    bool done = num < tol && scal[S_VALDIFF] < tol;  // fit.cpp:73
+    if (!done) {  // (the guards of the general form below)
+      if (num0 < 0.0) num0 = num;
+      if (num <= 1e-28 * num0 || !(num > 0.0) || !(denom > 0.0)) done = true;
+    }
+    scal[S_NUM0] = num0;
+    scal[S_NUM] = num;
+    scal[S_DENOM] = denom;
+    scal[S_GP] = d[2];
+    scal[S_DONE] = done ? 1.0 : 0.0;
+    scal[S_ALPHA] = done ? 0.0 : num / denom;
+    sh[0] = done ? 1.0 : 0.0;
+    sh[1] = done ? 0.0 : num / denom;
+    sh[2] = num;
+  }
+  __syncthreads();
+  if (sh[0] != 0.0) return;
+  const double alpha = sh[1], num = sh[2];
+  if (threadIdx.x == 0) {
+    scal[S_ITERS] += 1.0;
+    // recurrence: val += alpha g.p - alpha^2 p.q / 2
+    const double dv = alpha * d[2] - 0.5 * alpha * alpha * d[1];
+    scal[S_VALO] = scal[S_VAL];
+    scal[S_VAL] += dv;
+  }
+  double n2[2] = {0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const uint64_t k = threadIdx.x + (uint64_t)kCgThreads * j;
+    th[j] = fma(alpha, pv[j], th[j]);
+    g[j] = fma(-alpha, q[j], g[j]);  // grad -= alpha q
+    const double r = g[j] / md[j];   // rm = grad / m (fit.cpp:80-84)
+    n2[0] = fma(-(alpha * q[j]), r, n2[0]);
+    n2[1] = fma(g[j], r, n2[1]);
+    rm[j] = r;
+    if (k < v.p) {
+      v.theta[k] = th[j];
+      v.grad[k] = g[j];
+      v.rm[k] = r;
+    }
+  }
+  block_sum<2>(n2, red);
+  const double beta = n2[0] / num;
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const uint64_t k = threadIdx.x + (uint64_t)kCgThreads * j;
+    if (k < v.p) v.pv[k] = fma(beta, pv[j], rm[j]);
+  }
+  if (threadIdx.x == 0) {
+    const double vd = scal[S_VAL] - scal[S_VALO];
+    scal[S_VALDIFF] = vd;
+    scal[S_NEXT] = (n2[1] < tol && vd < tol) ? 1.0 : 0.0;
+  }
+}
+
 template <int PART>
 __global__ void __launch_bounds__(kCgThreads)
 k_cg_iter(CgVecs v, double tol, double *__restrict__ scal) {
@@ -435,6 +520,10 @@ k_cg_iter(CgVecs v, double tol, double *__restrict__ scal) {
   // the loop has ended (a launch enqueued ahead of the host's look at the break conditions: the
   // batched form of fit_cg_dev_impl): nothing to do
   if (PART != 2 && (scal[S_DONE] != 0.0 || scal[S_NEXT] != 0.0)) return;
+  if (PART == 0 && v.p <= 4 * (uint64_t)kCgThreads) {
+    cg_iter_regs(v, tol, scal, red, sh);
+    return;
+  }
   if (PART != 2) {
     double d[3] = {0.0, 0.0, 0.0};  // num = grad . rm, denom = q . pv, gp = grad . pv
     for (uint64_t k = threadIdx.x; k < v.p; k += kCgThreads) {
