@@ -678,15 +678,20 @@ int fit_cg_dev_impl(const obhip_basis *b, const obhip_terms *tc, const obhip_mod
   // said stop (S_DONE) or that the next iteration would stop at its opening test (S_NEXT)
   const bool can_spec = hessmult_fused_skippable(*b, t);
   auto hessmult = [&](bool spec = false) -> int {
+    // (one rank: q comes out of the reduction of the product's row-split partials; with several the
+    // sum over ranks lies between the two)
+    const HmThen then{e2, v.prec, v.pv, v.q};
     const int fused = launch_hessmult_fused(*b, t, v.pv, nullptr, 1.0, 0.0, dpv.p, nullptr, nullptr,
-                                            spec ? scal.p + S_DONE : nullptr, spec ? scal.p + S_NEXT : nullptr);
+                                            spec ? scal.p + S_DONE : nullptr, spec ? scal.p + S_NEXT : nullptr,
+                                            many ? nullptr : &then);
     if (fused != kNotFused) OB_TRY(fused);
     if (fused == kNotFused) {
       OB_TRY(launch_mm(*b, t, v.pv, yhat.p, false));
       OB_TRY(launch_tmm(*b, t, yhat.p, dpv.p, false));
     }
     if (many) OB_TRY(comm_allreduce(comm, dpv.p, p));
-    hipLaunchKernelGGL(k_cg_q, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, st, v, dpv.p, e2);
+    if (many || fused == kNotFused)
+      hipLaunchKernelGGL(k_cg_q, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, st, v, dpv.p, e2);
     OB_HIP(hipGetLastError());
     return 0;
   };

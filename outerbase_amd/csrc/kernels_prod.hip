@@ -1003,6 +1003,33 @@ k_tmm_reduce(const double *__restrict__ part, int nsplit, uint64_t p_pad, int p,
   }
 }
 
+// the same, and q[k] = e2 out[k] + prec[k] pv[k] (HmThen)
+__global__ void __launch_bounds__(kRedThreads)
+k_tmm_reduce_q(const double *__restrict__ part, int nsplit, uint64_t p_pad, int p, double *__restrict__ out,
+               double e2, const double *__restrict__ prec, const double *__restrict__ pv, double *__restrict__ q) {
+  __shared__ double red[kRedThreads / 64][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int r = w;
+  for (; r + 48 < nsplit; r += 64) {
+    s0 += part[(uint64_t)r * p_pad + k];
+    s1 += part[(uint64_t)(r + 16) * p_pad + k];
+    s2 += part[(uint64_t)(r + 32) * p_pad + k];
+    s3 += part[(uint64_t)(r + 48) * p_pad + k];
+  }
+  for (; r < nsplit; r += 16) s0 += part[(uint64_t)r * p_pad + k];
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && k < p) {
+    double tot = 0.0;
+#pragma unroll
+    for (int qq = 0; qq < kRedThreads / 64; ++qq) tot += red[qq][lane];
+    out[k] = tot;
+    q[k] = e2 * tot + prec[k] * pv[k];
+  }
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   return ensure_dyn_lds((const void *)kernel, bytes);
@@ -1519,7 +1546,7 @@ bool hessmult_fused_skippable(const obhip_basis &b, obhip_terms &t) {
 
 int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y,
                           double ca, double cb, double *d_out, double *d_yhat, double *d_ss,
-                          const double *d_stop0, const double *d_stop1) {
+                          const double *d_stop0, const double *d_stop1, const HmThen *then) {
   OB_TRY(t.prepare(b.md.cap, b.md.dims_h));
   static const bool off = getenv("OBHIP_HESSMULT_FUSED") && atoi(getenv("OBHIP_HESSMULT_FUSED")) == 0;
   // OBHIP_HM_V1=1: the round-3 kernel (A/B runs); OBHIP_HM2_VARIANT: block shapes of k_hm2
@@ -1577,8 +1604,12 @@ int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_
     }
 #undef OB_HM
   }
-  hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0, cur_stream(),
-                     part, (int)nsplit, t.p_pad, (int)t.p, d_out);
+  if (then)
+    hipLaunchKernelGGL(k_tmm_reduce_q, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0, cur_stream(),
+                       part, (int)nsplit, t.p_pad, (int)t.p, d_out, then->e2, then->prec, then->pv, then->q);
+  else
+    hipLaunchKernelGGL(k_tmm_reduce, dim3((unsigned)((t.p + 63) / 64)), dim3(kRedThreads), 0, cur_stream(),
+                       part, (int)nsplit, t.p_pad, (int)t.p, d_out);
   if (d_ss) hipLaunchKernelGGL(k_hm_ss, dim3(1), dim3(64), 0, cur_stream(), sspart, (int)nsplit, d_ss);
   OB_HIP(hipGetLastError());
   return 0;

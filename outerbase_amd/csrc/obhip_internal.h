@@ -414,9 +414,17 @@ constexpr int kNotFused = -1;
 // d_stop0 / d_stop1 (device scalars, may be null): the launch does nothing when either is non-zero
 // at the time it RUNS -- for launches enqueued before the host knows whether they are needed; only
 // where hessmult_fused_skippable says so
+// then (may be null): q[k] = e2 d_out[k] + prec[k] pv[k] written by the reduction of the row-split
+// partials as well -- the PCG's q = H pv (lpdfvec::hessmult, fit.cpp:382-392) without a launch of its own
+struct HmThen {
+  double e2;
+  const double *prec, *pv;
+  double *q;
+};
 int launch_hessmult_fused(const obhip_basis &b, obhip_terms &t, const double *d_a, const double *d_y,
                           double ca, double cb, double *d_out, double *d_yhat, double *d_ss,
-                          const double *d_stop0 = nullptr, const double *d_stop1 = nullptr);
+                          const double *d_stop0 = nullptr, const double *d_stop1 = nullptr,
+                          const HmThen *then = nullptr);
 bool hessmult_fused_skippable(const obhip_basis &b, obhip_terms &t);
 // d_out = B^T a and d_out2 = (B^2)^T a2 (a2 null: ones) in one pass; kNotFused: make two passes
 int launch_tmm_dual(const obhip_basis &b, obhip_terms &t, const double *d_a, double *d_out, const double *d_a2,
