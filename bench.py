@@ -608,13 +608,20 @@ def obfit_evaluation(kinds, knots, p, n, torch, _lib, reps=3, maxlev=None, what=
         _lib.call("obhip_profile_get", name.encode(), C.byref(cnt), C.byref(tot))
         if cnt.value:
             phases[name] = {"launches_per_evaluation": cnt.value / reps, "ms_per_evaluation": round(tot.value / reps, 3)}
+    cnt, tot = C.c_uint64(0), C.c_double(0)
+    _lib.call("obhip_profile_get", b"*", C.byref(cnt), C.byref(tot))
+    profiled = {"launches_per_evaluation": cnt.value / reps, "ms_per_evaluation": round(tot.value / reps, 3)}
     _lib.call("obhip_profile_enable", 0)
     out = {"workload": "one second-stage obfit function evaluation on " + what + ": updatehyp, "
                        "updateom, updatepara, lpdf$optcg (device PCG, tol 1e-3, <= 100 steps), then value, "
                        "%d hyper-parameter and 2 parameter gradients with the marginal adjustment "
                        "(lpdfvec of loglik_gauss and logpr_gauss)" % len(hyp),
            "ms_per_evaluation": ms, "cg_iterations": int(vec.cgiters) if hasattr(vec, "cgiters") else None,
-           "phases": phases, "gradhyp_norm": float(np.linalg.norm(np.asarray(vec.gradhyp))),
+           "phases": phases,
+           # every profiled scope of the library together: what is left of ms_per_evaluation is the host
+           # (the eigen-model of updatehyp, the interval tables, result copies) and unprofiled vector kernels
+           "all_profiled_scopes": profiled,
+           "gradhyp_norm": float(np.linalg.norm(np.asarray(vec.gradhyp))),
            "d": d, "p": p, "n": n, "covariance": "/".join(sorted(set(kinds))),
            "factors_per_term_max": int((terms > 0).sum(1).max()), "levels_max": int(terms.max())}
     del vec, lik, pr

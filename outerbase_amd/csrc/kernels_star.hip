@@ -815,7 +815,7 @@ int launch_star_predict(const obhip_model &m, obhip_terms &t, const double *d_th
     case 2: OB_SP(1, 12, false); break;
     case 3: OB_SP(1, 12, true); break;
     case 4: OB_SP(2, 12, false); break;
-    case 5: OB_SP(2, 10, true); break;
+    case 5: OB_SP(2, 10, true); break;  // (ring depth 8 and / or early inputs here: 1.79-1.86 ms either way)
     case 6: OB_SP(3, 10, false); break;
     default: OB_SP(3, 8, true); break;
   }
