@@ -26,7 +26,7 @@ namespace obhip {
 
 namespace {
 
-// Work split: a block of 4 waves takes 4 consecutive 64-row tiles, one per wave; all waves walk
+// Work split: a block of 8 waves (4 until round 5) takes 8 consecutive 64-row tiles, one per wave; all waves walk
 // the dimensions together, so that a dimension's interval tables (mat25 / mat25pow,
 // build_dim_tab: [m sorted u][m + 1][levels][6], 12 KB at 40 knots and 6 levels) are staged once
 // per block in LDS and the per-row table reads -- seven bisection steps and 3 x levels 16-byte
@@ -37,15 +37,19 @@ namespace {
 // (mat25ang, out-of-range hyper-parameters) or with tables beyond the LDS buffer (all levels
 // kept: tables grow with levels x knots) take the scalar-operand knot loop.  The kernel is
 // latency-bound (a chain of bisection steps and table reads per dimension; the next dimension's
-// tables and x values are fetched under it), so the register budget is capped for the five
-// blocks per CU the two 16-KB table buffers allow.
+// tables and x values are fetched under it), so the register budget is capped for the waves
+// per CU the two 16-KB table buffers allow (24 in three blocks of eight).
 constexpr int kBbTab = kIntervalTabMax;  // doubles of LDS for one dimension's tables
 
 __device__ __forceinline__ int bb_tab_size(const DimDesc &D) {
   return ((D.m + 1) & ~1) + (D.m + 1) * D.ncol * 6;
 }
 
-__global__ void __launch_bounds__(256, 5)
+// NW: waves (= 64-row tiles) per block.  More tiles per block stage a dimension's tables fewer
+// times (20 x 16 KB per block at d = 20) and put more waves on a CU.
+// (4 / 8 / 16 tiles per block at the headline shape: 0.476 / 0.426 / 0.655 ms -- sixteen spill)
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 5 : 6)
 k_build_basis(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
               const double *__restrict__ kb, const double *__restrict__ kc,
               const double *__restrict__ rot, const double *__restrict__ tab,
@@ -54,14 +58,15 @@ k_build_basis(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
   __shared__ __attribute__((aligned(16))) double ltab[2][kBbTab];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint64_t tile = (uint64_t)blockIdx.x * 4 + wave;
+  const uint64_t tile = (uint64_t)blockIdx.x * NW + wave;
   const bool mine = tile < ntiles;  // (wave-uniform)
   const uint64_t row = tile * kTileRows + lane;
   const StoreGlobal store{bm + tile * Mc * kTileRows + lane};
   // The tables and the x values of dimension l + 1 are fetched into registers before dimension l
   // is evaluated and go to the other LDS buffer after it: one barrier per dimension, and the
   // fetch latency hides under the evaluation.
-  constexpr int kPer = kBbTab / 256;
+  constexpr int kPer = kBbTab / (NW * 64);
+  static_assert(kBbTab % (NW * 64) == 0, "");
   double treg[kPer];
   double xnext = 0.5;
   auto fetch = [&](int l) {
@@ -74,7 +79,7 @@ k_build_basis(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
       const int sz = bb_tab_size(D);
 #pragma unroll
       for (int i = 0; i < kPer; ++i) {
-        const int e = threadIdx.x + 256 * i;
+        const int e = threadIdx.x + NW * 64 * i;
         treg[i] = e < sz ? tab[D.tab + e] : 0.0;
       }
     }
@@ -84,7 +89,7 @@ k_build_basis(const DimDesc *__restrict__ dims, const double *__restrict__ ka,
     const DimDesc D = dims[l];
     if (D.tab >= 0 && bb_tab_size(D) <= kBbTab) {
 #pragma unroll
-      for (int i = 0; i < kPer; ++i) ltab[l & 1][threadIdx.x + 256 * i] = treg[i];
+      for (int i = 0; i < kPer; ++i) ltab[l & 1][threadIdx.x + NW * 64 * i] = treg[i];
     }
   };
   fetch(0);
@@ -147,9 +152,16 @@ k_getbase(DimDesc D, const double *__restrict__ ka, const double *__restrict__ k
 int launch_build_basis(obhip_basis &b) {
   ProfScope ps("build_basis");
   const uint64_t tiles = b.n_pad / kTileRows;
-  hipLaunchKernelGGL(k_build_basis, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, cur_stream(),
-                     b.md.dims.p, b.md.ka.p, b.md.kb.p, b.md.kc.p, b.md.rot.p, b.md.tab.p, b.x.p, b.n,
-                     (int)b.d, b.md.Mc, tiles, b.bm.p, b.scale.p);
+  static const int nw = getenv("OBHIP_BB_WAVES") ? atoi(getenv("OBHIP_BB_WAVES")) : 8;
+#define OB_BB(NW_)                                                                                             \
+  hipLaunchKernelGGL(k_build_basis<NW_>, dim3((unsigned)((tiles + NW_ - 1) / NW_)), dim3(NW_ * 64), 0,        \
+                     cur_stream(), b.md.dims.p, b.md.ka.p, b.md.kb.p, b.md.kc.p, b.md.rot.p, b.md.tab.p, b.x.p, \
+                     b.n, (int)b.d, b.md.Mc, tiles, b.bm.p, b.scale.p)
+  if (nw == 4)
+    OB_BB(4);
+  else
+    OB_BB(8);
+#undef OB_BB
   OB_HIP(hipGetLastError());
   return 0;
 }

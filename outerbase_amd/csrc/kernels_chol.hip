@@ -613,7 +613,7 @@ static int chol_panels_at(uint64_t p, uint64_t m) {
   static const uint64_t m8 = getenv("OBHIP_CHOL_M8") ? strtoull(getenv("OBHIP_CHOL_M8"), nullptr, 10) : 8192;
   static const uint64_t m4 = getenv("OBHIP_CHOL_M4") ? strtoull(getenv("OBHIP_CHOL_M4"), nullptr, 10) : 4096;
   if (forced) return forced;
-  if (p < 4096) return 1;
+  if (p < 3072) return 1;  // (p = 1024 / 2048: 0.421 / 0.889 ms with one panel per pass, 0.434 / 0.894 with two; 3072: 1.474 / 1.441)
   return m >= m8 ? 8 : (m >= m4 ? 4 : 2);
 }
 // (the most any pass takes: the first)
